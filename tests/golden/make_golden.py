@@ -1,0 +1,186 @@
+"""Generate golden vectors by RUNNING THE REFERENCE ITSELF (showlab/EgoVLP, /root/reference).
+
+Run once in the build container (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+Writes small .npz fixtures next to this file.  Weights and inputs are NOT stored for the
+full-size model (181 M params): they are pure functions of (key, shape, seed) from
+egovlp_amd.synth, so any implementation regenerates them bit-identically; the tiny-config
+fixture stores everything.
+
+Fixtures
+  full_b4.npz   FrozenInTime (ViT-B/16 T=4 + DistilBERT L=32 ragged mask), B=4, eval():
+                text/video embeds, CLS features, sim_matrix, NormSoftmaxLoss, EgoNCE (reference
+                class with `.cuda()` neutralised), block-0 taps (sub-sampled rows),
+                gradient slices of sentinel weights and of the embeddings.
+  tiny_video.npz  reference SpaceTimeTransformer(img 32, patch 16, dim 64, depth 2, heads 2,
+                num_frames 4) on [3,3,3,32,32] input (curr_frames 3 < num_frames 4): all tensors.
+  gather_w2.npz reference AllGather_multi under gloo, world_size 2: loss + local embedding grads.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+from egovlp_amd.synth import synth_state_dict, synth_batch  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+SENTINELS = [
+    "video_model.blocks.0.timeattn.qkv.weight",
+    "video_model.blocks.11.mlp.fc2.weight",
+    "video_model.patch_embed.proj.weight",
+    "video_model.temporal_embed",
+    "video_model.blocks.5.norm1.weight",
+    "text_model.transformer.layer.0.attention.q_lin.weight",
+    "text_model.embeddings.position_embeddings.weight",
+    "txt_proj.1.weight",
+    "vid_proj.0.bias",
+]
+
+
+def np32(t):
+    return t.detach().cpu().float().numpy()
+
+
+def make_full(mm, ml):
+    torch.manual_seed(0)
+    net = mm.FrozenInTime(
+        video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 16,
+                      "pretrained": True, "time_init": "zeros"},
+        text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+        projection="minimal", load_checkpoint="")
+    net.text_model.config._attn_implementation = "eager"
+    schema = {k: v.shape for k, v in net.state_dict().items()}
+    net.load_state_dict(synth_state_dict(schema, seed=0), strict=True)
+    net.eval()
+    B = 4
+    batch = synth_batch(B, T=4, L=32, seed=1234, ragged=True)
+    data = {"video": batch["video"], "text": batch["text"]}
+
+    taps = {}
+    blk0 = net.video_model.blocks[0]
+    h1 = blk0.timeattn.register_forward_hook(lambda m, i, o: taps.__setitem__("block0_time_output", o))
+    h2 = blk0.attn.register_forward_hook(lambda m, i, o: taps.__setitem__("block0_space_output", o))
+    h3 = blk0.register_forward_hook(lambda m, i, o: taps.__setitem__("block0_block_out", o))
+    h4 = net.text_model.embeddings.register_forward_hook(lambda m, i, o: taps.__setitem__("text_embed", o))
+    text_embeds, video_embeds = net(data)
+    for h in (h1, h2, h3, h4):
+        h.remove()
+    text_embeds.retain_grad()
+    video_embeds.retain_grad()
+    sim = mm.sim_matrix(text_embeds, video_embeds)
+    infonce = ml.NormSoftmaxLoss()(sim)
+    # EgoNCE: the reference hard-codes torch.eye(n).cuda() (model/loss.py:35) -> neutralise .cuda()
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        sim_v = mm.sim_matrix(batch["verb_vec"], batch["verb_vec"])
+        sim_n = mm.sim_matrix(batch["noun_vec"], batch["noun_vec"])
+        ego = ml.EgoNCE()(sim, sim_v, sim_n)
+    finally:
+        torch.Tensor.cuda = _cuda
+    ego.backward()
+    out = {
+        "text_embeds": np32(text_embeds), "video_embeds": np32(video_embeds), "sim": np32(sim),
+        "infonce": np32(infonce), "egonce": np32(ego), "sim_v": np32(sim_v), "sim_n": np32(sim_n),
+        "grad_text_embeds": np32(text_embeds.grad), "grad_video_embeds": np32(video_embeds.grad),
+        # sub-sampled taps: tokens 0 (CLS), 1, 197 (frame 1 first patch), 784 (last); first 64 channels
+        "tap_rows": np.array([0, 1, 197, 784]),
+    }
+    rows = [0, 1, 197, 784]
+    for k in ("block0_time_output", "block0_space_output", "block0_block_out"):
+        out[k] = np32(taps[k][:, rows, :64])
+    out["text_embed"] = np32(taps["text_embed"][:, :4, :64])
+    params = dict(net.named_parameters())
+    for name in SENTINELS:
+        g = params[name].grad
+        g2 = g.reshape(g.shape[0], -1) if g.dim() > 1 else g.reshape(1, -1)
+        out["grad:" + name] = np32(g2[:8, :64])
+        out["gradnorm:" + name] = np32(g.norm())
+    np.savez_compressed(os.path.join(HERE, "full_b4.npz"), **out)
+    print("full_b4: infonce %.6f egonce %.6f sim[%.4f,%.4f]" % (infonce.item(), ego.item(), sim.min().item(), sim.max().item()))
+
+
+def make_tiny(mv):
+    torch.manual_seed(0)
+    net = mv.SpaceTimeTransformer(img_size=32, patch_size=16, embed_dim=64, depth=2, num_heads=2,
+                                  num_frames=4, time_init="rand", num_classes=0)
+    schema = {("video_model." + k): v.shape for k, v in net.state_dict().items()}
+    sd = synth_state_dict(schema, seed=7)
+    net.load_state_dict({k[len("video_model."):]: v for k, v in sd.items()}, strict=True)
+    net.eval()
+    g = torch.Generator().manual_seed(99)
+    video = torch.randn(3, 3, 3, 32, 32, generator=g)          # curr_frames 3 < model num_frames 4
+    video.requires_grad_(False)
+    taps = {}
+    h = net.blocks[0].register_forward_hook(lambda m, i, o: taps.__setitem__("block0", o))
+    feats = net(video)
+    h.remove()
+    feats.square().sum().backward()
+    out = {"video": np32(video), "feats": np32(feats), "block0": np32(taps["block0"])}
+    for k, v in sd.items():
+        out["w:" + k] = np32(v)
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            out["g:video_model." + n] = np32(p.grad)
+    np.savez_compressed(os.path.join(HERE, "tiny_video.npz"), **out)
+    print("tiny_video: feats", tuple(feats.shape), float(feats.abs().mean()))
+
+
+def _gather_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mm, ml, te, mv = ref_import.load_reference()
+    import types
+    args = types.SimpleNamespace(world_size=world, rank=rank)
+    B = 4
+    g = torch.Generator().manual_seed(500 + rank)
+    v = torch.randn(B, 256, generator=g, requires_grad=True)
+    t = torch.randn(B, 256, generator=g, requires_grad=True)
+    b = synth_batch(B, T=1, L=4, res=2, seed=900, rank=rank)
+    va = te.AllGather_multi.apply(v, world, args)
+    ta = te.AllGather_multi.apply(t, world, args)
+    na = te.AllGather_multi.apply(b["noun_vec"], world, args)
+    vba = te.AllGather_multi.apply(b["verb_vec"], world, args)
+    sim = mm.sim_matrix(ta, va)
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    loss = ml.EgoNCE()(sim, mm.sim_matrix(vba, vba), mm.sim_matrix(na, na))
+    torch.Tensor.cuda = _cuda
+    loss.backward()
+    q.put((rank, np32(v), np32(t), np32(b["noun_vec"]), np32(b["verb_vec"]), np32(loss), np32(v.grad), np32(t.grad)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def make_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, 29611, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    [p.join() for p in procs]
+    out = {}
+    for r, v, t, n, vb, loss, gv, gt in res:
+        out.update({f"v{r}": v, f"t{r}": t, f"noun{r}": n, f"verb{r}": vb, f"loss{r}": loss, f"gv{r}": gv, f"gt{r}": gt})
+    np.savez_compressed(os.path.join(HERE, "gather_w2.npz"), **out)
+    print("gather_w2: loss", out["loss0"], out["loss1"])
+
+
+if __name__ == "__main__":
+    assert ref_import.available(), "needs /root/reference (build container only)"
+    which = sys.argv[1:] or ["tiny", "gather", "full"]
+    if "gather" in which:
+        make_gather()
+    mm, ml, te, mv = ref_import.load_reference()
+    if "tiny" in which:
+        make_tiny(mv)
+    if "full" in which:
+        make_full(mm, ml)

@@ -1,0 +1,112 @@
+"""Pin the CPU oracle (oracle/egovlp_oracle.py) against outputs of the REFERENCE ITSELF
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egovlp_amd.synth import synth_state_dict, synth_batch
+from oracle import egovlp_oracle as O
+
+
+def rel(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def full_schema():
+    from egovlp_amd.model.schema import state_dict_schema
+    return state_dict_schema()
+
+
+@pytest.fixture(scope="module")
+def full(golden_dir):
+    g = np.load(os.path.join(golden_dir, "full_b4.npz"))
+    sd = synth_state_dict(full_schema(), seed=0)
+    sd = {k: v.requires_grad_(True) for k, v in sd.items()}
+    batch = synth_batch(4, T=4, L=32, seed=1234, ragged=True)
+    taps = {}
+    te, ve = O.frozen_in_time(batch, sd, O.VideoCfg(), O.TextCfg(), taps=taps)
+    return g, sd, batch, te, ve, taps
+
+
+def test_full_embeddings_match_reference(full):
+    g, sd, batch, te, ve, taps = full
+    assert rel(te, g["text_embeds"]) < 2e-5
+    assert rel(ve, g["video_embeds"]) < 2e-5
+
+
+def test_full_taps_match_reference(full):
+    g, sd, batch, te, ve, taps = full
+    rows = list(g["tap_rows"])
+    for k in ("block0_time_output", "block0_space_output", "block0_block_out"):
+        assert rel(taps[k][:, rows, :64], g[k]) < 2e-5, k
+    assert rel(taps["text_embed"][:, :4, :64], g["text_embed"]) < 2e-5
+
+
+def test_full_losses_and_grads_match_reference(full):
+    g, sd, batch, te, ve, taps = full
+    sim = O.sim_matrix(te, ve)
+    assert rel(sim, g["sim"]) < 2e-5
+    assert abs(float(O.norm_softmax_loss(sim)) - float(g["infonce"])) < 2e-5
+    loss, _ = O.egoclip_loss(te, ve, batch["noun_vec"], batch["verb_vec"])
+    assert abs(float(loss) - float(g["egonce"])) < 2e-5
+    assert float(g["egonce"]) < float(g["infonce"]) - 0.1      # the fixture has off-diagonal positives
+    te.retain_grad(); ve.retain_grad()
+    loss.backward()
+    assert rel(te.grad, g["grad_text_embeds"]) < 1e-4
+    assert rel(ve.grad, g["grad_video_embeds"]) < 1e-4
+    for key in g.files:
+        if not key.startswith("grad:"):
+            continue
+        name = key[5:]
+        gr = sd[name].grad
+        g2 = gr.reshape(gr.shape[0], -1) if gr.dim() > 1 else gr.reshape(1, -1)
+        assert rel(g2[:8, :64], g[key]) < 2e-4, name
+        assert abs(float(gr.norm()) / float(g["gradnorm:" + name]) - 1) < 2e-4, name
+
+
+def test_tiny_video_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_video.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("w:")}
+    cfg = O.VideoCfg(img_size=32, patch_size=16, embed_dim=64, depth=2, num_heads=2, num_frames=4)
+    taps = {}
+    feats = O.video_encoder(torch.from_numpy(g["video"]), sd, cfg, taps=taps)
+    assert rel(feats, g["feats"]) < 1e-5
+    assert rel(taps["block0_block_out"], g["block0"]) < 1e-5
+    feats.square().sum().backward()
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel(sd[k[2:]].grad, g[k]) < 1e-4, k
+
+
+def test_gather_w2_reference_semantics(golden_dir):
+    """Reference AllGather_multi (trainer/trainer_egoclip.py:11-27): every rank sees the
+    identical global loss; the local grad equals the local rows of the global grad."""
+    g = np.load(os.path.join(golden_dir, "gather_w2.npz"))
+    assert float(g["loss0"]) == pytest.approx(float(g["loss1"]), rel=1e-6)
+    v = torch.cat([torch.from_numpy(g["v0"]), torch.from_numpy(g["v1"])]).requires_grad_(True)
+    t = torch.cat([torch.from_numpy(g["t0"]), torch.from_numpy(g["t1"])]).requires_grad_(True)
+    noun = torch.cat([torch.from_numpy(g["noun0"]), torch.from_numpy(g["noun1"])])
+    verb = torch.cat([torch.from_numpy(g["verb0"]), torch.from_numpy(g["verb1"])])
+    loss, _ = O.egoclip_loss(t, v, noun, verb)
+    assert float(loss) == pytest.approx(float(g["loss0"]), rel=1e-5)
+    loss.backward()
+    B = 4
+    for r in range(2):
+        assert rel(v.grad[r * B:(r + 1) * B], g[f"gv{r}"]) < 1e-4
+        assert rel(t.grad[r * B:(r + 1) * B], g[f"gt{r}"]) < 1e-4
+
+
+def test_adamw_restatement_matches_published_algorithm():
+    """transformers==4.2.1 AdamW differs from torch.optim.AdamW only in where eps enters
+    (sqrt(v)+eps BEFORE bias correction); check the restatement against a scalar hand roll."""
+    torch.manual_seed(0)
+    p = torch.randn(5); g = torch.randn(5); m = torch.zeros(5); v = torch.zeros(5)
+    p0 = p.clone()
+    O.adamw_step(p, g, m, v, step=1, lr=1e-2)
+    m1 = 0.1 * g; v1 = 0.001 * g * g
+    ref = p0 - 1e-2 * (1 - 0.999) ** 0.5 / (1 - 0.9) * m1 / (v1.sqrt() + 1e-6)
+    assert torch.allclose(p, ref, rtol=1e-6, atol=1e-7)
