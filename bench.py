@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""EgoClip pre-training step benchmark (BASELINE.json metric: clip-pairs/sec, whole node).
+
+    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path = trainer/trainer_egoclip.py:123-141 restated in
+egovlp_amd.trainer.trainer_egoclip.egoclip_step: zero_grad, dual-encoder forward, embedding all-gather (RCCL),
+similarity + EgoNCE, backward (DDP gradient all-reduce overlapped), AdamW.  Workload = BASELINE configs[1]/[2]:
+synthetic EgoClip batch, 4 x 3 x 224 x 224 frames + 32-token text, ViT-B/16 + DistilBERT, B = 32 per GPU,
+random-init weights (no network for checkpoints), inputs resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work per clip-pair: 2*MACs, forward; training step = 3x
+FWD_GFLOP_PER_PAIR = {("base_patch16_224", 4): 187.4, ("base_patch16_224", 16): 741.9, ("large_patch14_224", 4): 856.0}
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip-level table
+
+
+def build_model(arch, model_frames):
+    from egovlp_amd.model.model import FrozenInTime
+    from egovlp_amd.synth import synth_state_dict
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": arch, "num_frames": model_frames,
+                                   "pretrained": True, "time_init": "rand"},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+                     projection="minimal", load_checkpoint="")
+    m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=0))
+    return m
+
+
+def cpu_baseline(B=8, T=4, L=32):
+    """The oracle (fp32 PyTorch-on-CPU restatement of the reference, pinned to reference outputs) timed on the
+    host cores of this box: one fwd+bwd+loss of the same workload at a bounded batch."""
+    from egovlp_amd.model.schema import state_dict_schema
+    from egovlp_amd.synth import synth_batch, synth_state_dict
+    from oracle import egovlp_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(state_dict_schema(), seed=0).items()}
+
+    def one(b):
+        batch = synth_batch(b, T=T, L=L, seed=7)
+        t0 = time.perf_counter()
+        te, ve = O.frozen_in_time(batch, sd, O.VideoCfg(), O.TextCfg())
+        loss, _ = O.egoclip_loss(te, ve, batch["noun_vec"], batch["verb_vec"])
+        loss.backward()
+        return time.perf_counter() - t0
+
+    one(1)                       # page in / warm the allocator
+    dt = one(B)
+    return {"value": round(B / dt, 4), "unit": "clip-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 fwd+bwd+EgoNCE step of the CPU oracle at B={B} (T={T}, L={L}), {dt:.1f} s, "
+                      f"{os.cpu_count()} logical cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--arch", default="base_patch16_224")
+    ap.add_argument("--precision", default=os.environ.get("EGOVLP_PRECISION", "bf16x3"),
+                    help="bf16x3 (parity mode, fp32-grade) | bf16 (single pass) | mixed (fwd bf16x3, bwd bf16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    from egovlp_amd import ops
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.optim import AdamW
+    from egovlp_amd.synth import synth_batch
+    from egovlp_amd.trainer.trainer_egoclip import egoclip_step
+
+    if args.precision == "mixed":
+        ops.Precision.set("bf16x3", "bf16")
+    else:
+        ops.Precision.set(args.precision)
+
+    B, T, L = args.batch, args.frames, 32
+    model = build_model(args.arch, 16).cuda().train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=100,
+                                                        gradient_as_bucket_view=True)
+    opt = AdamW(model.parameters(), lr=3e-5)
+    loss_fn = EgoNCE()
+    batch = synth_batch(B, T=T, L=L, seed=1234, rank=rank)
+    data = {"video": batch["video"].cuda(), "text": {k: v.cuda() for k, v in batch["text"].items()},
+            "noun_vec": batch["noun_vec"].cuda(), "verb_vec": batch["verb_vec"].cuda()}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        egoclip_step(net, loss_fn, opt, data, world, rank)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = egoclip_step(net, loss_fn, opt, data, world, rank)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    ms = dt / args.steps * 1e3
+    pairs = world * B * args.steps / dt
+    loss_val = float(loss)
+
+    # ---- dominant-kernel roofline: the bf16-MFMA GEMM.  HIP events bracket every egv_gemm_nt launch on the stream
+    # the kernels run on, in a separate instrumented pass of the same step (so the timed value above is untouched).
+    roof = None
+    if not args.no_kernel_timing:
+        ops.KERNEL_TIMER = ops.KernelTimer()
+        for _ in range(2):
+            egoclip_step(net, loss_fn, opt, data, world, rank)
+        torch.cuda.synchronize()
+        kt = ops.KERNEL_TIMER.summary()
+        ops.KERNEL_TIMER = None
+        g = kt["egv_gemm_nt"]
+        ach = g["flops"] / g["seconds"] / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (egv_gemm_nt)", "achieved": round(ach, 1),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": None, "launches_per_step": g["launches"] // 2,
+                "avg_launch_us": round(g["seconds"] / g["launches"] * 1e6, 2),
+                "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3),
+                "gemm_ms_per_step": round(g["seconds"] / 2 * 1e3, 3),
+                "mfma_issue_tflops": round(ach * (3 if ops.Precision.fwd_passes == 3 and ops.Precision.bwd_passes == 3 else 1), 1)
+                if args.precision != "mixed" else None,
+                "note": "achieved = algorithmic 2*M*N*K of all GEMM launches of a step / their summed HIP-event time; "
+                        "bf16x3 issues 3 MFMA passes per algorithmic product (ceiling 1/3 of peak)"}
+    key = (args.arch, T)
+    step_frac = None
+    if key in FWD_GFLOP_PER_PAIR:
+        step_frac = pairs / world * FWD_GFLOP_PER_PAIR[key] * 3 * 1e9 / (PEAK_BF16_TFLOPS * 1e12)
+
+    out = {
+        "metric": "clip-pairs/sec (whole node), 4f/224^2 ViT-B + 32-tok text, B=32/GPU, train step (fwd+gather+EgoNCE+bwd+AdamW)",
+        "value": round(pairs, 2), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
+        "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
+                               f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
+                   "parallelism": f"dp{world}", "precision": "/".join(ops.Precision.name())},
+        "loss": round(loss_val, 5),
+        "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
+    }
+    if roof is not None:
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

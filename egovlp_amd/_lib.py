@@ -1,0 +1,94 @@
+"""ctypes binding of libegovlp_hip.so (include/egovlp_hip.h) -- the only native boundary of the package.
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, every op
+raises.  A product path that silently ran on PyTorch eager kernels (or on the CPU oracle)
+would void the parity claims.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("EGOVLP_HIP_LIB", os.path.join(_HERE, "libegovlp_hip.so"))  # override: diagnostics only
+
+c_p = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+
+
+class GemmDesc(C.Structure):
+    """egv_gemm_desc (include/egovlp_hip.h)."""
+    _fields_ = [
+        ("a_hi", c_p), ("a_lo", c_p), ("lda", i64),
+        ("b_hi", c_p), ("b_lo", c_p), ("ldb", i64),
+        ("M", i32), ("N", i32), ("K", i32), ("passes", i32),
+        ("alpha", f32), ("act", i32),
+        ("bias", c_p),
+        ("residual", c_p), ("ldr", i64),
+        ("aux_in", c_p), ("aux_out", c_p), ("ldaux", i64),
+        ("out_f32", c_p), ("ldo", i64),
+        ("out_hi", c_p), ("out_lo", c_p), ("ldoh", i64),
+        ("ksplit", i32), ("accumulate", i32),
+        ("partial", c_p),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/egovlp_hip.h one to one (tests/test_abi.py checks it)
+PROTOTYPES = {
+    "egv_gemm_nt": (i32, [C.POINTER(GemmDesc), c_p]),
+    "egv_split_f32": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p, i64, c_p, c_p]),
+    "egv_transpose_planes": (i32, [c_p, c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p]),
+    "egv_layernorm_fwd": (i32, [c_p, c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
+    "egv_layernorm_bwd_parts": (i32, [i32]),
+    "egv_layernorm_bwd": (i32, [c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p, c_p]),
+    "egv_patch_gather": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, i64, c_p]),
+    "egv_assemble_tokens": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p]),
+    "egv_assemble_tokens_bwd": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),
+    "egv_divided_attn_fwd": (i32, [c_p, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
+    "egv_divided_attn_bwd": (i32, [c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p]),
+    "egv_embed_fwd": (i32, [c_p, c_p, c_p, i32, i32, i32, c_p, c_p]),
+    "egv_embed_bwd": (i32, [c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p]),
+    "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
+    "egv_text_attn_bwd": (i32, [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),
+    "egv_egonce_fwd_bwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, f32, f32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "egv_egonce_work_floats": (i64, [i32, i32]),
+    "egv_sim_matrix_fwd": (i32, [c_p, c_p, i32, i32, i32, f32, c_p, c_p, c_p, c_p, c_p]),
+    "egv_sim_matrix_bwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, f32, c_p, c_p, c_p]),
+    "egv_egonce_from_sim": (i32, [c_p, c_p, c_p, i32, f32, i32, i32, c_p, c_p, c_p, c_p]),
+    "egv_adamw_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, f32, f32, f32, f32, f32, i32, i32, f32, c_p]),
+    "egv_relu_split": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p]),
+    "egv_version": (i32, []),
+}
+
+_lib = None
+
+
+class EgovlpHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises EgovlpHipError if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EgovlpHipError(
+                f"{LIB_PATH} not found: build it with `make -C egovlp_amd/csrc` (or __graft_entry__.build()). "
+                "egovlp_amd has no CPU / eager fallback by design.")
+        try:
+            h = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise EgovlpHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        if rc == 1:
+            raise EgovlpHipError(f"{what}: invalid argument (nothing was launched)")
+        raise EgovlpHipError(f"{what}: HIP launch failed, hipError_t={rc - 2}")

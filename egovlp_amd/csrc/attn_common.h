@@ -1,0 +1,161 @@
+// Shared pieces of the MFMA attention kernels (space attention of the SpaceTimeTransformer and the
+// DistilBERT masked MHA).  Head dim is fixed at 64 (ViT-B/16, ViT-L/14 and DistilBERT all use 64).
+//
+// LDS image of a [rows][64] operand: bf16 planes with 128-B rows, 16-B chunks XOR-swizzled by (row & 7):
+//   byte(row, col) = row*128 + (((col >> 3) ^ (row & 7)) << 4) + (col & 7)*2
+// This one image serves BOTH MFMA read patterns conflict-free:
+//   * contraction along columns (d):  ds_read_b128, lane -> row (l&15), chunk (l>>4) + 4*ks
+//   * contraction along rows (keys / queries): ds_read_b64_tr_b16 (CDNA4 transpose read): each 16-lane
+//     group reads a [4 rows][16 cols] block and lane i receives column i, so no transposed copy of
+//     K / V / Q / dO ever exists in LDS or HBM.
+// k-index convention for row-contraction fragments (A and B operands use the same one, which is all an
+// MFMA needs): element j of lane-group g covers row  r0 + 4g + j  (j < 4)  and  r0 + 16 + 4g + (j-4).
+// It is chosen so that the C-layout of a preceding 16x16 MFMA pair (rows 4g..4g+3 of two fragments) IS
+// the B operand of the next MFMA without any cross-lane movement.
+#pragma once
+#include "common.h"
+
+#define ATT_D 64
+#define ATT_ROW_BYTES 128
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ int att_off(int row, int col) {
+  return row * ATT_ROW_BYTES + ((((col >> 3) ^ (row & 7)) << 4) | ((col & 7) << 1));
+}
+
+// Stage `nrows` rows (zero-filled up to `prows`) of a [*, 64] fp32 operand into swizzled split planes.
+// row_ptr(r) returns the global pointer of row r (64 contiguous floats).  256 threads.
+template <typename RowPtr>
+__device__ __forceinline__ void att_stage(char* hi, char* lo, int nrows, int prows, float scale, RowPtr row_ptr) {
+  for (int t = threadIdx.x; t < prows * 8; t += 256) {
+    const int row = t >> 3, chunk = t & 7;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (row < nrows) {
+      const float* p = row_ptr(row) + chunk * 8;
+      a = *(const f32x4_t*)p;
+      b = *(const f32x4_t*)(p + 4);
+    }
+    bf16_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      split_bf16(a[e] * scale, h[e], l[e]);
+      split_bf16(b[e] * scale, h[4 + e], l[4 + e]);
+    }
+    const int off = row * ATT_ROW_BYTES + ((chunk ^ (row & 7)) << 4);
+    *(u32x4_t*)(hi + off) = (u32x4_t){pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
+    if (lo) *(u32x4_t*)(lo + off) = (u32x4_t){pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])};
+  }
+}
+
+// column-contraction fragment: lane (row r0 + (l&15), cols 8*((l>>4) + 4*ks) .. +7)
+__device__ __forceinline__ bf16x8_t att_frag_cols(const char* plane, int r0, int ks, int lane) {
+  const int row = r0 + (lane & 15);
+  const int chunk = (lane >> 4) + 4 * ks;
+  return *(const bf16x8_t*)(plane + row * ATT_ROW_BYTES + ((chunk ^ (row & 7)) << 4));
+}
+
+// row-contraction fragment via the hardware transpose read: lane (g = l>>4, c = l&15) receives column
+// col0 + c at rows r0+4g..r0+4g+3 (elements 0..3) and r0+16+4g..+3 (elements 4..7).
+__device__ __forceinline__ bf16x8_t att_frag_rows(const char* plane, int r0, int col0, int lane) {
+  const int g = lane >> 4, p = lane & 15;
+  const int col = col0 + ((p & 3) << 2);
+  const int ra = r0 + 4 * g + (p >> 2);
+  const int rb = ra + 16;
+#if defined(EGV_NO_TR_READ)
+  // reference path (slow, 8 scalar LDS reads) used to validate the transpose-read semantics on hardware
+  bf16x8_t out;
+  const int c = col0 + p;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned short a = *(const unsigned short*)(plane + att_off(r0 + 4 * g + j, c));
+    const unsigned short b = *(const unsigned short*)(plane + att_off(r0 + 16 + 4 * g + j, c));
+    out[j] = __builtin_bit_cast(__bf16, a);
+    out[4 + j] = __builtin_bit_cast(__bf16, b);
+  }
+  return out;
+#else
+  const s16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(plane + att_off(ra, col)));
+  const s16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(plane + att_off(rb, col)));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+  return __builtin_bit_cast(bf16x8_t, z);
+#endif
+}
+
+// 8 fp32 -> split bf16x8 pair
+__device__ __forceinline__ void att_split8(const float* v, bf16x8_t& hi, bf16x8_t& lo) {
+  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+  u16x8_t h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bf16_t a, b;
+    split_bf16(v[e], a, b);
+    h[e] = a;
+    l[e] = b;
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, l);
+}
+
+// B-operand fragment straight from global: lane -> row (l&15) given by `p` (already row-resolved),
+// cols 8*((l>>4) + 4*ks) .. +7, scaled, split.
+__device__ __forceinline__ void att_gfrag(const float* rowp, int ks, int lane, float scale, bf16x8_t& hi, bf16x8_t& lo) {
+  const float* p = rowp + ((lane >> 4) + 4 * ks) * 8;
+  const f32x4_t a = *(const f32x4_t*)p;
+  const f32x4_t b = *(const f32x4_t*)(p + 4);
+  float v[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale,
+                b[0] * scale, b[1] * scale, b[2] * scale, b[3] * scale};
+  att_split8(v, hi, lo);
+}
+
+template <int PASSES>
+__device__ __forceinline__ f32x4_t att_mma(bf16x8_t ah, bf16x8_t al, bf16x8_t bh, bf16x8_t bl, f32x4_t c) {
+  if (PASSES == 3) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+
+// Geometry of one attention "group" (the rows that attend to each other).
+//  MODE_SPACE: qkv [B,S,3,H,64]; group = (b, f, h); nq = n queries (tokens 1+f*n+i), nk = n+1 keys
+//              (key 0 = CLS token 0, key j = token f*n + j)            model/video_transformer.py:114-124
+//  MODE_TEXT : separate q,k,v [B,L,H*64]; group = (b, h); nq = nk = L; key j masked if mask[b,j] == 0
+enum { MODE_SPACE = 0, MODE_TEXT = 2 };
+
+struct AttGeom {
+  const float* q;
+  const float* k;
+  const float* v;
+  long tok_stride;   // floats between consecutive tokens in q/k/v
+  int B, T, n, H, S; // S = tokens per batch item (1+T*n or L)
+  int nq, nk;
+  const long long* mask;  // MODE_TEXT only
+};
+
+template <int MODE>
+struct AttGroup {
+  int b, f, h;
+  long tok0;  // first token of batch item b
+  __device__ __forceinline__ AttGroup(const AttGeom& g, int gid) {
+    h = gid % g.H;
+    int r = gid / g.H;
+    if (MODE == MODE_SPACE) {
+      f = r % g.T;
+      b = r / g.T;
+    } else {
+      f = 0;
+      b = r;
+    }
+    tok0 = (long)b * g.S;
+  }
+  __device__ __forceinline__ long q_tok(const AttGeom& g, int i) const {
+    return MODE == MODE_SPACE ? tok0 + 1 + (long)f * g.n + i : tok0 + i;
+  }
+  __device__ __forceinline__ long k_tok(const AttGeom& g, int j) const {
+    return MODE == MODE_SPACE ? (j == 0 ? tok0 : tok0 + (long)f * g.n + j) : tok0 + j;
+  }
+};

@@ -1,0 +1,320 @@
+// Fused attention backward on bf16 MFMA (space attention / DistilBERT MHA), flash-style recomputation:
+// probabilities are rebuilt from the saved log-sum-exp, nothing of size [q, k] ever reaches HBM.
+//
+// Two kernels per group because an MFMA contracts over the index that runs along lane-groups/elements:
+//   dQ  kernel: wave owns 16-query tiles; S^T, dP^T with keys in registers -> contraction over KEYS
+//               (dQ^T = K^T . dS^T, K^T fragments by transpose-read from the row-major K image);
+//               also emits delta[q] = sum_k P dP for the second kernel.
+//   dKV kernel: wave owns 16-key fragments; S, dP with queries in registers -> contraction over QUERIES
+//               (dV^T = dO^T . P, dK^T = Q^T . dS, transposed fragments again by transpose-read of the
+//               row-major Q / dO images in LDS).
+// CLS-key gradients of the space mode are shared by the T frame-groups of a clip: atomicAdd.
+#include "attn_common.h"
+#include "egovlp_hip.h"
+
+namespace {
+
+struct AttGrad {
+  float* dq;
+  float* dk;
+  float* dv;
+  long tok_stride;     // floats between tokens in dq/dk/dv
+  const float* d_out;  // [B, S, H*64] fp32
+  long do_stride;
+  const float* lse;    // [B, H, S]
+  float* delta;        // [B, H, S] workspace (written by dQ kernel, read by dKV kernel)
+};
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int MODE, int NKF, int PASSES>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const AttGrad gr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKP = NKF * 16;
+  constexpr int PLANE = NKP * ATT_ROW_BYTES;
+  char* k_hi = smem;
+  char* v_hi = smem + PLANE;
+  char* k_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
+  char* v_lo = (PASSES == 3) ? smem + 3 * PLANE : nullptr;
+  float* kbias = (float*)(smem + ((PASSES == 3) ? 4 : 2) * PLANE);
+
+  const AttGroup<MODE> grp(g, blockIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long hoff = (long)grp.h * ATT_D;
+
+  att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  for (int j = threadIdx.x; j < NKP; j += 256) {
+    float bias = (j < g.nk) ? 0.f : -1e30f;
+    if (MODE == MODE_TEXT && j < g.nk && g.mask[(long)grp.b * g.S + j] == 0) bias = -1e30f;
+    kbias[j] = bias;
+  }
+  __syncthreads();
+
+  const int gq = lane >> 4;
+  const int ntiles = (g.nq + 15) / 16;
+  for (int qt = wave; qt < ntiles; qt += 4) {
+    asm volatile("" ::: "memory");  // K/V fragments are loop-invariant: stop LICM from hoisting ~900 VGPRs of them
+    const int qi = qt * 16 + (lane & 15);
+    const int qc = min(qi, g.nq - 1);
+    const long tok = grp.q_tok(g, qc);
+    const float* qrow = g.q + tok * g.tok_stride + hoff;
+    const float* grow = gr.d_out + tok * gr.do_stride + hoff;
+    bf16x8_t qh[2], ql[2], gh[2], gl[2];
+    att_gfrag(qrow, 0, lane, 0.125f, qh[0], ql[0]);
+    att_gfrag(qrow, 1, lane, 0.125f, qh[1], ql[1]);
+    att_gfrag(grow, 0, lane, 1.0f, gh[0], gl[0]);
+    att_gfrag(grow, 1, lane, 1.0f, gh[1], gl[1]);
+    const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (tok - grp.tok0);
+    const float L = gr.lse[lrow];
+
+    f32x4_t p[NKF], dp[NKF];
+    float delta = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < NKF; ++kf) {
+      f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+      f32x4_t d = s;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
+        bf16x8_t al = ah;
+        if (PASSES == 3) al = att_frag_cols(k_lo, kf * 16, ks, lane);
+        s = att_mma<PASSES>(ah, al, qh[ks], ql[ks], s);
+        const bf16x8_t bh = att_frag_cols(v_hi, kf * 16, ks, lane);
+        bf16x8_t bl = bh;
+        if (PASSES == 3) bl = att_frag_cols(v_lo, kf * 16, ks, lane);
+        d = att_mma<PASSES>(bh, bl, gh[ks], gl[ks], d);
+      }
+      const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[kf][r] = __expf(s[r] + kb[r] - L);
+        delta += p[kf][r] * d[r];
+      }
+      dp[kf] = d;
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+
+    f32x4_t dq[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) dq[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NKF / 2; ++c) {
+      float dsv[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dsv[r] = p[2 * c][r] * (dp[2 * c][r] - delta);
+        dsv[4 + r] = p[2 * c + 1][r] * (dp[2 * c + 1][r] - delta);
+      }
+      bf16x8_t sh, sl;
+      att_split8(dsv, sh, sl);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8_t kh = att_frag_rows(k_hi, 32 * c, df * 16, lane);
+        bf16x8_t kl = kh;
+        if (PASSES == 3) kl = att_frag_rows(k_lo, 32 * c, df * 16, lane);
+        dq[df] = att_mma<PASSES>(kh, kl, sh, sl, dq[df]);
+      }
+    }
+    if (qi < g.nq) {
+      float* out = gr.dq + tok * gr.tok_stride + hoff;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) *(f32x4_t*)(out + df * 16 + 4 * gq) = dq[df] * 0.125f;
+      if (gq == 0) gr.delta[lrow] = delta;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- dKV
+template <int MODE, int NQF, int PASSES>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, const AttGrad gr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NQP = NQF * 16;
+  constexpr int PLANE = NQP * ATT_ROW_BYTES;
+  char* q_hi = smem;
+  char* o_hi = smem + PLANE;
+  char* q_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
+  char* o_lo = (PASSES == 3) ? smem + 3 * PLANE : nullptr;
+  float* lse_s = (float*)(smem + ((PASSES == 3) ? 4 : 2) * PLANE);
+  float* del_s = lse_s + NQP;
+
+  const AttGroup<MODE> grp(g, blockIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long hoff = (long)grp.h * ATT_D;
+
+  att_stage(q_hi, q_lo, g.nq, NQP, 0.125f, [&](int r) { return g.q + grp.q_tok(g, r) * g.tok_stride + hoff; });
+  att_stage(o_hi, o_lo, g.nq, NQP, 1.0f, [&](int r) { return gr.d_out + grp.q_tok(g, r) * gr.do_stride + hoff; });
+  for (int i = threadIdx.x; i < NQP; i += 256) {
+    float L = 1e30f, dl = 0.f;  // padded query rows: P = exp(s - 1e30) = 0
+    if (i < g.nq) {
+      const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (grp.q_tok(g, i) - grp.tok0);
+      L = gr.lse[lrow];
+      dl = gr.delta[lrow];
+    }
+    lse_s[i] = L;
+    del_s[i] = dl;
+  }
+  __syncthreads();
+
+  const int gq = lane >> 4;
+  const int nkfrags = (g.nk + 15) / 16;
+  for (int kf = wave; kf < nkfrags; kf += 4) {
+    const int kj = kf * 16 + (lane & 15);
+    const int kc = min(kj, g.nk - 1);
+    const long ktok = grp.k_tok(g, kc);
+    const float* krow = g.k + ktok * g.tok_stride + hoff;
+    const float* vrow = g.v + ktok * g.tok_stride + hoff;
+    bf16x8_t kh[2], kl[2], vh[2], vl[2];
+    att_gfrag(krow, 0, lane, 1.0f, kh[0], kl[0]);
+    att_gfrag(krow, 1, lane, 1.0f, kh[1], kl[1]);
+    att_gfrag(vrow, 0, lane, 1.0f, vh[0], vl[0]);
+    att_gfrag(vrow, 1, lane, 1.0f, vh[1], vl[1]);
+    float kb = (kj < g.nk) ? 0.f : -1e30f;
+    if (MODE == MODE_TEXT && kj < g.nk && g.mask[(long)grp.b * g.S + kj] == 0) kb = -1e30f;
+
+    f32x4_t dk[4], dv[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      dk[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      dv[df] = dk[df];
+    }
+#pragma unroll 1
+    for (int c = 0; c < NQF / 2; ++c) {
+      float pv[8], dsv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int r0 = 32 * c + 16 * t;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        f32x4_t d = s;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8_t ah = att_frag_cols(q_hi, r0, ks, lane);
+          bf16x8_t al = ah;
+          if (PASSES == 3) al = att_frag_cols(q_lo, r0, ks, lane);
+          s = att_mma<PASSES>(ah, al, kh[ks], kl[ks], s);
+          const bf16x8_t bh = att_frag_cols(o_hi, r0, ks, lane);
+          bf16x8_t bl = bh;
+          if (PASSES == 3) bl = att_frag_cols(o_lo, r0, ks, lane);
+          d = att_mma<PASSES>(bh, bl, vh[ks], vl[ks], d);
+        }
+        const f32x4_t L4 = *(const f32x4_t*)(lse_s + r0 + 4 * gq);
+        const f32x4_t D4 = *(const f32x4_t*)(del_s + r0 + 4 * gq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __expf(s[r] + kb - L4[r]);
+          pv[4 * t + r] = pr;
+          dsv[4 * t + r] = pr * (d[r] - D4[r]);
+        }
+      }
+      bf16x8_t ph, pl, sh, sl;
+      att_split8(pv, ph, pl);
+      att_split8(dsv, sh, sl);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8_t gh = att_frag_rows(o_hi, 32 * c, df * 16, lane);
+        bf16x8_t gl = gh;
+        if (PASSES == 3) gl = att_frag_rows(o_lo, 32 * c, df * 16, lane);
+        dv[df] = att_mma<PASSES>(gh, gl, ph, pl, dv[df]);
+        const bf16x8_t qh = att_frag_rows(q_hi, 32 * c, df * 16, lane);
+        bf16x8_t ql = qh;
+        if (PASSES == 3) ql = att_frag_rows(q_lo, 32 * c, df * 16, lane);
+        dk[df] = att_mma<PASSES>(qh, ql, sh, sl, dk[df]);
+      }
+    }
+    if (kj < g.nk) {
+      float* okp = gr.dk + ktok * gr.tok_stride + hoff;
+      float* ovp = gr.dv + ktok * gr.tok_stride + hoff;
+      const bool shared_cls = (MODE == MODE_SPACE) && (kj == 0);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const int d = df * 16 + 4 * gq;
+        if (shared_cls) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(okp + d + r, dk[df][r]);
+            atomicAdd(ovp + d + r, dv[df][r]);
+          }
+        } else {
+          *(f32x4_t*)(okp + d) = dk[df];
+          *(f32x4_t*)(ovp + d) = dv[df];
+        }
+      }
+    }
+  }
+}
+
+template <int MODE, int NF>
+int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hipStream_t s) {
+  const int planes = passes == 3 ? 4 : 2;
+  const size_t lds = (size_t)planes * NF * 16 * ATT_ROW_BYTES + 2 * NF * 16 * sizeof(float);
+  if (passes == 3) {
+    auto k1 = attn_bwd_dq_kernel<MODE, NF, 3>;
+    auto k2 = attn_bwd_dkv_kernel<MODE, NF, 3>;
+    (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
+    EGV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+  } else {
+    auto k1 = attn_bwd_dq_kernel<MODE, NF, 1>;
+    auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
+    (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
+    EGV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+  }
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+template <int MODE>
+int dispatch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hipStream_t s) {
+  const int m = g.nk > g.nq ? g.nk : g.nq;  // one fragment count covers both the key and the query extent
+  if (m <= 32) return launch_bwd<MODE, 2>(g, gr, ngroups, passes, s);
+  if (m <= 64) return launch_bwd<MODE, 4>(g, gr, ngroups, passes, s);
+  if (m <= 224) return launch_bwd<MODE, 14>(g, gr, ngroups, passes, s);
+  if (m <= 288) return launch_bwd<MODE, 18>(g, gr, ngroups, passes, s);
+  return EGV_ERR_ARG;
+}
+
+}  // namespace
+
+int egv_attn_space_bwd_impl(const float* qkv, const float* d_out, const float* lse, float* delta, int B, int T, int n,
+                            int H, int passes, float* dqkv, hipStream_t s) {
+  AttGeom g;
+  const long HD = (long)H * ATT_D;
+  g.q = qkv; g.k = qkv + HD; g.v = qkv + 2 * HD;
+  g.tok_stride = 3 * HD;
+  g.B = B; g.T = T; g.n = n; g.H = H; g.S = 1 + T * n;
+  g.nq = n; g.nk = n + 1;
+  g.mask = nullptr;
+  AttGrad gr;
+  gr.dq = dqkv; gr.dk = dqkv + HD; gr.dv = dqkv + 2 * HD;
+  gr.tok_stride = 3 * HD;
+  gr.d_out = d_out; gr.do_stride = HD;
+  gr.lse = lse; gr.delta = delta;
+  return dispatch_bwd<MODE_SPACE>(g, gr, B * T * H, passes, s);
+}
+
+extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v, const int64_t* mask,
+                                 const float* d_out, const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
+                                 float* dq, float* dk, float* dv, float* delta_work, void* stream) {
+  if (!q || !k || !v || !mask || !d_out || !lse || !dq || !dk || !dv || !delta_work) return EGV_ERR_ARG;
+  if (passes != 1 && passes != 3) return EGV_ERR_ARG;
+  AttGeom g;
+  const long HD = (long)H * ATT_D;
+  g.q = q; g.k = k; g.v = v;
+  g.tok_stride = HD;
+  g.B = B; g.T = 1; g.n = L; g.H = H; g.S = L;
+  g.nq = L; g.nk = L;
+  g.mask = (const long long*)mask;
+  AttGrad gr;
+  gr.dq = dq; gr.dk = dk; gr.dv = dv;
+  gr.tok_stride = HD;
+  gr.d_out = d_out; gr.do_stride = HD;
+  gr.lse = lse; gr.delta = delta_work;
+  return dispatch_bwd<MODE_TEXT>(g, gr, B * H, passes, (hipStream_t)stream);
+}

@@ -1,0 +1,190 @@
+// Fused attention forward on bf16 MFMA for the two "dense" attention shapes of the hot path:
+//   space attention of the SpaceTimeTransformer (model/video_transformer.py:114-133: per (b, frame, head)
+//   196 queries x (CLS + 196) keys) and DistilBERT's masked MHA (L x L per (b, head)).
+//
+// One workgroup (4 waves) per group.  The whole K and V of a group (<= 288 keys x 64) live in LDS as
+// swizzled split-bf16 planes, so scores never touch HBM (the reference materialises a 237 MB score
+// tensor per block) and no online-softmax rescaling is needed: a wave takes a 16-query
+// tile, computes S^T = K.Q^T for ALL keys into registers, does the row softmax with two wave shuffles
+// (the key axis is register-local + lane groups 16/32 apart), and feeds P^T straight back as the B
+// operand of O^T = V^T.P^T -- V^T fragments come from the row-major V image through the CDNA4
+// transpose read.  q/k/v are read directly out of the fused qkv buffer with index arithmetic; none
+// of the reference's rearrange / repeat / cat copies exist.
+#include "attn_common.h"
+#include "egovlp_hip.h"
+
+namespace {
+
+template <int MODE, int NKF, int PASSES>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
+                                                       bf16_t* __restrict__ out_lo, long out_stride,
+                                                       float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKP = NKF * 16;
+  constexpr int PLANE = NKP * ATT_ROW_BYTES;
+  char* k_hi = smem;
+  char* v_hi = smem + PLANE;
+  char* k_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
+  char* v_lo = (PASSES == 3) ? smem + 3 * PLANE : nullptr;
+  float* kbias = (float*)(smem + ((PASSES == 3) ? 4 : 2) * PLANE);  // [NKP] additive key bias (0 / -1e30)
+
+  const AttGroup<MODE> grp(g, blockIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long hoff = (long)grp.h * ATT_D;
+
+  att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  for (int j = threadIdx.x; j < NKP; j += 256) {
+    float bias = (j < g.nk) ? 0.f : -1e30f;
+    if (MODE == MODE_TEXT && j < g.nk && g.mask[(long)grp.b * g.S + j] == 0) bias = -1e30f;
+    kbias[j] = bias;
+  }
+  __syncthreads();
+
+  const int gq = lane >> 4;  // lane group
+  const int ntiles = (g.nq + 15) / 16;
+  for (int qt = wave; qt < ntiles; qt += 4) {
+    asm volatile("" ::: "memory");  // K/V fragments are loop-invariant: stop LICM from hoisting ~900 VGPRs of them
+    const int qi = qt * 16 + (lane & 15);
+    const int qc = min(qi, g.nq - 1);
+    const float* qrow = g.q + grp.q_tok(g, qc) * g.tok_stride + hoff;
+    bf16x8_t qh[2], ql[2];
+    att_gfrag(qrow, 0, lane, 0.125f, qh[0], ql[0]);  // q *= 64^-0.5 (video_transformer.py:106)
+    att_gfrag(qrow, 1, lane, 0.125f, qh[1], ql[1]);
+
+    f32x4_t s[NKF];
+#pragma unroll
+    for (int kf = 0; kf < NKF; ++kf) {
+      s[kf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
+        bf16x8_t al = ah;
+        if (PASSES == 3) al = att_frag_cols(k_lo, kf * 16, ks, lane);
+        s[kf] = att_mma<PASSES>(ah, al, qh[ks], ql[ks], s[kf]);
+      }
+    }
+    // softmax over keys: lane holds keys kf*16 + 4*gq + r of query qi
+    float m = -3e38f;
+#pragma unroll
+    for (int kf = 0; kf < NKF; ++kf) {
+      const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
+      s[kf] += kb;
+      m = fmaxf(m, fmaxf(fmaxf(s[kf][0], s[kf][1]), fmaxf(s[kf][2], s[kf][3])));
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kf = 0; kf < NKF; ++kf) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kf][r] = __expf(s[kf][r] - m);
+        l += s[kf][r];
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+
+    f32x4_t o[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NKF / 2; ++c) {
+      float pv[8] = {s[2 * c][0], s[2 * c][1], s[2 * c][2], s[2 * c][3],
+                     s[2 * c + 1][0], s[2 * c + 1][1], s[2 * c + 1][2], s[2 * c + 1][3]};
+      bf16x8_t ph, pl;
+      att_split8(pv, ph, pl);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8_t vh = att_frag_rows(v_hi, 32 * c, df * 16, lane);
+        bf16x8_t vl = vh;
+        if (PASSES == 3) vl = att_frag_rows(v_lo, 32 * c, df * 16, lane);
+        o[df] = att_mma<PASSES>(vh, vl, ph, pl, o[df]);
+      }
+    }
+    if (qi < g.nq) {
+      const float inv = 1.0f / l;
+      const long tok = grp.q_tok(g, qi);
+      bf16_t* oh = out_hi + tok * out_stride + hoff;
+      bf16_t* ol = out_lo ? out_lo + tok * out_stride + hoff : nullptr;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        bf16_t h[4], lo4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) split_bf16(o[df][r] * inv, h[r], lo4[r]);
+        const int d = df * 16 + 4 * gq;
+        *(u32x2_t*)(oh + d) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+        if (ol) *(u32x2_t*)(ol + d) = (u32x2_t){pack2(lo4[0], lo4[1]), pack2(lo4[2], lo4[3])};
+      }
+      if (gq == 0 && lse) {
+        const long srow = tok - grp.tok0;
+        lse[((long)grp.b * g.H + grp.h) * g.S + srow] = m + __logf(l);
+      }
+    }
+  }
+}
+
+template <int MODE, int NKF>
+int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol, long ostride, float* lse,
+               hipStream_t s) {
+  const int planes = passes == 3 ? 4 : 2;
+  const size_t lds = (size_t)planes * NKF * 16 * ATT_ROW_BYTES + NKF * 16 * sizeof(float);
+  if (passes == 3) {
+    auto kern = attn_fwd_kernel<MODE, NKF, 3>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(ngroups), dim3(256), lds, s, g, oh, ol, ostride, lse);
+  } else {
+    auto kern = attn_fwd_kernel<MODE, NKF, 1>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(ngroups), dim3(256), lds, s, g, oh, nullptr, ostride, lse);
+  }
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+}  // namespace
+
+// dispatch on the padded key count (NKF 16-key fragments, even): 2 (<=32 keys: DistilBERT L<=32 and the
+// tiny test configs), 4, 14 (ViT-B/16: 197 keys), 18 (ViT-L/14: 257 keys)
+template <int MODE>
+static int dispatch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol, long ostride, float* lse,
+                        hipStream_t s) {
+  if (g.nk <= 32) return launch_fwd<MODE, 2>(g, ngroups, passes, oh, ol, ostride, lse, s);
+  if (g.nk <= 64) return launch_fwd<MODE, 4>(g, ngroups, passes, oh, ol, ostride, lse, s);
+  if (g.nk <= 224) return launch_fwd<MODE, 14>(g, ngroups, passes, oh, ol, ostride, lse, s);
+  if (g.nk <= 288) return launch_fwd<MODE, 18>(g, ngroups, passes, oh, ol, ostride, lse, s);
+  return EGV_ERR_ARG;
+}
+
+int egv_attn_space_fwd_impl(const float* qkv, int B, int T, int n, int H, int passes, bf16_t* out_hi, bf16_t* out_lo,
+                            float* lse, hipStream_t s) {
+  AttGeom g;
+  const long HD = (long)H * ATT_D;
+  g.q = qkv;
+  g.k = qkv + HD;
+  g.v = qkv + 2 * HD;
+  g.tok_stride = 3 * HD;
+  g.B = B; g.T = T; g.n = n; g.H = H; g.S = 1 + T * n;
+  g.nq = n; g.nk = n + 1;
+  g.mask = nullptr;
+  return dispatch_fwd<MODE_SPACE>(g, B * T * H, passes, out_hi, out_lo, HD, lse, s);
+}
+
+extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v, const int64_t* mask, int32_t B,
+                                 int32_t L, int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse,
+                                 void* stream) {
+  if (!q || !k || !v || !out_hi || B <= 0 || L <= 0 || H <= 0) return EGV_ERR_ARG;
+  if (passes != 1 && passes != 3) return EGV_ERR_ARG;
+  if (passes == 3 && !out_lo) return EGV_ERR_ARG;
+  AttGeom g;
+  const long HD = (long)H * ATT_D;
+  g.q = q; g.k = k; g.v = v;
+  g.tok_stride = HD;
+  g.B = B; g.T = 1; g.n = L; g.H = H; g.S = L;
+  g.nq = L; g.nk = L;
+  g.mask = (const long long*)mask;
+  if (!mask) return EGV_ERR_ARG;
+  return dispatch_fwd<MODE_TEXT>(g, B * H, passes, out_hi, out_lo, HD, lse, (hipStream_t)stream);
+}

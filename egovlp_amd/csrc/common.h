@@ -1,0 +1,72 @@
+// Shared device helpers for the EgoVLP gfx950 (MI355X / CDNA4) kernels.
+// Everything here assumes wave64 and gfx950; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned short us4_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short us8_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+#define EGV_OK 0
+#define EGV_ERR_ARG 1
+#define EGV_ERR_LAUNCH 2
+
+#define EGV_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return EGV_ERR_LAUNCH + (int)e__; \
+  } while (0)
+
+// ---- bf16 <-> f32 -----------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even (inputs are finite in this path; NaN propagates as a quiet NaN)
+__device__ __forceinline__ bf16_t f32_to_bf16(float x) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// "split-bf16": x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi); |x - hi - lo| <= 2^-17 |x|.
+// Three bf16 MFMA passes (hi*hi + hi*lo + lo*hi) on such pairs reproduce an fp32 product to ~2^-16
+// relative, which is what lets bf16 matrix cores meet the 1e-3 parity bar against the fp32 reference.
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f32_to_bf16(x);
+  lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+
+__device__ __forceinline__ uint32_t pack2(bf16_t a, bf16_t b) { return (uint32_t)a | ((uint32_t)b << 16); }
+
+// ---- wave64 reductions ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU and its derivative -- nn.GELU default, model/video_transformer.py:37
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// XCD-aware, bijective remap of a 1-D block id: blocks that the dispatcher places on one XCD
+// (bid % 8) receive a CONTIGUOUS range of work ids, so neighbouring tiles share that XCD's L2.
+// Speed only -- correctness never depends on placement.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}

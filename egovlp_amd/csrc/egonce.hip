@@ -1,0 +1,395 @@
+// Contrastive head: sim_matrix (x3) + EgoNCE / NormSoftmaxLoss, forward AND analytic backward.
+//   model/model.py:189-197 (sim_matrix), model/loss.py:13-25 (NormSoftmaxLoss), :34-53 (EgoNCE),
+//   trainer/trainer_egoclip.py:130-137 (the three sim_matrix calls feeding the loss).
+// The whole problem is n = W*B <= 1024 rows (256 at 8 GPUs x 32): latency-bound, not throughput-bound,
+// so the design goal is few launches and no host round trip: 5 small kernels replace the ~40 ATen
+// launches + autograd graph of the reference, and the gradient w.r.t. both embeddings comes out of
+// the same call.  All arithmetic fp32.
+//   x_ij   = <t_i/max(|t_i|,eps), v_j/max(|v_j|,eps)>
+//   m_ij   = (simv_ij * simn_ij + [i==j]) > 0                       (EgoNCE, noun & verb)
+//   loss   = -1/n sum_i [log sum_j m_ij a_ij - log sum_j a_ij]      a_ij = exp(x_ij / tau)
+//            -1/n sum_i [log sum_j m_ij a_ji - log sum_j a_ji]
+#include "common.h"
+#include "egovlp_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {  // 256 threads
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// A: per row i: clamped norms + normalised text / video rows
+__global__ __launch_bounds__(256) void egonce_norm_kernel(const float* __restrict__ text, const float* __restrict__ video,
+                                                          const float* __restrict__ noun, const float* __restrict__ verb,
+                                                          int n, int D, int dn, int dv, float eps,
+                                                          float* __restrict__ tn, float* __restrict__ vn,
+                                                          float* __restrict__ stats /* [4][n]: |t|,|v|,|noun|c,|verb|c */) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x;
+  float st = 0.f, sv = 0.f, sn = 0.f, sb = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float a = text[(long)i * D + d], b = video[(long)i * D + d];
+    st += a * a;
+    sv += b * b;
+  }
+  if (noun)
+    for (int d = threadIdx.x; d < dn; d += 256) {
+      const float a = noun[(long)i * dn + d];
+      sn += a * a;
+    }
+  if (verb)
+    for (int d = threadIdx.x; d < dv; d += 256) {
+      const float a = verb[(long)i * dv + d];
+      sb += a * a;
+    }
+  const float nt = sqrtf(block_sum(st, sh));
+  const float nv = sqrtf(block_sum(sv, sh));
+  const float nno = sqrtf(block_sum(sn, sh));
+  const float nve = sqrtf(block_sum(sb, sh));
+  const float ct = fmaxf(nt, eps), cv = fmaxf(nv, eps);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    tn[(long)i * D + d] = text[(long)i * D + d] / ct;
+    vn[(long)i * D + d] = video[(long)i * D + d] / cv;
+  }
+  if (threadIdx.x == 0) {
+    stats[0 * n + i] = nt;
+    stats[1 * n + i] = nv;
+    stats[2 * n + i] = fmaxf(nno, eps);
+    stats[3 * n + i] = fmaxf(nve, eps);
+  }
+}
+
+// B: row i of x and of the mask; row statistics rmax_i, Z_i, P_i
+__global__ __launch_bounds__(256) void egonce_rows_kernel(const float* __restrict__ tn, const float* __restrict__ vn,
+                                                          const float* __restrict__ noun, const float* __restrict__ verb,
+                                                          const float* __restrict__ stats, int n, int D, int dn, int dv,
+                                                          float inv_tau, int use_noun, int use_verb,
+                                                          float* __restrict__ x, float* __restrict__ mask,
+                                                          float* __restrict__ rstat /* [3][n] */) {
+  extern __shared__ float rowbuf[];  // [D + dn + dv]
+  __shared__ float sh[4];
+  const int i = blockIdx.x;
+  float* ti = rowbuf;
+  float* ni = rowbuf + D;
+  float* bi = ni + dn;
+  for (int d = threadIdx.x; d < D; d += 256) ti[d] = tn[(long)i * D + d];
+  if (noun)
+    for (int d = threadIdx.x; d < dn; d += 256) ni[d] = noun[(long)i * dn + d];
+  if (verb)
+    for (int d = threadIdx.x; d < dv; d += 256) bi[d] = verb[(long)i * dv + d];
+  __syncthreads();
+  float lmax = -3e38f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float acc = 0.f;
+    const float* vj = vn + (long)j * D;
+    for (int d = 0; d < D; d += 4) {
+      const f32x4_t b = *(const f32x4_t*)(vj + d);
+      acc += ti[d] * b[0] + ti[d + 1] * b[1] + ti[d + 2] * b[2] + ti[d + 3] * b[3];
+    }
+    float m = (i == j) ? 1.f : 0.f;
+    if (noun || verb) {
+      float sn = 0.f, sv = 0.f;
+      if (noun && use_noun) {
+        const float* nj = noun + (long)j * dn;
+        for (int d = 0; d < dn; ++d) sn += ni[d] * nj[d];
+        sn = (sn / stats[2 * n + i]) / stats[2 * n + j];
+      }
+      if (verb && use_verb) {
+        const float* bj = verb + (long)j * dv;
+        for (int d = 0; d < dv; ++d) sv += bi[d] * bj[d];
+        sv = (sv / stats[3 * n + i]) / stats[3 * n + j];
+      }
+      float mm;
+      if (use_noun && use_verb) mm = sv * sn + m;   // loss.py:36-37
+      else if (use_noun) mm = sn + m;               // :38-39
+      else mm = sv + m;                             // :40-41
+      m = mm > 0.f ? 1.f : 0.f;                     // :47
+    }
+    x[(long)i * n + j] = acc;
+    mask[(long)i * n + j] = m;
+    lmax = fmaxf(lmax, acc);
+  }
+}
+
+// B2: row statistics rmax_i, Z_i = sum_j a_ij, P_i = sum_j m_ij a_ij
+__global__ __launch_bounds__(256) void egonce_rowstat_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                             int n, float inv_tau, float* __restrict__ rstat) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x;
+  float lmax = -3e38f;
+  for (int j = threadIdx.x; j < n; j += 256) lmax = fmaxf(lmax, x[(long)i * n + j]);
+  const float rmax = block_max(lmax, sh);
+  float z = 0.f, p = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float a = __expf((x[(long)i * n + j] - rmax) * inv_tau);
+    z += a;
+    p += a * mask[(long)i * n + j];
+  }
+  z = block_sum(z, sh);
+  p = block_sum(p, sh);
+  if (threadIdx.x == 0) {
+    rstat[0 * n + i] = rmax;
+    rstat[1 * n + i] = z;
+    rstat[2 * n + i] = p;
+  }
+}
+
+// mask from precomputed similarity matrices (API-compatible EgoNCE.forward(x, mask_v, mask_n), loss.py:34-47)
+__global__ __launch_bounds__(256) void egonce_mask_from_sim_kernel(const float* __restrict__ sim_v,
+                                                                   const float* __restrict__ sim_n, int n, int use_noun,
+                                                                   int use_verb, float* __restrict__ mask) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)n * n) return;
+  const float d = (i / n == i % n) ? 1.f : 0.f;
+  float m = d;
+  if (sim_v || sim_n) {
+    if (use_noun && use_verb) m = sim_v[i] * sim_n[i] + d;
+    else if (use_noun) m = sim_n[i] + d;
+    else m = sim_v[i] + d;
+  }
+  mask[i] = m > 0.f ? 1.f : 0.f;
+}
+
+// generic sim_matrix pieces: row normalisation, C = An . Bn^T, and the backward through both
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ a, int D, float eps,
+                                                      float* __restrict__ an, float* __restrict__ norms) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float v = a[(long)i * D + d];
+    s += v * v;
+  }
+  const float nrm = sqrtf(block_sum(s, sh));
+  const float c = fmaxf(nrm, eps);
+  for (int d = threadIdx.x; d < D; d += 256) an[(long)i * D + d] = a[(long)i * D + d] / c;
+  if (threadIdx.x == 0) norms[i] = nrm;
+}
+__global__ __launch_bounds__(256) void dot_nt_kernel(const float* __restrict__ an, const float* __restrict__ bn, int m,
+                                                     int D, float* __restrict__ out) {
+  extern __shared__ float rowbuf[];
+  const int i = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) rowbuf[d] = an[(long)i * D + d];
+  __syncthreads();
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const float* bj = bn + (long)j * D;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += rowbuf[d] * bj[d];
+    out[(long)i * m + j] = acc;
+  }
+}
+// d_a[i,:] = normalisation-backward( sum_j G[i,j] (or G[j,i] if transposed) * bn[j,:] )
+__global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ G, int transposed, int rows, int cols,
+                                                      const float* __restrict__ an, const float* __restrict__ bn,
+                                                      const float* __restrict__ norms, int D, float eps,
+                                                      float* __restrict__ da) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x;  // row of a (rows of them); sums over `cols` rows of b
+  const float nrm = norms[i];
+  float proj = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float g = 0.f;
+    for (int j = 0; j < cols; ++j) {
+      const float gij = transposed ? G[(long)j * rows + i] : G[(long)i * cols + j];
+      g += gij * bn[(long)j * D + d];
+    }
+    da[(long)i * D + d] = g;  // stash the raw gradient w.r.t. the normalised row
+    proj += g * an[(long)i * D + d];
+  }
+  proj = block_sum(proj, sh);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float g = da[(long)i * D + d];
+    da[(long)i * D + d] = nrm > eps ? (g - an[(long)i * D + d] * proj) / nrm : g / eps;
+  }
+}
+
+// C: column statistics for column c: cmax_c, C_c = sum_r a_rc, Q_c = sum_r m_cr a_rc
+__global__ __launch_bounds__(256) void egonce_cols_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                          int n, float inv_tau, float* __restrict__ cstat /* [3][n] */) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x;
+  float lmax = -3e38f;
+  for (int r = threadIdx.x; r < n; r += 256) lmax = fmaxf(lmax, x[(long)r * n + c]);
+  const float cmax = block_max(lmax, sh);
+  float s = 0.f, q = 0.f;
+  for (int r = threadIdx.x; r < n; r += 256) {
+    const float a = __expf((x[(long)r * n + c] - cmax) * inv_tau);
+    s += a;
+    q += a * mask[(long)c * n + r];
+  }
+  s = block_sum(s, sh);
+  q = block_sum(q, sh);
+  if (threadIdx.x == 0) {
+    cstat[0 * n + c] = cmax;
+    cstat[1 * n + c] = s;
+    cstat[2 * n + c] = q;
+  }
+}
+
+// D: G_ij = dL/dx_ij (row i per block)
+__global__ __launch_bounds__(256) void egonce_grad_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                          const float* __restrict__ rstat, const float* __restrict__ cstat,
+                                                          int n, float inv_tau, float* __restrict__ G) {
+  const int i = blockIdx.x;
+  const float rmax = rstat[i], Zi = rstat[n + i], Pi = rstat[2 * n + i];
+  const float sc = -inv_tau / (float)n;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float xv = x[(long)i * n + j];
+    const float ar = __expf((xv - rmax) * inv_tau);             // row-normalised numerator
+    const float ac = __expf((xv - cstat[j]) * inv_tau);         // column-normalised numerator
+    const float g_row = mask[(long)i * n + j] * ar / Pi - ar / Zi;
+    const float g_col = mask[(long)j * n + i] * ac / cstat[2 * n + j] - ac / cstat[n + j];
+    G[(long)i * n + j] = sc * (g_row + g_col);
+  }
+}
+
+// E: loss scalar + embedding gradients.  Block i, thread d.
+__global__ __launch_bounds__(256) void egonce_embgrad_kernel(const float* __restrict__ G, const float* __restrict__ tn,
+                                                             const float* __restrict__ vn,
+                                                             const float* __restrict__ stats, int n, int D, float eps,
+                                                             float* __restrict__ d_text, float* __restrict__ d_video) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x;
+  const float nt = stats[i], nv = stats[n + i];
+  for (int d0 = 0; d0 < D; d0 += 256) {
+    const int d = d0 + threadIdx.x;
+    float gt = 0.f, gv = 0.f;
+    if (d < D) {
+      for (int j = 0; j < n; ++j) {
+        gt += G[(long)i * n + j] * vn[(long)j * D + d];
+        gv += G[(long)j * n + i] * tn[(long)j * D + d];
+      }
+    }
+    // D <= 256 in the hot path; for larger D the projection term needs a full-row dot, handled below
+    if (D <= 256) {
+      const float th = d < D ? tn[(long)i * D + d] : 0.f;
+      const float vh = d < D ? vn[(long)i * D + d] : 0.f;
+      const float pt = block_sum(th * gt, sh);
+      const float pv = block_sum(vh * gv, sh);
+      if (d < D) {
+        if (d_text) d_text[(long)i * D + d] = nt > eps ? (gt - th * pt) / nt : gt / eps;
+        if (d_video) d_video[(long)i * D + d] = nv > eps ? (gv - vh * pv) / nv : gv / eps;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void egonce_loss_kernel(const float* __restrict__ rstat, const float* __restrict__ cstat,
+                                                          int n, float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256)
+    s += (__logf(rstat[2 * n + i]) - __logf(rstat[n + i])) + (__logf(cstat[2 * n + i]) - __logf(cstat[n + i]));
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) loss[0] = -s / (float)n;
+}
+
+}  // namespace
+
+extern "C" int64_t egv_egonce_work_floats(int32_t n, int32_t D) {
+  return 2LL * n * D + 3LL * n * n + 16LL * n;
+}
+
+extern "C" int egv_egonce_fwd_bwd(const float* text, const float* video, const float* noun, const float* verb,
+                                  int32_t n, int32_t D, int32_t dn, int32_t dv, float temperature, float eps,
+                                  int32_t use_noun, int32_t use_verb, float* loss, float* sim, float* d_text,
+                                  float* d_video, float* work, void* stream) {
+  if (!text || !video || !loss || !work || n <= 0 || n > 1024 || D <= 0 || D > 256 || D % 4 != 0) return EGV_ERR_ARG;
+  if ((noun != nullptr) != (verb != nullptr)) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* tn = work;
+  float* vn = tn + (long)n * D;
+  float* x = sim ? sim : vn + (long)n * D;
+  float* mask = vn + (long)n * D + (long)n * n;
+  float* G = mask + (long)n * n;
+  float* stats = G + (long)n * n;  // 4n
+  float* rstat = stats + 4 * n;    // 3n
+  float* cstat = rstat + 3 * n;    // 3n
+  const float inv_tau = 1.0f / temperature;
+  hipLaunchKernelGGL(egonce_norm_kernel, dim3(n), dim3(256), 0, s, text, video, noun, verb, n, D, dn, dv, eps, tn, vn,
+                     stats);
+  EGV_CHECK_LAUNCH();
+  const size_t lds = (size_t)(D + (noun ? dn + dv : 0)) * sizeof(float);
+  hipLaunchKernelGGL(egonce_rows_kernel, dim3(n), dim3(256), lds, s, tn, vn, noun, verb, stats, n, D, dn, dv, inv_tau,
+                     use_noun, use_verb, x, mask, rstat);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(egonce_rowstat_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, rstat);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(egonce_cols_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, cstat);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(egonce_loss_kernel, dim3(1), dim3(256), 0, s, rstat, cstat, n, loss);
+  EGV_CHECK_LAUNCH();
+  if (d_text || d_video) {
+    hipLaunchKernelGGL(egonce_grad_kernel, dim3(n), dim3(256), 0, s, x, mask, rstat, cstat, n, inv_tau, G);
+    EGV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(egonce_embgrad_kernel, dim3(n), dim3(256), 0, s, G, tn, vn, stats, n, D, eps, d_text, d_video);
+    EGV_CHECK_LAUNCH();
+  }
+  return EGV_OK;
+}
+
+// API-compatible pieces -------------------------------------------------------------------------------
+extern "C" int egv_sim_matrix_fwd(const float* a, const float* b, int32_t n, int32_t m, int32_t D, float eps,
+                                  float* an, float* bn, float* norms /* [n+m] */, float* out, void* stream) {
+  if (!a || !b || !an || !bn || !norms || !out || n <= 0 || m <= 0 || D <= 0 || D > 8192) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(rownorm_kernel, dim3(n), dim3(256), 0, s, a, D, eps, an, norms);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rownorm_kernel, dim3(m), dim3(256), 0, s, b, D, eps, bn, norms + n);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dot_nt_kernel, dim3(n), dim3(256), (size_t)D * sizeof(float), s, an, bn, m, D, out);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_sim_matrix_bwd(const float* g, const float* an, const float* bn, const float* norms, int32_t n,
+                                  int32_t m, int32_t D, float eps, float* da, float* db, void* stream) {
+  if (!g || !an || !bn || !norms || n <= 0 || m <= 0 || D <= 0) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (da) {
+    hipLaunchKernelGGL(sim_bwd_kernel, dim3(n), dim3(256), 0, s, g, 0, n, m, an, bn, norms, D, eps, da);
+    EGV_CHECK_LAUNCH();
+  }
+  if (db) {
+    hipLaunchKernelGGL(sim_bwd_kernel, dim3(m), dim3(256), 0, s, g, 1, m, n, bn, an, norms + n, D, eps, db);
+    EGV_CHECK_LAUNCH();
+  }
+  return EGV_OK;
+}
+
+extern "C" int egv_egonce_from_sim(const float* x, const float* sim_v, const float* sim_n, int32_t n,
+                                   float temperature, int32_t use_noun, int32_t use_verb, float* loss, float* dx,
+                                   float* work /* n*n + 6n floats */, void* stream) {
+  if (!x || !loss || !work || n <= 0 || n > 4096) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  float* mask = work;
+  float* rstat = mask + (long)n * n;
+  float* cstat = rstat + 3 * n;
+  const float inv_tau = 1.0f / temperature;
+  const long nn = (long)n * n;
+  hipLaunchKernelGGL(egonce_mask_from_sim_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, sim_v, sim_n, n,
+                     use_noun, use_verb, mask);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(egonce_rowstat_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, rstat);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(egonce_cols_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, cstat);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(egonce_loss_kernel, dim3(1), dim3(256), 0, s, rstat, cstat, n, loss);
+  EGV_CHECK_LAUNCH();
+  if (dx) {
+    hipLaunchKernelGGL(egonce_grad_kernel, dim3(n), dim3(256), 0, s, x, mask, rstat, cstat, n, inv_tau, dx);
+    EGV_CHECK_LAUNCH();
+  }
+  return EGV_OK;
+}

@@ -1,0 +1,343 @@
+// Format kernels: fp32 <-> split-bf16 planes, transposes (+ column sums = bias gradients),
+// patch gather, token assembly.  All HBM-bound: 16-byte global accesses, LDS only for transposes.
+#include "common.h"
+#include "egovlp_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// split_f32: one 64x64 tile per block (256 threads).  Reads fp32 rows coalesced (float4), writes the
+// row-major planes directly and the transposed planes through a padded LDS tile; column sums are
+// block-reduced and accumulated with one atomicAdd per column per block (colsum is zeroed first).
+// SRC_PLANES: the source is already a pair of bf16 planes (value = hi + lo) instead of fp32.
+template <bool SRC_PLANES>
+__global__ __launch_bounds__(256) void split_transpose_kernel(
+    const float* __restrict__ x, const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, long ldx, int rows,
+    int cols, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long ldo, bf16_t* __restrict__ thi,
+    bf16_t* __restrict__ tlo, long ldt, float* __restrict__ colsum) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  const int tr = tid >> 4;         // 0..15
+  const int tc = (tid & 15) * 4;   // 0..60
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rr = 0; rr < 64; rr += 16) {
+    const int r = r0 + rr + tr, c = c0 + tc;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && c < cols) {  // cols % 4 == 0
+      if (SRC_PLANES) {
+        const us4_t h = *(const us4_t*)(xh + (long)r * ldx + c);
+        us4_t l = {0, 0, 0, 0};
+        if (xl) l = *(const us4_t*)(xl + (long)r * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = bf16_to_f32(h[e]) + bf16_to_f32(l[e]);
+      } else {
+        v = *(const f32x4_t*)(x + (long)r * ldx + c);
+        if (hi) {
+          bf16_t h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+          *(u32x2_t*)(hi + (long)r * ldo + c) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+          if (lo) *(u32x2_t*)(lo + (long)r * ldo + c) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      tile[rr + tr][tc + e] = v[e];
+      csum[e] += v[e];
+    }
+  }
+  __syncthreads();
+  if (colsum) {
+    // reduce csum over the 16 row-threads sharing a column group: lanes tid, tid+16, ... (tr varies)
+    // use LDS-free approach: every thread adds its partial for its 4 columns via the tile's spare space
+    // (simple and cheap: 16-way shuffle-free reduction through atomics on LDS would be slower), so
+    // re-read the tile column-wise instead: thread t < 64 sums column t over 64 rows.
+    if (tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) s += tile[r][tid];
+      if (c0 + tid < cols) atomicAdd(colsum + c0 + tid, s);
+    }
+  }
+  if (thi) {
+    // transposed write: output row = column index c, output col = row index r (contiguous over r)
+#pragma unroll
+    for (int cc = 0; cc < 64; cc += 16) {
+      const int c = c0 + cc + tr;   // output row
+      const int r = r0 + tc;        // output col start (4 consecutive source rows)
+      if (c < cols && r < ldt) {
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (r + e < rows) ? tile[tc + e][cc + tr] : 0.f;
+          split_bf16(v, h[e], l[e]);
+        }
+        *(u32x2_t*)(thi + (long)c * ldt + r) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+        if (tlo) *(u32x2_t*)(tlo + (long)c * ldt + r) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+      }
+    }
+  }
+}
+
+// relu(x) -> split planes (txt_proj's ReLU, model/model.py:73)
+__global__ __launch_bounds__(256) void relu_split_kernel(const float* __restrict__ x, long ldx, int rows, int cols,
+                                                         bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = cols / 4;
+  if (i >= (long)rows * c4) return;
+  const int r = (int)(i / c4), c = (int)(i % c4) * 4;
+  f32x4_t v = *(const f32x4_t*)(x + (long)r * ldx + c);
+  bf16_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_bf16(fmaxf(v[e], 0.f), h[e], l[e]);
+  *(u32x2_t*)(hi + (long)r * ldo + c) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+  if (lo) *(u32x2_t*)(lo + (long)r * ldo + c) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+}
+
+// ---------------------------------------------------------------------------------------------
+// patch gather (im2col for a PxP / stride P conv): one thread moves 4 consecutive pixels of one patch row.
+// Source rows are W*4 B contiguous, so a wave reads 64*16 B = 1 KiB of one image row segment: coalesced.
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ video, int BT, int C, int H, int W,
+                                                           int P, bf16_t* __restrict__ ahi, bf16_t* __restrict__ alo,
+                                                           long lda) {
+  // thread -> (image bt, channel c, image row y, 4-pixel group xg)
+  const int W4 = W / 4;
+  const long total = (long)BT * C * H * W4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int xg = (int)(i % W4);
+  long t = i / W4;
+  const int y = (int)(t % H);
+  t /= H;
+  const int c = (int)(t % C);
+  const int bt = (int)(t / C);
+  const f32x4_t v = *(const f32x4_t*)(video + (((long)bt * C + c) * H + y) * W + xg * 4);
+  const int gw = W / P, gh = H / P;
+  const int py = y / P, iy = y % P;
+  const int x = xg * 4;
+  const int px = x / P, ix = x % P;
+  const long row = ((long)bt * gh + py) * gw + px;
+  const int col = (c * P + iy) * P + ix;
+  bf16_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+  *(u32x2_t*)(ahi + row * lda + col) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+  if (alo) *(u32x2_t*)(alo + row * lda + col) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+}
+
+// x[b, s, :] for s = 0: cls + pos[0]; s = 1 + f*n + i: pe[(b*T+f)*n + i] + pos[1+i] + temporal[f]
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos,
+                                                              const float* __restrict__ temporal, int B, int T, int n,
+                                                              int D, float* __restrict__ x) {
+  const int D4 = D / 4;
+  const long S = 1 + (long)T * n;
+  const long total = (long)B * S * D4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int d = (int)(i % D4) * 4;
+  const long tok = i / D4;
+  const int s = (int)(tok % S);
+  const int b = (int)(tok / S);
+  f32x4_t v;
+  if (s == 0) {
+    v = *(const f32x4_t*)(cls + d) + *(const f32x4_t*)(pos + d);
+  } else {
+    const int f = (s - 1) / n, ii = (s - 1) % n;
+    v = *(const f32x4_t*)(pe + (((long)b * T + f) * n + ii) * D + d) + *(const f32x4_t*)(pos + (long)(1 + ii) * D + d) +
+        *(const f32x4_t*)(temporal + (long)f * D + d);
+  }
+  *(f32x4_t*)(x + tok * D + d) = v;
+}
+
+// backward: d_pe gather + reductions for d_cls, d_pos, d_temporal.
+// grid.x = D/256-ish column blocks; each thread owns one channel d and loops over tokens it reduces.
+// d_pos[1+i, d]  = sum_{b,f} dx[b, 1+f*n+i, d];  d_pos[0,d] = d_cls[d] = sum_b dx[b,0,d]
+// d_temporal[f,d] = sum_{b,i} dx[b, 1+f*n+i, d]
+__global__ __launch_bounds__(256) void assemble_bwd_pos_kernel(const float* __restrict__ dx, int B, int T, int n, int D,
+                                                               float* __restrict__ d_pos, float* __restrict__ d_cls) {
+  // one block per position row p in [0, n]; threads over d
+  const int p = blockIdx.x;
+  const long S = 1 + (long)T * n;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    if (p == 0) {
+      for (int b = 0; b < B; ++b) s += dx[((long)b * S) * D + d];
+      d_cls[d] = s;
+    } else {
+      for (int b = 0; b < B; ++b)
+        for (int f = 0; f < T; ++f) s += dx[((long)b * S + 1 + (long)f * n + (p - 1)) * D + d];
+    }
+    d_pos[(long)p * D + d] = s;
+  }
+}
+__global__ __launch_bounds__(256) void assemble_bwd_temporal_kernel(const float* __restrict__ dx, int B, int T, int n,
+                                                                    int D, int T_model, float* __restrict__ d_temporal) {
+  // grid (T_model, ceil(D/64)); block 256 = 4 row-groups x 64 channels; LDS reduce over the 4 groups
+  __shared__ float red[4][64];
+  const int f = blockIdx.x;
+  const int d = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  const long S = 1 + (long)T * n;
+  float s = 0.f;
+  if (f < T && d < D) {
+    for (int bi = g; bi < B * n; bi += 4) {
+      const int b = bi / n, i = bi % n;
+      s += dx[((long)b * S + 1 + (long)f * n + i) * D + d];
+    }
+  }
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && d < D) d_temporal[(long)f * D + d] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void assemble_bwd_pe_kernel(const float* __restrict__ dx, int B, int T, int n, int D,
+                                                              float* __restrict__ d_pe) {
+  const int D4 = D / 4;
+  const long total = (long)B * T * n * D4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int d = (int)(i % D4) * 4;
+  const long r = i / D4;  // (b*T+f)*n + ii
+  const long b = r / ((long)T * n);
+  const long rem = r % ((long)T * n);
+  const long S = 1 + (long)T * n;
+  *(f32x4_t*)(d_pe + r * D + d) = *(const f32x4_t*)(dx + (b * S + 1 + rem) * D + d);
+}
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                        const float* __restrict__ pos, int B, int L, int D,
+                                                        float* __restrict__ e) {
+  const int D4 = D / 4;
+  const long total = (long)B * L * D4;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int d = (int)(i % D4) * 4;
+  const long t = i / D4;
+  const int l = (int)(t % L);
+  const long id = ids[t];
+  *(f32x4_t*)(e + t * D + d) = *(const f32x4_t*)(word + id * D + d) + *(const f32x4_t*)(pos + (long)l * D + d);
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ de,
+                                                        int B, int L, int D, long pad_id,
+                                                        float* __restrict__ d_word,
+                                                        float* __restrict__ d_pos) {
+  const long total = (long)B * L * D;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int d = (int)(i % D);
+  const long t = i / D;
+  const int l = (int)(t % L);
+  const float g = de[i];
+  if (ids[t] != pad_id) atomicAdd(d_word + ids[t] * D + d, g);  // nn.Embedding(padding_idx): no grad to the pad row
+  atomicAdd(d_pos + (long)l * D + d, g);
+}
+
+}  // namespace
+
+extern "C" int egv_split_f32(const float* x, int64_t ldx, int32_t rows, int32_t cols, egv_bf16* hi, egv_bf16* lo,
+                             int64_t ldo, egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream) {
+  if (!x || rows <= 0 || cols <= 0 || cols % 4 != 0) return EGV_ERR_ARG;
+  if (t_hi && (ldt < rows || ldt % 4 != 0)) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (colsum) {
+    if (hipMemsetAsync(colsum, 0, sizeof(float) * cols, s) != hipSuccess) return EGV_ERR_LAUNCH;
+  }
+  const int row_extent = t_hi ? (int)ldt : rows;  // cover the zero pad of the transposed planes
+  dim3 grid((cols + 63) / 64, (row_extent + 63) / 64);
+  hipLaunchKernelGGL(split_transpose_kernel<false>, grid, dim3(256), 0, s, x, nullptr, nullptr, ldx, rows, cols, hi, lo,
+                     ldo, t_hi, t_lo, ldt, colsum);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, int32_t rows, int32_t cols,
+                                    egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream) {
+  if (!hi || rows <= 0 || cols <= 0 || cols % 4 != 0) return EGV_ERR_ARG;
+  if (t_hi && (ldt < rows || ldt % 4 != 0)) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (colsum) {
+    if (hipMemsetAsync(colsum, 0, sizeof(float) * cols, s) != hipSuccess) return EGV_ERR_LAUNCH;
+  }
+  const int row_extent = t_hi ? (int)ldt : rows;
+  dim3 grid((cols + 63) / 64, (row_extent + 63) / 64);
+  hipLaunchKernelGGL(split_transpose_kernel<true>, grid, dim3(256), 0, s, nullptr, hi, lo, ldx, rows, cols, nullptr,
+                     nullptr, 0, t_hi, t_lo, ldt, colsum);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_relu_split(const float* x, int64_t ldx, int32_t rows, int32_t cols, egv_bf16* hi, egv_bf16* lo,
+                              int64_t ldo, void* stream) {
+  if (!x || !hi || cols % 4 != 0) return EGV_ERR_ARG;
+  const long total = (long)rows * (cols / 4);
+  hipLaunchKernelGGL(relu_split_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
+                     cols, hi, lo, ldo);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
+                                egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream) {
+  if (!video || !a_hi || P % 4 != 0 || W % P != 0 || H % P != 0) return EGV_ERR_ARG;
+  const long total = (long)BT * C * H * (W / 4);
+  hipLaunchKernelGGL(patch_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C,
+                     H, W, P, a_hi, a_lo, lda);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_assemble_tokens(const float* pe, const float* cls, const float* pos, const float* temporal,
+                                   int32_t B, int32_t T, int32_t n, int32_t D, float* x, void* stream) {
+  if (!pe || !cls || !pos || !temporal || !x || D % 4 != 0) return EGV_ERR_ARG;
+  const long total = (long)B * (1 + (long)T * n) * (D / 4);
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pe, cls,
+                     pos, temporal, B, T, n, D, x);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, int32_t n, int32_t D, int32_t T_model,
+                                       float* d_pe, float* d_cls, float* d_pos, float* d_temporal, void* stream) {
+  if (!dx || D % 4 != 0 || T > T_model) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (d_pos && d_cls) {
+    hipLaunchKernelGGL(assemble_bwd_pos_kernel, dim3(n + 1), dim3(256), 0, s, dx, B, T, n, D, d_pos, d_cls);
+    EGV_CHECK_LAUNCH();
+  }
+  if (d_temporal) {
+    hipLaunchKernelGGL(assemble_bwd_temporal_kernel, dim3(T_model, (D + 63) / 64), dim3(256), 0, s, dx, B, T, n, D,
+                       T_model, d_temporal);
+    EGV_CHECK_LAUNCH();
+  }
+  if (d_pe) {
+    const long total = (long)B * T * n * (D / 4);
+    hipLaunchKernelGGL(assemble_bwd_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dx, B, T, n, D, d_pe);
+    EGV_CHECK_LAUNCH();
+  }
+  return EGV_OK;
+}
+
+extern "C" int egv_embed_fwd(const int64_t* ids, const float* word, const float* pos, int32_t B, int32_t L, int32_t D,
+                             float* e, void* stream) {
+  if (!ids || !word || !pos || !e || D % 4 != 0) return EGV_ERR_ARG;
+  const long total = (long)B * L * (D / 4);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, word, pos, B,
+                     L, D, e);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, int32_t L, int32_t D, int64_t pad_id,
+                             float* d_word, float* d_pos, void* stream) {
+  if (!ids || !d_e || !d_word || !d_pos) return EGV_ERR_ARG;
+  const long total = (long)B * L * D;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, d_e, B, L, D,
+                     (long)pad_id, d_word, d_pos);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_version(void) { return 1; }

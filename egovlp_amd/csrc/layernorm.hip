@@ -1,0 +1,196 @@
+// LayerNorm forward / backward for rows of <= 1024 channels (ViT-B 768, ViT-L 1024, DistilBERT 768).
+// HBM-bound: one wave64 owns a row, the row lives in registers (<= 4 float4 per lane), statistics by
+// wave shuffles (two-pass mean / centred variance, matching the fp32 reference's numerics), outputs
+// written once as split-bf16 planes (the next GEMM's operand format) and/or fp32.
+#include "common.h"
+#include "egovlp_hip.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 per lane -> cols <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ xadd, long ldx, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, int rows, int cols, float* __restrict__ sum_out,
+    bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo, float* __restrict__ yf, long ldy, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = cols / 4;
+  f32x4_t v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + i * 64;
+    v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (c4 < nv) {
+      v[i] = *(const f32x4_t*)(x + (long)row * ldx + c4 * 4);
+      if (xadd) v[i] += *(const f32x4_t*)(xadd + (long)row * ldx + c4 * 4);
+      if (sum_out) *(f32x4_t*)(sum_out + (long)row * ldx + c4 * 4) = v[i];
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + i * 64;
+    if (c4 < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float var = wave_sum(q) / (float)cols;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + i * 64;
+    if (c4 < nv) {
+      const f32x4_t g = *(const f32x4_t*)(gamma + c4 * 4);
+      const f32x4_t b = *(const f32x4_t*)(beta + c4 * 4);
+      f32x4_t y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      if (yf) *(f32x4_t*)(yf + (long)row * ldy + c4 * 4) = y;
+      if (yhi) {
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_bf16(y[e], h[e], l[e]);
+        *(u32x2_t*)(yhi + (long)row * ldy + c4 * 4) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+        if (ylo) *(u32x2_t*)(ylo + (long)row * ldy + c4 * 4) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+      }
+    }
+  }
+}
+
+// backward: each wave walks rows wave_id, wave_id + nwaves, ...; per-lane partial dgamma/dbeta stay in
+// registers; one LDS reduction per block at the end -> work[block][2][cols]; a second kernel sums blocks.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int cols, const float* __restrict__ add1,
+    const float* __restrict__ add2, float* __restrict__ dx, long lddx, float* __restrict__ work) {
+  __shared__ float red[2][4][MAXV * 256];  // [dgamma/dbeta][wave][col]  32 KiB
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nv = cols / 4;
+  f32x4_t dg[MAXV], db[MAXV], g[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    dg[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    db[i] = dg[i];
+    g[i] = dg[i];
+    const int c4 = lane + i * 64;
+    if (c4 < nv) g[i] = *(const f32x4_t*)(gamma + c4 * 4);
+  }
+  const float inv_cols = 1.0f / (float)cols;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4_t gy[MAXV], xh[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c4 = lane + i * 64;
+      gy[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      xh[i] = gy[i];
+      if (c4 < nv) {
+        const f32x4_t d = *(const f32x4_t*)(dy + (long)row * lddy + c4 * 4);
+        const f32x4_t xv = *(const f32x4_t*)(x + (long)row * ldx + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          gy[i][e] = d[e] * g[i][e];
+          dg[i][e] += d[e] * xh[i][e];
+          db[i][e] += d[e];
+          s1 += gy[i][e];
+          s2 += gy[i][e] * xh[i][e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) * inv_cols;
+    const float c2 = wave_sum(s2) * inv_cols;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c4 = lane + i * 64;
+      if (c4 < nv) {
+        f32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
+        if (add1) o += *(const f32x4_t*)(add1 + (long)row * lddx + c4 * 4);
+        if (add2) o += *(const f32x4_t*)(add2 + (long)row * lddx + c4 * 4);
+        *(f32x4_t*)(dx + (long)row * lddx + c4 * 4) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][wave][c4 * 4 + e] = dg[i][e];
+      red[1][wave][c4 * 4 + e] = db[i][e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    work[((long)blockIdx.x * 2 + 0) * cols + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    work[((long)blockIdx.x * 2 + 1) * cols + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ work, int parts, int cols,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f, b = 0.f;
+  for (int p = 0; p < parts; ++p) {
+    a += work[((long)p * 2 + 0) * cols + c];
+    b += work[((long)p * 2 + 1) * cols + c];
+  }
+  if (dgamma) dgamma[c] = a;
+  if (dbeta) dbeta[c] = b;
+}
+
+}  // namespace
+
+extern "C" int egv_layernorm_fwd(const float* x, const float* x_add, int64_t ldx, const float* gamma,
+                                 const float* beta, float eps, int32_t rows, int32_t cols, float* sum_out,
+                                 egv_bf16* y_hi, egv_bf16* y_lo, float* y_f32, int64_t ldy, float* mean, float* rstd,
+                                 void* stream) {
+  if (!x || !gamma || !beta || rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
+  if (!y_hi && !y_f32) return EGV_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_add, ldx,
+                     gamma, beta, eps, rows, cols, sum_out, y_hi, y_lo, y_f32, ldy, mean, rstd);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+extern "C" int egv_layernorm_bwd_parts(int32_t rows) {
+  const int b = (rows + 3) / 4;
+  return b < 512 ? b : 512;
+}
+
+extern "C" int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* mean, const float* rstd, int32_t rows, int32_t cols, const float* add1,
+                                 const float* add2, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* work,
+                                 void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !work) return EGV_ERR_ARG;
+  if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
+  const int parts = egv_layernorm_bwd_parts(rows);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, lddy, x, ldx, gamma, mean, rstd, rows,
+                     cols, add1, add2, dx, lddx, work);
+  EGV_CHECK_LAUNCH();
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, work, parts, cols, dgamma,
+                     dbeta);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}

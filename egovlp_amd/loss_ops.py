@@ -1,0 +1,50 @@
+"""Tensor-level wrappers of the contrastive-head kernels (include/egovlp_hip.h: egv_sim_matrix_*,
+egv_egonce_from_sim, egv_egonce_fwd_bwd)."""
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import _p, _stream
+
+
+def sim_fwd(a, b, eps):
+    ops._need_cuda(a, b)
+    a = a.contiguous().float()
+    b = b.contiguous().float()
+    n, D = a.shape
+    m = b.shape[0]
+    dev = a.device
+    an = torch.empty_like(a)
+    bn = torch.empty_like(b)
+    norms = torch.empty(n + m, dtype=torch.float32, device=dev)
+    out = torch.empty((n, m), dtype=torch.float32, device=dev)
+    check(_lib.lib().egv_sim_matrix_fwd(_p(a), _p(b), n, m, D, float(eps), _p(an), _p(bn), _p(norms), _p(out),
+                                        _stream()), "egv_sim_matrix_fwd")
+    return out, (an, bn, norms, n, m, D, float(eps))
+
+
+def sim_bwd(data, g):
+    an, bn, norms, n, m, D, eps = data
+    g = g.contiguous()
+    da = torch.empty_like(an)
+    db = torch.empty_like(bn)
+    check(_lib.lib().egv_sim_matrix_bwd(_p(g), _p(an), _p(bn), _p(norms), n, m, D, eps, _p(da), _p(db), _stream()),
+          "egv_sim_matrix_bwd")
+    return da, db
+
+
+def egonce_from_sim(x, sim_v, sim_n, temperature, use_noun, use_verb, want_grad=True):
+    ops._need_cuda(x)
+    x = x.contiguous()
+    n = x.shape[0]
+    if x.shape[1] != n:
+        raise ValueError("EgoNCE / NormSoftmaxLoss need a square similarity matrix")
+    dev = x.device
+    work = torch.empty(n * n + 6 * n, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dx = torch.empty_like(x) if want_grad else None
+    sv = sim_v.contiguous() if sim_v is not None else None
+    sn = sim_n.contiguous() if sim_n is not None else None
+    check(_lib.lib().egv_egonce_from_sim(_p(x), _p(sv), _p(sn), n, float(temperature), int(use_noun), int(use_verb),
+                                         _p(loss), _p(dx), _p(work), _stream()), "egv_egonce_from_sim")
+    return loss, dx

@@ -1,0 +1,72 @@
+"""EgoNCE / NormSoftmaxLoss -- drop-in for the reference's model/loss.py:7-53.
+
+Two ways in, same kernels underneath (egovlp_amd/csrc/egonce.hip):
+  * the reference's own call shape  `loss(sim_matrix(text, video), sim_v, sim_n)`  (model/loss.py:34,
+    trainer/trainer_egoclip.py:130-137): `forward` below, an autograd node over egv_egonce_from_sim;
+  * the fused hot path  `loss.fused(text, video, noun, verb)`: ONE call computes the three similarity
+    matrices, the mask, the loss and the gradients w.r.t. both embeddings (egv_egonce_fwd_bwd).
+The other losses of model/loss.py (MaxMarginRankingLoss :55-90, AdaptiveMaxMarginRankingLoss :92-133,
+CrossEntropy :135-141) belong to fine-tuning paths and are out of scope.
+"""
+import torch
+from torch import nn
+
+from .. import loss_ops, ops
+
+
+class _LossFromSimFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask_v, mask_n, temperature, use_noun, use_verb):
+        loss, dx = loss_ops.egonce_from_sim(x, mask_v, mask_n, temperature, use_noun, use_verb, want_grad=True)
+        ctx.save_for_backward(dx)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None, None, None, None, None
+
+
+class _FusedHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, text, video, noun, verb, temperature, use_noun, use_verb):
+        loss, _, dt, dv = ops.egonce_fwd_bwd(text.contiguous(), video.contiguous(),
+                                             None if noun is None else noun.contiguous().float(),
+                                             None if verb is None else verb.contiguous().float(),
+                                             temperature, use_noun=use_noun, use_verb=use_verb)
+        ctx.save_for_backward(dt, dv)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dt, dv = ctx.saved_tensors
+        return dt * g, dv * g, None, None, None, None, None
+
+
+class NormSoftmaxLoss(nn.Module):
+    def __init__(self, temperature=0.05):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, x):
+        "x: similarity matrix N x N in [-1, 1] (model/loss.py:13-25)"
+        return _LossFromSimFn.apply(x, None, None, self.temperature, True, True)
+
+    def fused(self, text_embeds, video_embeds):
+        return _FusedHeadFn.apply(text_embeds, video_embeds, None, None, self.temperature, True, True)
+
+
+class EgoNCE(nn.Module):
+    def __init__(self, temperature=0.05, noun=True, verb=True):
+        super().__init__()
+        self.noun = noun
+        self.verb = verb
+        self.temperature = temperature
+
+    def forward(self, x, mask_v, mask_n):
+        # noun=False, verb=False falls into the reference's else-branch (mask_v), model/loss.py:40-41
+        return _LossFromSimFn.apply(x, mask_v, mask_n, self.temperature, self.noun, self.verb or not self.noun)
+
+    def fused(self, text_embeds, video_embeds, noun_vec, verb_vec):
+        return _FusedHeadFn.apply(text_embeds, video_embeds, noun_vec, verb_vec, self.temperature, self.noun,
+                                  self.verb or not self.noun)

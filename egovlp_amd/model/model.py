@@ -1,0 +1,241 @@
+"""FrozenInTime dual encoder + sim_matrix -- drop-in for the reference's model/model.py.
+
+Same constructor / forward / attribute surface (model/model.py:14-143), so
+`config.initialize('arch', egovlp_amd.model.model)` builds it from configs/pt/egoclip.json unchanged.
+Differences from the reference are confined to what cannot exist in an offline MI355X container:
+  * `AutoModel.from_pretrained('distilbert-base-uncased')` (:32) needs the HF hub -> the text encoder is
+    our DistilBertModel with HF's init; real weights arrive through `load_checkpoint` / load_state_dict;
+  * the timm ViT-B/16 checkpoint `pretrained/jx_vit_base_p16_224-80ecf9dd.pth` (:48) is loaded when the
+    file exists and skipped (random init) otherwise;
+  * `arch_config='large_patch14_224'` is an extension (BASELINE config 5); the reference only accepts
+    'base_patch16_224' (:45-53).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import ACT_RELU_BWD, Precision
+from ..weights import WeightCache
+from .text_transformer import DistilBertModel
+from .video_transformer import SpaceTimeTransformer, _lin_bwd
+
+
+def state_dict_data_parallel_fix(load_state_dict, curr_state_dict):
+    """utils/util.py:25-51: add / strip the DDP 'module.' prefix so that key sets line up."""
+    load_keys = list(load_state_dict.keys())
+    curr_keys = list(curr_state_dict.keys())
+    redo_dp = False
+    undo_dp = False
+    if not curr_keys[0].startswith('module.') and load_keys[0].startswith('module.'):
+        undo_dp = True
+    elif curr_keys[0].startswith('module.') and not load_keys[0].startswith('module.'):
+        redo_dp = True
+    if undo_dp:
+        return type(load_state_dict)((k[7:], v) for k, v in load_state_dict.items())
+    if redo_dp:
+        return type(load_state_dict)(('module.' + k, v) for k, v in load_state_dict.items())
+    return load_state_dict
+
+
+class _ProjFn(torch.autograd.Function):
+    """y = [relu](x) W^T + b on rows of x (possibly strided: the CLS row of every caption)."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, b, relu, wc: WeightCache):
+        P = Precision.fwd_passes
+        M, K = x2d.shape
+        if relu:
+            a = ops.relu_split(x2d, P)
+        else:
+            a, _, _ = ops.split_f32(x2d, P)
+        y = torch.empty((M, w.shape[0]), dtype=torch.float32, device=x2d.device)
+        ops.gemm_nt(a, wc.get(w, need_t=False)[0], passes=P, bias=b, out_f32=y)
+        ctx.a, ctx.relu, ctx.wc, ctx.P = a, relu, wc, P
+        ctx.save_for_backward(x2d, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, w = ctx.saved_tensors
+        Pb = Precision.bwd_passes
+        dy = dy.contiguous()
+        dy_pl, dy_t, db = ops.split_f32(dy, Pb, want_rowmajor=True, want_transposed=True, want_colsum=True)
+        _, dW, _ = _lin_bwd(None, ctx.a, None, Pb, need_dx=False, dy_planes=dy_pl, dy_t=dy_t, db=db)
+        dx = torch.empty((x2d.shape[0], x2d.shape[1]), dtype=torch.float32, device=dy.device)
+        wt = ctx.wc.get(w, need_t=True)[1]
+        if ctx.relu:
+            ops.gemm_nt(dy_pl, wt, passes=Pb, act=ACT_RELU_BWD, aux_in=x2d, out_f32=dx, K=w.shape[0])
+        else:
+            ops.gemm_nt(dy_pl, wt, passes=Pb, out_f32=dx, K=w.shape[0])
+        return dx, dW, db, None, None
+
+
+class _ReluLinear(nn.Sequential):
+    """nn.Sequential(nn.ReLU(), nn.Linear) container (keys `1.weight`, `1.bias`), model/model.py:73-75."""
+
+
+class BaseModel(nn.Module):
+    """base/base_model.py:7-25."""
+
+    def __str__(self):
+        n = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        return super().__str__() + '\nTrainable parameters: {}'.format(n)
+
+
+class FrozenInTime(BaseModel):
+    def __init__(self, video_params, text_params, projection_dim=256, load_checkpoint=None,
+                 projection='minimal', load_temporal_fix='zeros'):
+        super().__init__()
+        self.video_params = video_params
+        self.text_params = text_params
+        self.load_temporal_fix = load_temporal_fix
+        if not text_params['pretrained']:
+            raise NotImplementedError("Huggingface text models require pretrained init.")       # :27-28
+        if self.text_params['model'].startswith('distilbert'):
+            self.text_model = DistilBertModel()
+        else:
+            raise NotImplementedError(f"{text_params['model']}: only distilbert is on the EgoClip hot path")
+        self.text_model.train()
+
+        if video_params['model'] == "SpaceTimeTransformer":
+            num_frames = video_params.get('num_frames', 4)
+            time_init = video_params.get('time_init', 'zeros')
+            attention_style = video_params.get('attention_style', 'frozen-in-time')
+            arch_config = video_params.get('arch_config', 'base_patch16_224')
+            if arch_config == 'base_patch16_224':
+                model = SpaceTimeTransformer(num_frames=num_frames, time_init=time_init,
+                                             attention_style=attention_style)
+                vit_path = "pretrained/jx_vit_base_p16_224-80ecf9dd.pth"
+            elif arch_config == 'large_patch14_224':          # extension: BASELINE config 5
+                model = SpaceTimeTransformer(patch_size=14, embed_dim=1024, depth=24, num_heads=16,
+                                             num_frames=num_frames, time_init=time_init,
+                                             attention_style=attention_style)
+                vit_path = None
+            else:
+                raise NotImplementedError                                                        # :53
+            model.head = nn.Identity()
+            model.pre_logits = nn.Identity()
+            ftr_dim = model.embed_dim
+            if load_checkpoint in ["", None] and vit_path and os.path.exists(vit_path):
+                vit_checkpoint = torch.load(vit_path, map_location="cpu")
+                new_vit_dict = state_dict_data_parallel_fix(vit_checkpoint, model.state_dict())
+                model.load_state_dict(new_vit_dict, strict=False)                                # :58-63
+            self.video_model = model
+        else:
+            raise NotImplementedError(f"{video_params['model']} not implemented")               # :66
+        self.video_model.fc = nn.Identity()
+
+        if projection == 'minimal':
+            txt_proj = _ReluLinear(nn.ReLU(), nn.Linear(self.text_model.config.hidden_size, projection_dim))
+            vid_proj = nn.Sequential(nn.Linear(ftr_dim, projection_dim))
+        elif projection == '':
+            txt_proj = nn.Identity()
+            vid_proj = nn.Identity()
+        else:
+            raise NotImplementedError                                                            # :84
+        self.txt_proj = txt_proj
+        self.vid_proj = vid_proj
+        self._wc = WeightCache()
+
+        if load_checkpoint not in ["", None]:
+            local_rank = int(os.environ.get('LOCAL_RANK', 0))
+            dev = 'cuda:{}'.format(local_rank) if torch.cuda.is_available() else 'cpu'
+            checkpoint = torch.load(load_checkpoint, map_location=dev)
+            state_dict = checkpoint['state_dict']
+            new_state_dict = state_dict_data_parallel_fix(state_dict, self.state_dict())
+            new_state_dict = self._inflate_positional_embeds(new_state_dict)
+            self.load_state_dict(new_state_dict, strict=True)                                    # :88-95
+
+    def set_device(self, device):
+        self.device = device
+
+    def forward(self, data, video_only=False, return_embeds=True):
+        if video_only:
+            return self.compute_video(data['video'])
+        text_embeddings = self.compute_text(data['text'])
+        video_embeddings = self.compute_video(data['video'])
+        if return_embeds:
+            return text_embeddings, video_embeddings
+        return sim_matrix(text_embeddings, video_embeddings)
+
+    def _txt(self, x2d):
+        if isinstance(self.txt_proj, nn.Identity):
+            return x2d
+        lin = self.txt_proj[1]
+        return _ProjFn.apply(x2d, lin.weight, lin.bias, True, self._wc)
+
+    def compute_text(self, text_data):
+        if not self.text_params['model'].startswith('distilbert'):
+            raise NotImplementedError
+        hidden = self.text_model(**text_data).last_hidden_state          # :122
+        return self._txt(hidden[:, 0, :])
+
+    def compute_text_tokens(self, text_data):
+        hidden = self.text_model(**text_data).last_hidden_state          # :133
+        B, L, D = hidden.shape
+        y = self._txt(hidden.reshape(B * L, D))
+        return y.view(B, L, -1)
+
+    def compute_video(self, video_data):
+        v = self.video_model(video_data)
+        if isinstance(self.vid_proj, nn.Identity):
+            return v
+        lin = self.vid_proj[0]
+        return _ProjFn.apply(v, lin.weight, lin.bias, False, self._wc)
+
+    def _inflate_positional_embeds(self, new_state_dict):
+        """model/model.py:145-187: adapt temporal_embed when the checkpoint has a different num_frames."""
+        curr_keys = list(self.state_dict().keys())
+        if 'video_model.temporal_embed' in new_state_dict and 'video_model.temporal_embed' in curr_keys:
+            load_temporal_embed = new_state_dict['video_model.temporal_embed']
+            load_num_frames = load_temporal_embed.shape[1]
+            curr_num_frames = self.video_params['num_frames']
+            embed_dim = load_temporal_embed.shape[2]
+            if load_num_frames != curr_num_frames:
+                if load_num_frames > curr_num_frames:
+                    new_temporal_embed = load_temporal_embed[:, :curr_num_frames, :]
+                else:
+                    if self.load_temporal_fix == 'zeros':
+                        new_temporal_embed = torch.zeros([load_temporal_embed.shape[0], curr_num_frames, embed_dim])
+                        new_temporal_embed[:, :load_num_frames] = load_temporal_embed
+                    elif self.load_temporal_fix in ['interp', 'bilinear']:
+                        mode = 'bilinear' if self.load_temporal_fix == 'bilinear' else 'nearest'
+                        new_temporal_embed = F.interpolate(load_temporal_embed.unsqueeze(0),
+                                                           (curr_num_frames, embed_dim), mode=mode,
+                                                           align_corners=True).squeeze(0)
+                    else:
+                        raise NotImplementedError
+                new_state_dict['video_model.temporal_embed'] = new_temporal_embed
+        if 'video_model.pos_embed' in new_state_dict and 'video_model.pos_embed' in curr_keys:
+            if new_state_dict['video_model.pos_embed'].shape[1] != self.state_dict()['video_model.pos_embed'].shape[1]:
+                raise NotImplementedError(
+                    'Loading models with different spatial resolution / patch number not yet implemented, sorry.')
+        return new_state_dict
+
+
+class _SimMatrixFn(torch.autograd.Function):
+    """sim_matrix(a, b, eps) = (a / max(|a|, eps)) @ (b / max(|b|, eps))^T, model/model.py:189-197, for the
+    square case through the contrastive-head kernels (egv_egonce_fwd_bwd writes x and its row/col maths)."""
+
+    @staticmethod
+    def forward(ctx, a, b, eps):
+        from ..loss_ops import sim_fwd
+        sim, ctxdata = sim_fwd(a, b, eps)
+        ctx.data = ctxdata
+        return sim
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..loss_ops import sim_bwd
+        da, db = sim_bwd(ctx.data, g)
+        return da, db, None
+
+
+def sim_matrix(a, b, eps=1e-8):
+    """added eps for numerical stability (model/model.py:189-197)."""
+    return _SimMatrixFn.apply(a, b, eps)

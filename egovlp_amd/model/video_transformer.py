@@ -1,0 +1,345 @@
+"""SpaceTimeTransformer on MI355X kernels -- drop-in for the reference's model/video_transformer.py.
+
+Same constructor, same parameter names and shapes (state_dict compatible), same
+arithmetic (reference lines cited inline), different execution: one autograd node per
+SpaceTimeBlock whose forward and hand-written backward are sequences of enqueues of the gfx950
+kernels behind include/egovlp_hip.h.  The residual stream is fp32; every GEMM operand is a
+split-bf16 plane pair produced by the epilogue of the kernel before it (LayerNorm, attention, GELU),
+so no activation is ever re-formatted in a separate pass in forward.
+
+nn.Linear / nn.LayerNorm / nn.Conv2d are used as PARAMETER CONTAINERS only (names + default init
+identical to the reference); their own forward is never called.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_GELU_BWD, Planes, Precision
+from ..weights import WeightCache
+
+
+def _lin_bwd(dy_f32, x_pl: Planes, wt: Planes, Pb, need_dx=True, dy_planes=None, dy_t=None, db=None):
+    """Backward of y = x W^T + b given dy (fp32 [M,N]) or already-split dy planes.
+    -> (dx fp32 [M,K] | None, dW fp32 [N,K], db [N])."""
+    M, K = x_pl.rows, x_pl.cols
+    if dy_planes is None or dy_t is None:
+        dy_planes, dy_t, db = ops.split_f32(dy_f32, Pb, want_rowmajor=need_dx, want_transposed=True, want_colsum=True)
+    N = dy_t.rows
+    x_t, _ = ops.transpose_planes(x_pl, Pb)
+    dW = torch.empty((N, K), dtype=torch.float32, device=x_pl.hi.device)
+    Kc = ops.pad32(M)
+    ops.gemm_nt(dy_t, x_t, passes=Pb, out_f32=dW, ksplit=ops.pick_ksplit(N, K, Kc), K=Kc)
+    dx = None
+    if need_dx:
+        dx = torch.empty((M, K), dtype=torch.float32, device=x_pl.hi.device)
+        ops.gemm_nt(dy_planes, wt, passes=Pb, out_f32=dx, K=N)
+    return dx, dW, db
+
+
+class _SpaceTimeBlockFn(torch.autograd.Function):
+    """SpaceTimeBlock.forward, model/video_transformer.py:163-177:
+         t  = timeattn(norm3(x));  tr = x + t
+         s  = attn(norm1(tr));     sr = x + s          (residual from x, NOT tr -- :171)
+         out = sr + mlp(norm2(sr))
+    """
+
+    @staticmethod
+    def forward(ctx, x, geom, wc: WeightCache,
+                n3w, n3b, tqkv_w, tqkv_b, tproj_w, tproj_b,
+                n1w, n1b, sqkv_w, sqkv_b, sproj_w, sproj_b,
+                n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+        B, T, n, H, eps = geom
+        S = 1 + T * n
+        D = x.shape[-1]
+        M = B * S
+        P = Precision.fwd_passes
+        dev = x.device
+        x2 = x.contiguous().view(M, D)
+        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, n3w, tqkv_w, fc1_w))
+
+        def W(p):
+            return wc.get(p, need_t=False)[0]
+
+        # ---- temporal attention branch (:166-167)
+        n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P)
+        qkv_t = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
+        ops.gemm_nt(n3, W(tqkv_w), passes=P, bias=tqkv_b, out_f32=qkv_t)
+        a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, P)
+        tr = torch.empty((M, D), dtype=torch.float32, device=dev)
+        ops.gemm_nt(a_t, W(tproj_w), passes=P, bias=tproj_b, residual=x2, out_f32=tr)
+        # ---- spatial attention branch (:168-171)
+        n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P)
+        qkv_s = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
+        ops.gemm_nt(n1, W(sqkv_w), passes=P, bias=sqkv_b, out_f32=qkv_s)
+        a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, P)
+        sr = torch.empty((M, D), dtype=torch.float32, device=dev)
+        ops.gemm_nt(a_s, W(sproj_w), passes=P, bias=sproj_b, residual=x2, out_f32=sr)
+        # ---- MLP (:175, Mlp.forward :46-52), exact-erf GELU fused into the fc1 epilogue
+        n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P)
+        Hd = fc1_w.shape[0]
+        h = ops.empty_planes(M, Hd, P, dev)
+        z = torch.empty((M, Hd), dtype=torch.float32, device=dev) if train else None
+        ops.gemm_nt(n2, W(fc1_w), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h)
+        out = torch.empty((M, D), dtype=torch.float32, device=dev)
+        ops.gemm_nt(h, W(fc2_w), passes=P, bias=fc2_b, residual=sr, out_f32=out)
+
+        if train:
+            ctx.geom, ctx.wc, ctx.P = geom, wc, P
+            ctx.planes = (n3, a_t, n1, a_s, n2, h)
+            ctx.save_for_backward(x2, mean3, rstd3, qkv_t, lse_t, tr, mean1, rstd1, qkv_s, lse_s, sr, mean2, rstd2, z,
+                                  n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w)
+        return out.view(B, S, D)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (x2, mean3, rstd3, qkv_t, lse_t, tr, mean1, rstd1, qkv_s, lse_s, sr, mean2, rstd2, z,
+         n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w) = ctx.saved_tensors
+        n3, a_t, n1, a_s, n2, h = ctx.planes
+        B, T, n, H, eps = ctx.geom
+        wc = ctx.wc
+        Pb = Precision.bwd_passes
+        if Pb > ctx.P:
+            raise RuntimeError("backward precision bf16x3 needs a bf16x3 forward (the saved activation planes carry no lo part)")
+        M, D = x2.shape
+        G = g_out.contiguous().view(M, D)
+
+        def Wt(p):
+            return wc.get(p, need_t=True)[1]
+
+        # ---- MLP backward.  dZ = (G . W2) * gelu'(z) comes out of the fc2-dgrad epilogue already split.
+        G_pl, G_t, d_fc2_b = ops.split_f32(G, Pb, want_rowmajor=True, want_transposed=True, want_colsum=True)
+        Hd = fc1_w.shape[0]
+        dZ = ops.empty_planes(M, Hd, Pb, G.device)
+        ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
+        _, d_fc2_w, _ = _lin_bwd(None, h, None, Pb, need_dx=False, dy_planes=G_pl, dy_t=G_t, db=d_fc2_b)
+        dZ_t, d_fc1_b = ops.transpose_planes(dZ, Pb, want_colsum=True)
+        d_n2, d_fc1_w, _ = _lin_bwd(None, n2, Wt(fc1_w), Pb, dy_planes=dZ, dy_t=dZ_t, db=d_fc1_b)
+        # d_sr = G + LN2'(d_n2)
+        d_sr, d_n2w, d_n2b = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G)
+        # ---- spatial attention backward
+        d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr, a_s, Wt(sproj_w), Pb)
+        d_qkv_s = ops.divided_attn_bwd(qkv_s, d_as, lse_s, B, T, n, H, 0, Pb)
+        d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb)
+        d_tr, d_n1w, d_n1b = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1)
+        # ---- temporal attention backward
+        d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr, a_t, Wt(tproj_w), Pb)
+        d_qkv_t = ops.divided_attn_bwd(qkv_t, d_at, lse_t, B, T, n, H, 1, Pb)
+        d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb)
+        # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
+        d_x, d_n3w, d_n3b = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr)
+        S = 1 + T * n
+        return (d_x.view(B, S, D), None, None,
+                d_n3w, d_n3b, d_tqkv_w, d_tqkv_b, d_tproj_w, d_tproj_b,
+                d_n1w, d_n1b, d_sqkv_w, d_sqkv_b, d_sproj_w, d_sproj_b,
+                d_n2w, d_n2b, d_fc1_w.view_as(fc1_w), d_fc1_b, d_fc2_w.view_as(fc2_w), d_fc2_b)
+
+
+class _PatchTokensFn(torch.autograd.Function):
+    """VideoPatchEmbed (:72-77) + flatten/CLS/pos/temporal (:305-320): patch gather -> MFMA GEMM (+bias)
+    -> token assembly.  No gradient flows to the input frames."""
+
+    @staticmethod
+    def forward(ctx, video, geom, wc, proj_w, proj_b, cls_token, pos_embed, temporal_embed):
+        B, T, n, P_, D, T_model = geom
+        Pp = Precision.fwd_passes
+        a = ops.patch_gather(video.contiguous(), P_, Pp)
+        pe = torch.empty((a.rows, D), dtype=torch.float32, device=video.device)
+        ops.gemm_nt(a, wc.get(proj_w, need_t=False)[0], passes=Pp, bias=proj_b, out_f32=pe)
+        x = ops.assemble_tokens(pe, cls_token, pos_embed, temporal_embed, B, T, n, D)
+        ctx.geom, ctx.a, ctx.Pp = geom, a, Pp
+        ctx.wshape = proj_w.shape
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, T, n, P_, D, T_model = ctx.geom
+        Pb = Precision.bwd_passes
+        d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
+        _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False)
+        return None, None, None, d_w.view(ctx.wshape), d_b, d_cls, d_pos, d_tmp
+
+
+class _ClsNormFn(torch.autograd.Function):
+    """`self.norm(x)[:, 0]` (:330): LayerNorm is per token, so only the B CLS rows are normalised."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        B, S, D = x.shape
+        xc = x.contiguous()
+        _, y, mean, rstd, _ = ops.layernorm_fwd(xc.view(B * S, D), w, b, eps, 1, want_f32=True, want_planes=False,
+                                                rows=B, ldx=S * D)
+        ctx.save_for_backward(xc, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w, mean, rstd = ctx.saved_tensors
+        B, S, D = xc.shape
+        dx = torch.zeros_like(xc)
+        _, dg, db = ops.layernorm_bwd(dy.contiguous(), xc.view(B * S, D), w, mean, rstd, rows=B, ldx=S * D,
+                                      dx=dx.view(B * S, D), lddx=S * D)
+        return dx, dg, db, None
+
+
+def to_2tuple(x):
+    return x if isinstance(x, tuple) else (x, x)
+
+
+class Mlp(nn.Module):
+    """Parameter container for model/video_transformer.py:36-52 (fc1 -> GELU -> fc2)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        if drop != 0.:
+            raise NotImplementedError("dropout > 0 is not on the EgoClip hot path (video drop rates are all 0)")
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+
+class VideoPatchEmbed(nn.Module):
+    """model/video_transformer.py:55-77."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, num_frames=8):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0]) * num_frames
+        self.num_frames = num_frames
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class VarAttention(nn.Module):
+    """Parameter container for model/video_transformer.py:80-98 (incl. the 'zeros' initialisation :90-96)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.,
+                 initialize='random'):
+        super().__init__()
+        if attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError("attention dropout is 0 on the EgoClip hot path")
+        if dim // num_heads != 64:
+            raise NotImplementedError("the gfx950 attention kernels are built for head_dim 64 (ViT-B/16, ViT-L/14)")
+        if qk_scale is not None and qk_scale != 64 ** -0.5:
+            raise NotImplementedError("qk_scale override is not supported")
+        self.num_heads = num_heads
+        self.scale = 64 ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        if initialize == 'zeros':
+            self.qkv.weight.data.fill_(0)
+            self.qkv.bias.data.fill_(0)
+            self.proj.weight.data.fill_(1)
+            self.proj.bias.data.fill_(0)
+
+
+class SpaceTimeBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, time_init='zeros',
+                 attention_style='frozen-in-time'):
+        super().__init__()
+        if drop_path != 0.:
+            raise NotImplementedError("stochastic depth is 0 on the EgoClip hot path")
+        if attention_style != 'frozen-in-time':
+            raise NotImplementedError  # model/video_transformer.py:173
+        self.norm1 = norm_layer(dim)
+        self.attn = VarAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                 attn_drop=attn_drop, proj_drop=drop)
+        self.timeattn = VarAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                     attn_drop=attn_drop, proj_drop=drop, initialize=time_init)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.norm3 = norm_layer(dim)
+        self.num_heads = num_heads
+        self.attention_style = attention_style
+
+    def forward(self, x, B, T, n, wc):
+        geom = (B, T, n, self.num_heads, self.norm1.eps)
+        return _SpaceTimeBlockFn.apply(
+            x, geom, wc,
+            self.norm3.weight, self.norm3.bias, self.timeattn.qkv.weight, self.timeattn.qkv.bias,
+            self.timeattn.proj.weight, self.timeattn.proj.bias,
+            self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
+            self.attn.proj.weight, self.attn.proj.bias,
+            self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias,
+            self.mlp.fc2.weight, self.mlp.fc2.bias)
+
+
+class SpaceTimeTransformer(nn.Module):
+    """Drop-in for model/video_transformer.py:180-338 (same ctor signature :196-199)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., hybrid_backbone=None, norm_layer=None,
+                 num_frames=8, time_init='rand', attention_style='frozen-in-time'):
+        super().__init__()
+        if hybrid_backbone is not None:
+            raise NotImplementedError('hybrid backbone not implemented')       # :231
+        if drop_rate != 0. or attn_drop_rate != 0. or drop_path_rate != 0.:
+            raise NotImplementedError("non-zero video drop rates are not on the EgoClip hot path (model/model.py:49-51)")
+        if representation_size:
+            raise NotImplementedError("representation_size (pre_logits) is not on the EgoClip hot path")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_frames = num_frames
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)             # :228
+        self.patch_embed = VideoPatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                           embed_dim=embed_dim, num_frames=num_frames)
+        num_patches = self.patch_embed.num_patches
+        self.patches_per_frame = num_patches // num_frames
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patches_per_frame + 1, embed_dim))
+        self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, embed_dim))
+        self.blocks = nn.ModuleList([
+            SpaceTimeBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                           qk_scale=qk_scale, norm_layer=norm_layer, time_init=time_init,
+                           attention_style=attention_style)
+            for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        nn.init.trunc_normal_(self.pos_embed, std=.02, a=-2., b=2.)            # :264-265
+        nn.init.trunc_normal_(self.cls_token, std=.02, a=-2., b=2.)
+        if num_frames == 1:                                                    # :272-273
+            self.apply(self._init_weights)
+        self._wc = WeightCache()
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02, a=-2., b=2.)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def forward_features(self, x):
+        b, curr_frames, channels, Hh, Ww = x.shape
+        assert curr_frames <= self.num_frames                                  # :74
+        P_ = self.patch_embed.patch_size[0]
+        n = (Hh // P_) * (Ww // P_)
+        if n != self.patches_per_frame:
+            raise NotImplementedError("input resolution must match the positional embedding")
+        geom = (b, curr_frames, n, P_, self.embed_dim, self.num_frames)
+        x = _PatchTokensFn.apply(x, geom, self._wc, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
+                                 self.cls_token, self.pos_embed, self.temporal_embed)
+        for blk in self.blocks:                                                # :325-328
+            x = blk(x, b, curr_frames, n, self._wc)
+        x = _ClsNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)   # :330
+        return self.pre_logits(x)
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        if not isinstance(self.head, nn.Identity):
+            raise NotImplementedError("classification head: FrozenInTime replaces it with Identity (model/model.py:55)")
+        return x

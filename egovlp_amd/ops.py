@@ -1,0 +1,338 @@
+"""Thin tensor-level wrappers over the C ABI (include/egovlp_hip.h).
+
+PyTorch is used here for what the task statement calls plumbing: device memory (caching
+allocator), streams and autograd bookkeeping.  Every arithmetic op below is one enqueue of a
+hand-written gfx950 kernel on the current HIP stream; nothing falls back to ATen math.
+
+Data format: an fp32-grade activation that feeds a GEMM lives as `Planes` = (hi, lo) bf16
+tensors with hi = bf16(x), lo = bf16(x - hi).  `passes` = 3 uses both (fp32-grade product on bf16
+MFMA), `passes` = 1 uses hi only (plain bf16).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
+
+
+class Precision:
+    """Global precision policy.  'bf16x3' = split-bf16, three MFMA passes, fp32-grade (meets the
+    1e-3 parity bar); 'bf16' = single pass.  fwd/bwd are set independently."""
+    fwd_passes = 3
+    bwd_passes = 3
+
+    @classmethod
+    def set(cls, fwd: str = "bf16x3", bwd: Optional[str] = None):
+        table = {"bf16x3": 3, "bf16": 1}
+        cls.fwd_passes = table[fwd]
+        cls.bwd_passes = table[bwd if bwd is not None else fwd]
+
+    @classmethod
+    def name(cls):
+        inv = {3: "bf16x3", 1: "bf16"}
+        return inv[cls.fwd_passes], inv[cls.bwd_passes]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class KernelTimer:
+    """Opt-in HIP-event timing of individual C-ABI calls (bench.py's roofline leg).  Events are recorded on
+    the stream the kernel is launched on, immediately before and after the enqueue."""
+
+    def __init__(self):
+        self.records = {}
+
+    def time(self, name, flops, fn):
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        fn()
+        e1.record(st)
+        self.records.setdefault(name, []).append((e0, e1, flops))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            out[name] = {"launches": len(recs), "seconds": sum(a.elapsed_time(b) for a, b, _ in recs) * 1e-3,
+                         "flops": float(sum(f for _, _, f in recs))}
+        return out
+
+
+KERNEL_TIMER = None
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.EgovlpHipError("egovlp_amd ops need tensors resident in HBM (device 'cuda'); "
+                                      "there is no CPU path in the product")
+
+
+@dataclass
+class Planes:
+    hi: torch.Tensor                 # bf16 [rows, ld]
+    lo: Optional[torch.Tensor]       # bf16 [rows, ld] or None (passes == 1)
+    rows: int
+    cols: int                        # logical columns (<= ld)
+
+    @property
+    def ld(self):
+        return self.hi.stride(0)
+
+    def float(self):
+        v = self.hi[:, : self.cols].float()
+        if self.lo is not None:
+            v = v + self.lo[:, : self.cols].float()
+        return v
+
+
+def empty_planes(rows, cols, passes, device, ld=None, zero=False):
+    ld = cols if ld is None else ld
+    mk = torch.zeros if zero else torch.empty
+    hi = mk((rows, ld), dtype=torch.bfloat16, device=device)
+    lo = mk((rows, ld), dtype=torch.bfloat16, device=device) if passes == 3 else None
+    return Planes(hi, lo, rows, cols)
+
+
+def pad32(n):
+    return (n + 31) // 32 * 32
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_NONE, aux_in=None, aux_out=None,
+            out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=1, K=None):
+    """C[M,N] = A[M,K] . B[N,K]^T with the fused epilogue of egv_gemm_nt.  A.rows = M, B.rows = N."""
+    M, N = a.rows, b.rows
+    K = a.cols if K is None else K
+    d = GemmDesc()
+    d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
+    d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
+    d.M, d.N, d.K, d.passes = M, N, K, passes
+    d.alpha, d.act = alpha, act
+    d.bias = _p(bias)
+    d.residual, d.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
+    aux = aux_in if aux_in is not None else aux_out
+    d.aux_in, d.aux_out, d.ldaux = _p(aux_in), _p(aux_out), (aux.stride(0) if aux is not None else 0)
+    d.out_f32, d.ldo = _p(out_f32), (out_f32.stride(0) if out_f32 is not None else 0)
+    if out_planes is not None:
+        d.out_hi, d.out_lo, d.ldoh = _p(out_planes.hi), _p(out_planes.lo), out_planes.ld
+    partial = None
+    if ksplit > 1:
+        partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device)
+    d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
+    if KERNEL_TIMER is not None:
+        KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * K,
+                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"))
+    else:
+        check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
+
+
+def pick_ksplit(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ks = K // 32
+    want = max(1, 1024 // max(tiles, 1))
+    return max(1, min(want, ks // 8 if ks >= 16 else 1))
+
+
+# ---------------------------------------------------------------------------------------------- formats
+def split_f32(x2d: torch.Tensor, passes, *, want_rowmajor=True, want_transposed=False, want_colsum=False):
+    """fp32 [rows, cols] -> (Planes row-major | None, Planes transposed [cols, pad32(rows)] | None, colsum | None)."""
+    _need_cuda(x2d)
+    rows, cols = x2d.shape
+    dev = x2d.device
+    pl = empty_planes(rows, cols, passes, dev) if want_rowmajor else None
+    tp = empty_planes(cols, rows, passes, dev, ld=pad32(rows)) if want_transposed else None
+    cs = torch.empty(cols, dtype=torch.float32, device=dev) if want_colsum else None
+    check(_lib.lib().egv_split_f32(
+        _p(x2d), x2d.stride(0), rows, cols,
+        _p(pl.hi) if pl else None, _p(pl.lo) if pl else None, pl.ld if pl else 0,
+        _p(tp.hi) if tp else None, _p(tp.lo) if tp else None, tp.ld if tp else 0,
+        _p(cs), _stream()), "egv_split_f32")
+    return pl, tp, cs
+
+
+def transpose_planes(x: Planes, passes, want_colsum=False):
+    """Planes [rows, cols] -> Planes [cols, pad32(rows)] (zero pad) (+ column sums of hi+lo)."""
+    dev = x.hi.device
+    tp = empty_planes(x.cols, x.rows, passes, dev, ld=pad32(x.rows))
+    cs = torch.empty(x.cols, dtype=torch.float32, device=dev) if want_colsum else None
+    check(_lib.lib().egv_transpose_planes(_p(x.hi), _p(x.lo) if passes == 3 else None, x.ld, x.rows, x.cols,
+                                          _p(tp.hi), _p(tp.lo), tp.ld, _p(cs), _stream()), "egv_transpose_planes")
+    return tp, cs
+
+
+def relu_split(x2d: torch.Tensor, passes) -> Planes:
+    rows, cols = x2d.shape
+    pl = empty_planes(rows, cols, passes, x2d.device)
+    check(_lib.lib().egv_relu_split(_p(x2d), x2d.stride(0), rows, cols, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
+          "egv_relu_split")
+    return pl
+
+
+# --------------------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, want_f32=False, want_planes=True,
+                  rows=None, ldx=None):
+    """rows of x2d (optionally x2d + x_add) -> (Planes | None, y_f32 | None, mean, rstd, sum | None).
+    `rows`/`ldx` allow strided row selection (e.g. only the CLS row of every clip)."""
+    _need_cuda(x2d, gamma, beta)
+    cols = x2d.shape[-1]
+    rows = x2d.shape[0] if rows is None else rows
+    ldx = x2d.stride(0) if ldx is None else ldx
+    dev = x2d.device
+    pl = empty_planes(rows, cols, passes, dev) if want_planes else None
+    yf = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_f32 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    s = torch.empty_like(x2d) if want_sum else None
+    check(_lib.lib().egv_layernorm_fwd(_p(x2d), _p(x_add), ldx, _p(gamma), _p(beta), float(eps), rows, cols, _p(s),
+                                       _p(pl.hi) if pl else None, _p(pl.lo) if pl else None, _p(yf), cols,
+                                       _p(mean), _p(rstd), _stream()), "egv_layernorm_fwd")
+    return pl, yf, mean, rstd, s
+
+
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=None, ldx=None, dx=None, lddx=None):
+    """-> (dx [rows, cols] (= add1 + add2 + LN-backward), dgamma, dbeta)."""
+    cols = dy2d.shape[-1]
+    rows = dy2d.shape[0] if rows is None else rows
+    ldx = x2d.stride(0) if ldx is None else ldx
+    dev = dy2d.device
+    if dx is None:
+        dx = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+        lddx = cols
+    dg = torch.empty(cols, dtype=torch.float32, device=dev)
+    db = torch.empty(cols, dtype=torch.float32, device=dev)
+    parts = _lib.lib().egv_layernorm_bwd_parts(rows)
+    work = torch.empty(2 * cols * parts, dtype=torch.float32, device=dev)
+    check(_lib.lib().egv_layernorm_bwd(_p(dy2d), dy2d.stride(0), _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
+                                       cols, _p(add1), _p(add2), _p(dx), lddx, _p(dg), _p(db), _p(work), _stream()),
+          "egv_layernorm_bwd")
+    return dx, dg, db
+
+
+# ------------------------------------------------------------------------------------------ video tokens
+def patch_gather(video5d, P, passes) -> Planes:
+    B, T, Cc, H, W = video5d.shape
+    rows = B * T * (H // P) * (W // P)
+    K = Cc * P * P
+    pl = empty_planes(rows, K, passes, video5d.device)
+    check(_lib.lib().egv_patch_gather(_p(video5d), B * T, Cc, H, W, P, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
+          "egv_patch_gather")
+    return pl
+
+
+def assemble_tokens(pe, cls, pos, temporal, B, T, n, D):
+    x = torch.empty((B, 1 + T * n, D), dtype=torch.float32, device=pe.device)
+    check(_lib.lib().egv_assemble_tokens(_p(pe), _p(cls), _p(pos), _p(temporal), B, T, n, D, _p(x), _stream()),
+          "egv_assemble_tokens")
+    return x
+
+
+def assemble_tokens_bwd(dx, B, T, n, D, T_model):
+    dev = dx.device
+    d_pe = torch.empty((B * T * n, D), dtype=torch.float32, device=dev)
+    d_cls = torch.empty((1, 1, D), dtype=torch.float32, device=dev)
+    d_pos = torch.empty((1, n + 1, D), dtype=torch.float32, device=dev)
+    d_tmp = torch.zeros((1, T_model, D), dtype=torch.float32, device=dev)
+    check(_lib.lib().egv_assemble_tokens_bwd(_p(dx), B, T, n, D, T_model, _p(d_pe), _p(d_cls), _p(d_pos), _p(d_tmp),
+                                             _stream()), "egv_assemble_tokens_bwd")
+    return d_pe, d_cls, d_pos, d_tmp
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def divided_attn_fwd(qkv, B, T, n, H, mode, passes):
+    """qkv fp32 [B*S, 3*H*64] -> (Planes [B*S, H*64], lse [B,H,S])."""
+    S = 1 + T * n
+    out = empty_planes(B * S, H * 64, passes, qkv.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().egv_divided_attn_fwd(_p(qkv), B, T, n, H, mode, passes, _p(out.hi), _p(out.lo), _p(lse),
+                                          _stream()), "egv_divided_attn_fwd")
+    return out, lse
+
+
+def divided_attn_bwd(qkv, d_out, lse, B, T, n, H, mode, passes):
+    S = 1 + T * n
+    dqkv = torch.empty_like(qkv)
+    work = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().egv_divided_attn_bwd(_p(qkv), _p(d_out), _p(lse), B, T, n, H, mode, passes, _p(dqkv), _p(work),
+                                          _stream()), "egv_divided_attn_bwd")
+    return dqkv
+
+
+def text_attn_fwd(q, k, v, mask, B, L, H, passes):
+    out = empty_planes(B * L, H * 64, passes, q.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+    check(_lib.lib().egv_text_attn_fwd(_p(q), _p(k), _p(v), _p(mask), B, L, H, passes, _p(out.hi), _p(out.lo),
+                                       _p(lse), _stream()), "egv_text_attn_fwd")
+    return out, lse
+
+
+def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes):
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    work = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
+    check(_lib.lib().egv_text_attn_bwd(_p(q), _p(k), _p(v), _p(mask), _p(d_out), _p(lse), B, L, H, passes, _p(dq),
+                                       _p(dk), _p(dv), _p(work), _stream()), "egv_text_attn_bwd")
+    return dq, dk, dv
+
+
+def embed_fwd(ids, word, pos, D):
+    B, L = ids.shape
+    e = torch.empty((B * L, D), dtype=torch.float32, device=word.device)
+    check(_lib.lib().egv_embed_fwd(_p(ids), _p(word), _p(pos), B, L, D, _p(e), _stream()), "egv_embed_fwd")
+    return e
+
+
+def embed_bwd(ids, d_e, word_shape, pos_shape, pad_id=-1):
+    B, L = ids.shape
+    D = word_shape[1]
+    d_word = torch.zeros(word_shape, dtype=torch.float32, device=d_e.device)
+    d_pos = torch.zeros(pos_shape, dtype=torch.float32, device=d_e.device)
+    check(_lib.lib().egv_embed_bwd(_p(ids), _p(d_e), B, L, D, int(pad_id), _p(d_word), _p(d_pos), _stream()),
+          "egv_embed_bwd")
+    return d_word, d_pos
+
+
+# ------------------------------------------------------------------------------------------- loss / optim
+def egonce_fwd_bwd(text, video, noun, verb, temperature, eps=1e-8, use_noun=True, use_verb=True, want_grads=True,
+                   want_sim=False):
+    _need_cuda(text, video, noun, verb)
+    n, D = text.shape
+    dev = text.device
+    dn = noun.shape[1] if noun is not None else 0
+    dv = verb.shape[1] if verb is not None else 0
+    wf = _lib.lib().egv_egonce_work_floats(n, D)
+    work = torch.empty(wf, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    sim = torch.empty((n, n), dtype=torch.float32, device=dev) if want_sim else None
+    dt = torch.empty_like(text) if want_grads else None
+    dvv = torch.empty_like(video) if want_grads else None
+    check(_lib.lib().egv_egonce_fwd_bwd(_p(text), _p(video), _p(noun), _p(verb), n, D, dn, dv, float(temperature),
+                                        float(eps), int(use_noun), int(use_verb), _p(loss), _p(sim), _p(dt), _p(dvv),
+                                        _p(work), _stream()), "egv_egonce_fwd_bwd")
+    return loss, sim, dt, dvv
+
+
+def adamw_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step, correct_bias=True, grad_scale=1.0):
+    n = len(params)
+    arr = C.c_void_p * n
+    P = arr(*[p.data_ptr() for p in params])
+    G = arr(*[g.data_ptr() for g in grads])
+    M_ = arr(*[m.data_ptr() for m in ms])
+    V = arr(*[v.data_ptr() for v in vs])
+    N = (C.c_int64 * n)(*[p.numel() for p in params])
+    check(_lib.lib().egv_adamw_multi(n, P, G, M_, V, None, None, N, float(lr), float(beta1), float(beta2),
+                                     float(eps), float(weight_decay), int(step), int(correct_bias),
+                                     float(grad_scale), _stream()), "egv_adamw_multi")

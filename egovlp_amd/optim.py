@@ -1,0 +1,60 @@
+"""AdamW with transformers==4.2.1 semantics on the fused multi-tensor kernel (egv_adamw_multi).
+
+The reference builds its optimizer with `config.initialize('optimizer', transformers, params)`
+(run/train_egoclip.py:72-73) -> `transformers.AdamW(lr=3e-5)` with that version's defaults
+betas (0.9, 0.999), eps 1e-6, weight_decay 0.0, correct_bias True.  transformers 5.x no longer
+ships AdamW, so this module is what `optimizer.type == "AdamW"` resolves to.
+"""
+import torch
+
+from . import ops, weights
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameters: {}".format(betas))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            ps, gs, ms, vs = [], [], [], []
+            step = None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("AdamW does not support sparse gradients")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                if step is None:
+                    step = st["step"]
+                elif step != st["step"]:
+                    # tensors at different step counts get their own launch group
+                    self._launch(group, ps, gs, ms, vs, step, grad_scale)
+                    ps, gs, ms, vs, step = [], [], [], [], st["step"]
+                if not (p.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("AdamW (HIP) needs contiguous parameters and gradients")
+                ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+            self._launch(group, ps, gs, ms, vs, step, grad_scale)
+        weights.bump_epoch()   # parameters were written through raw pointers: invalidate the bf16 planes
+        return loss
+
+    @staticmethod
+    def _launch(group, ps, gs, ms, vs, step, grad_scale):
+        if not ps:
+            return
+        b1, b2 = group["betas"]
+        ops.adamw_multi(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
+                        group["correct_bias"], grad_scale)

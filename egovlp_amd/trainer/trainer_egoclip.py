@@ -1,0 +1,150 @@
+"""EgoClip pre-training step -- drop-in for the reference's trainer/trainer_egoclip.py.
+
+`AllGather_multi` keeps the reference's autograd contract (trainer/trainer_egoclip.py:11-27): forward =
+all-gather + rank-major concatenation, backward = the LOCAL rows of the incoming gradient, no reduction
+(every rank computes the identical global loss; DDP's mean over ranks then yields (1/W) dL_global/dtheta,
+SURVEY 3.2).  On MI355X the four per-step gathers of the reference (:126-129: video, text, noun, verb =
+four latency-bound RCCL launches + 4W allocations + 4 cats) become ONE `all_gather_into_tensor` of a
+packed [B, 256+256+582+118] fp32 row block (~152 KiB per rank at B=32) written straight into its final
+place -- xGMI is point-to-point, so for a payload this small launch latency, not link bandwidth, is
+what there is to save.  `backend='nccl'` on PyTorch-ROCm IS RCCL.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..model.model import sim_matrix
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
+    if world == 1:
+        return t
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+class AllGather_multi(torch.autograd.Function):
+    """An autograd function that performs allgather on a tensor (reference signature kept:
+    `AllGather_multi.apply(tensor, n_gpu, args)` with args.world_size / args.rank)."""
+
+    @staticmethod
+    def forward(ctx, tensor, n_gpu, args):
+        ctx.rank = args.rank
+        ctx.batch_size = tensor.shape[0]
+        return _gather_rows(tensor, args.world_size)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return (grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None, None)
+
+
+class AllGatherFused(torch.autograd.Function):
+    """(video_embeds, text_embeds, noun_vec, verb_vec) -> their global-batch versions with ONE collective."""
+
+    @staticmethod
+    def forward(ctx, video, text, noun, verb, world_size, rank):
+        ctx.rank, ctx.B = rank, video.shape[0]
+        if world_size == 1:
+            return video, text, noun, verb
+        widths = [video.shape[1], text.shape[1], noun.shape[1], verb.shape[1]]
+        packed = torch.cat([video, text, noun.to(video.dtype), verb.to(video.dtype)], dim=1)
+        allp = _gather_rows(packed, world_size)
+        v, t, n, b = torch.split(allp, widths, dim=1)
+        return v.contiguous(), t.contiguous(), n.contiguous(), b.contiguous()
+
+    @staticmethod
+    def backward(ctx, gv, gt, gn, gb):
+        lo, hi = ctx.B * ctx.rank, ctx.B * (ctx.rank + 1)
+        return gv[lo:hi], gt[lo:hi], None, None, None, None
+
+
+def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_head=True):
+    """One optimisation step = trainer/trainer_egoclip.py:123-141 (zero_grad, forward, gathers,
+    similarity + loss, backward, optimizer.step).  Returns the (device) loss tensor; no host sync."""
+    optimizer.zero_grad(set_to_none=True)
+    text_embeds, video_embeds = model(data)
+    n_embeds, v_embeds = data['noun_vec'], data['verb_vec']
+    video_embeds, text_embeds, n_embeds, v_embeds = AllGatherFused.apply(
+        video_embeds, text_embeds, n_embeds, v_embeds, world_size, rank)
+    is_ego = type(loss_fn).__name__ == 'EgoNCE'
+    if fused_head and hasattr(loss_fn, 'fused'):
+        loss = loss_fn.fused(text_embeds, video_embeds, n_embeds, v_embeds) if is_ego \
+            else loss_fn.fused(text_embeds, video_embeds)
+    else:
+        output = sim_matrix(text_embeds, video_embeds)                      # :130
+        if is_ego:
+            sim_v = sim_matrix(v_embeds, v_embeds)                          # :133
+            sim_n = sim_matrix(n_embeds, n_embeds)                          # :134
+            loss = loss_fn(output, sim_v, sim_n)                            # :135
+        else:
+            loss = loss_fn(output)
+    loss.backward()                                                         # :139
+    optimizer.step()                                                        # :141
+    return loss.detach()
+
+
+class Multi_Trainer_dist:
+    """The reference's trainer class reduced to the training hot loop (`_train_epoch`, :82-180) -- the
+    epoch/ckpt/validation scaffolding of base/base_trainer.py is boundary code that stays in Python in
+    the reference and is not rebuilt here."""
+
+    def __init__(self, args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader=None,
+                 lr_scheduler=None, len_epoch=None, writer=None, visualizer=None, tokenizer=None,
+                 max_samples_per_epoch=50000):
+        self.args, self.config = args, config
+        self.model, self.loss, self.optimizer = model, loss, optimizer
+        self.data_loader = data_loader
+        self.len_epoch = min(len(x) for x in data_loader) if len_epoch is None else len_epoch
+        self.tokenizer = tokenizer
+        self.max_samples_per_epoch = max_samples_per_epoch
+        self.n_gpu = self.args.world_size
+        self.allgather = AllGather_multi.apply
+        self.batch_size = self.data_loader[0].batch_size
+        self.log_step = int(np.sqrt(self.batch_size))
+        self.total_batch_sum = sum(x.batch_size for x in self.data_loader)
+        self.device = torch.device('cuda', getattr(args, 'local_rank', 0))
+
+    def _adjust_learning_rate(self, optimizer, epoch, args):
+        lr = args.learning_rate1                                            # :75-80
+        for milestone in args.schedule:
+            lr *= 0.1 if epoch >= milestone else 1.
+        for param_group in optimizer.param_groups:
+            param_group['lr'] = lr
+
+    def _train_epoch(self, epoch):
+        self.model.train()
+        total_loss = [torch.zeros((), device=self.device) for _ in self.data_loader]
+        for loader in self.data_loader:
+            if hasattr(loader, 'train_sampler'):
+                loader.train_sampler.set_epoch(epoch)
+        steps = 0
+        for batch_idx, data_li in enumerate(zip(*self.data_loader)):
+            if (batch_idx + 1) * self.total_batch_sum > self.max_samples_per_epoch:
+                break
+            for dl_idx, data in enumerate(data_li):
+                if 'video_neg' in data.keys():                              # :109-113
+                    data['text'] = data['text'] + data['text_neg']
+                    data['video'] = torch.cat((data['video'], data['video_neg']), axis=0)
+                    data['noun_vec'] = torch.cat((data['noun_vec'], data['noun_vec_neg']), axis=0)
+                    data['verb_vec'] = torch.cat((data['verb_vec'], data['verb_vec_neg']), axis=0)
+                if self.tokenizer is not None:
+                    data['text'] = self.tokenizer(data['text'], return_tensors='pt', padding=True, truncation=True)
+                data['text'] = {k: v.to(self.device) for k, v in data['text'].items()}
+                data['video'] = data['video'].to(self.device)
+                data['noun_vec'] = data['noun_vec'].to(self.device)
+                data['verb_vec'] = data['verb_vec'].to(self.device)
+                loss = egoclip_step(self.model, self.loss, self.optimizer, data, self.n_gpu, self.args.rank)
+                total_loss[dl_idx] += loss      # stays on device: no per-step .item() sync (reference :148,150)
+            steps += 1
+            if batch_idx == self.len_epoch:
+                break
+        log = {f'loss_{i}': float(t) / max(steps, 1) for i, t in enumerate(total_loss)}
+        self._adjust_learning_rate(self.optimizer, epoch, self.args)        # :178
+        return log

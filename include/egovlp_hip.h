@@ -1,0 +1,176 @@
+/* egovlp_hip.h -- C ABI of libegovlp_hip.so: the MI355X (gfx950) kernels behind the EgoVLP
+ * EgoClip pre-training hot path.
+ *
+ * The reference (showlab/EgoVLP) has NO native boundary: its hot path is reached through Python
+ * `nn.Module`s and every device kernel is implicit ATen/cuBLAS/cuDNN.  This header is the
+ * boundary a maintainer binds instead: each entry point below replaces the implicit kernels issued
+ * by the cited reference lines.  The binding is ctypes (egovlp_amd/_lib.py).
+ *
+ * Conventions
+ *  - plain pointers + sizes only; all pointers are DEVICE pointers (HBM) unless noted; buffers are
+ *    BORROWED for the duration of the enqueue (the caller -- PyTorch's caching allocator -- owns them);
+ *  - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (graph-capturable:
+ *    no allocation, no synchronisation, no host readback inside);
+ *  - return value: 0 = ok, 1 = invalid argument (nothing enqueued), >=2 = 2 + hipError_t of the launch;
+ *  - re-entrant and stateless (called from the autograd engine thread and DDP hooks as well);
+ *  - bf16 tensors are raw uint16 bit patterns.  "split planes" (x_hi, x_lo): x_hi = bf16(x),
+ *    x_lo = bf16(x - x_hi); x_lo may be NULL wherever `passes == 1` / documented optional;
+ *  - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef EGOVLP_HIP_H
+#define EGOVLP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t egv_bf16;
+
+enum { EGV_ACT_NONE = 0, EGV_ACT_GELU = 1, EGV_ACT_GELU_BWD = 2, EGV_ACT_RELU_BWD = 3 };
+
+/* ---- GEMM --------------------------------------------------------------------------------------
+ * C[M,N] = alpha * A[M,K] . B[N,K]^T, then (in this order) + bias[n], activation, + residual[m,n].
+ * Replaces nn.Linear / Conv2d-as-GEMM forward, dgrad and wgrad: model/video_transformer.py:41-50
+ * (Mlp fc1/fc2), :70,76 (patch-embed conv), :88-89,103,135 (qkv/proj); HF DistilBERT q/k/v/out_lin,
+ * ffn.lin1/lin2; model/model.py:72-79 (projections).  passes = 1: bf16 operands (hi planes only);
+ * passes = 3: split-bf16 operands, fp32-grade product.  Requirements: K % 32 == 0, N % 4 == 0,
+ * lda % 8 == ldb % 8 == 0, 16-byte aligned base pointers.
+ *  act = EGV_ACT_GELU      : v = gelu(v); if aux_out != NULL the pre-activation is stored there first
+ *  act = EGV_ACT_GELU_BWD  : v *= gelu'(aux_in[m,n])           (fc2 dgrad -> dZ)
+ *  act = EGV_ACT_RELU_BWD  : v  = aux_in[m,n] > 0 ? v : 0
+ * Outputs: any subset of out_f32 / (out_hi[, out_lo]).  Split-K (ksplit > 1, used by wgrad where
+ * K = #tokens): raw partial sums go to partial[ksplit][M][N] and a second kernel reduces them into
+ * out_f32 (ldo must equal N; accumulate != 0 adds to the existing contents); no epilogue then.   */
+typedef struct egv_gemm_desc {
+  const egv_bf16* a_hi; const egv_bf16* a_lo; int64_t lda;
+  const egv_bf16* b_hi; const egv_bf16* b_lo; int64_t ldb;
+  int32_t M, N, K, passes;
+  float alpha;
+  int32_t act;
+  const float* bias;
+  const float* residual; int64_t ldr;
+  const float* aux_in; float* aux_out; int64_t ldaux;
+  float* out_f32; int64_t ldo;
+  egv_bf16* out_hi; egv_bf16* out_lo; int64_t ldoh;
+  int32_t ksplit, accumulate;
+  float* partial;
+} egv_gemm_desc;
+int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
+
+/* ---- format kernels (HBM-bound) -----------------------------------------------------------------
+ * fp32 [rows, cols] -> split planes, optionally also the TRANSPOSED planes t_*[cols, ldt] (ldt >= rows,
+ * columns rows..ldt-1 are zero-filled so a following GEMM can contract over a K padded to 32) and the
+ * column sums colsum[cols] (= bias gradient; overwritten).  Any output may be NULL.               */
+int egv_split_f32(const float* x, int64_t ldx, int32_t rows, int32_t cols,
+                  egv_bf16* hi, egv_bf16* lo, int64_t ldo,
+                  egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream);
+/* split planes [rows, cols] -> transposed planes [cols, ldt] (+ zero pad, + colsum of hi+lo).        */
+int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, int32_t rows, int32_t cols,
+                         egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream);
+
+/* ---- LayerNorm ----------------------------------------------------------------------------------
+ * nn.LayerNorm over the last dim (video eps 1e-6: model/video_transformer.py:146,156,159,228,253;
+ * DistilBERT eps 1e-12).  Optional fused pre-add: the normalised input is x + x_add (DistilBERT's
+ * post-LN `LN(sublayer + x)`), and that sum is stored to sum_out if non-NULL.  Outputs: split planes
+ * and/or fp32; mean/rstd [rows] are saved for backward.                                            */
+int egv_layernorm_fwd(const float* x, const float* x_add, int64_t ldx, const float* gamma, const float* beta,
+                      float eps, int32_t rows, int32_t cols, float* sum_out,
+                      egv_bf16* y_hi, egv_bf16* y_lo, float* y_f32, int64_t ldy,
+                      float* mean, float* rstd, void* stream);
+/* dx[r,:] = (add1 + add2)[r,:] + LN'(dy; x, gamma, mean, rstd)[r,:];  dgamma/dbeta [cols] overwritten.
+ * `work` must hold 2 * cols * egv_layernorm_bwd_parts(rows) floats.                                */
+int egv_layernorm_bwd_parts(int32_t rows);
+int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, int32_t rows, int32_t cols,
+                      const float* add1, const float* add2, float* dx, int64_t lddx,
+                      float* dgamma, float* dbeta, float* work, void* stream);
+
+/* ---- video tokens -------------------------------------------------------------------------------
+ * Patch gather for the 16x16/s16 conv (model/video_transformer.py:70-77): video [B*T,C,H,W] fp32 ->
+ * A[(bt*gh + py)*gw + px][c*P*P + i*P + j] split planes, K = C*P*P (a multiple of 32 for P=16/C=3).   */
+int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
+                     egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream);
+/* x[b,0,:] = cls + pos[0]; x[b,1+f*n+i,:] = pe[(b*T+f)*n+i,:] + pos[1+i] + temporal[f]
+ * (model/video_transformer.py:305-320; pos tiling by the MODEL's num_frames, sliced to T).          */
+int egv_assemble_tokens(const float* pe, const float* cls, const float* pos, const float* temporal,
+                        int32_t B, int32_t T, int32_t n, int32_t D, float* x, void* stream);
+/* backward of the above: d_pe (gather), d_cls, d_pos [n+1,D], d_temporal [T_model,D] (rows >= T zeroed). */
+int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, int32_t n, int32_t D, int32_t T_model,
+                            float* d_pe, float* d_cls, float* d_pos, float* d_temporal, void* stream);
+
+/* ---- divided space-time attention ------------------------------------------------------------------
+ * VarAttention core (model/video_transformer.py:104-133) on the fused qkv buffer [B, S, 3, H, 64] fp32
+ * (S = 1 + T*n, token order 1 + f*n + i).  q is scaled by 64^-0.5 inside.  mode 0 = space
+ * (group = (b,f,h): n queries x (CLS + n) keys), mode 1 = time (group = (b,i,h): T queries x (CLS + T)
+ * keys).  The CLS query row (attends to all S keys, :112) is computed by the same call.  Output: split
+ * planes [B, S, H*64]; lse [B, H, S] (log-sum-exp of each query row, saved for backward).           */
+int egv_divided_attn_fwd(const float* qkv, int32_t B, int32_t T, int32_t n, int32_t H, int32_t mode,
+                         int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream);
+/* dqkv [B,S,3,H,64] fp32 is fully written (CLS rows zeroed inside, then accumulated).  d_out [B,S,H*64] fp32. */
+int egv_divided_attn_bwd(const float* qkv, const float* d_out, const float* lse, int32_t B, int32_t T,
+                         int32_t n, int32_t H, int32_t mode, int32_t passes, float* dqkv,
+                         float* work /* B*H*S floats (mode 0) */, void* stream);
+
+/* ---- DistilBERT pieces ----------------------------------------------------------------------------
+ * Embeddings (modeling_distilbert.py:82-118): e[b,l,:] = word[ids[b,l]] + pos[l] (fp32 sum; LN is a
+ * separate egv_layernorm_fwd).  Backward scatters d_e into d_word (atomic adds; d_word/d_pos must be
+ * zero-initialised by the caller) and reduces d_pos.                                               */
+int egv_embed_fwd(const int64_t* ids, const float* word, const float* pos, int32_t B, int32_t L, int32_t D,
+                  float* e, void* stream);
+int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, int32_t L, int32_t D, int64_t pad_id /* -1: none */,
+                  float* d_word, float* d_pos, void* stream);
+/* Masked multi-head attention (modeling_distilbert.py:122-203) on separate q,k,v [B, L, H*64] fp32;
+ * mask [B, L] int64 (0 = padded key -> -inf).  Output split planes [B, L, H*64]; probs are recomputed
+ * in backward from lse [B,H,L].                                                                     */
+int egv_text_attn_fwd(const float* q, const float* k, const float* v, const int64_t* mask, int32_t B, int32_t L,
+                      int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream);
+int egv_text_attn_bwd(const float* q, const float* k, const float* v, const int64_t* mask, const float* d_out,
+                      const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
+                      float* dq, float* dk, float* dv, float* delta_work /* B*H*L floats */, void* stream);
+
+/* ---- contrastive head ---------------------------------------------------------------------------------
+ * sim_matrix x3 + EgoNCE/NormSoftmaxLoss forward AND backward in one launch
+ * (model/model.py:189-197; model/loss.py:13-25,34-53; trainer/trainer_egoclip.py:130-137).
+ * text, video [n, D] fp32 (the all-gathered global batch); noun [n, dn], verb [n, dv] multi-hot fp32
+ * (NULL for NormSoftmaxLoss: mask = I).  Writes loss[1], sim [n,n] (optional), and the gradients of
+ * the loss w.r.t. text and video [n, D] (optional).  n <= 1024.  `use_noun/use_verb` mirror EgoNCE's ctor. */
+int egv_egonce_fwd_bwd(const float* text, const float* video, const float* noun, const float* verb,
+                       int32_t n, int32_t D, int32_t dn, int32_t dv, float temperature, float eps,
+                       int32_t use_noun, int32_t use_verb,
+                       float* loss, float* sim, float* d_text, float* d_video, float* work, void* stream);
+int64_t egv_egonce_work_floats(int32_t n, int32_t D);
+/* The same head in the reference's own decomposition (kept for API compatibility with code that calls
+ * model.model.sim_matrix and model.loss.EgoNCE(x, mask_v, mask_n) separately):
+ *  sim_matrix forward (any n, m, D): an/bn = normalised rows (saved for backward), norms [n+m], out [n,m];
+ *  sim_matrix backward: g [n,m] -> da [n,D], db [m,D] (either may be NULL);
+ *  EgoNCE / NormSoftmaxLoss on a given similarity matrix x [n,n] (sim_v/sim_n NULL => mask = I): loss[1], dx. */
+int egv_sim_matrix_fwd(const float* a, const float* b, int32_t n, int32_t m, int32_t D, float eps,
+                       float* an, float* bn, float* norms, float* out, void* stream);
+int egv_sim_matrix_bwd(const float* g, const float* an, const float* bn, const float* norms, int32_t n, int32_t m,
+                       int32_t D, float eps, float* da, float* db, void* stream);
+int egv_egonce_from_sim(const float* x, const float* sim_v, const float* sim_n, int32_t n, float temperature,
+                        int32_t use_noun, int32_t use_verb, float* loss, float* dx,
+                        float* work /* n*n + 6n floats */, void* stream);
+
+/* ---- optimizer ----------------------------------------------------------------------------------------
+ * transformers==4.2.1 AdamW (run/train_egoclip.py:73, configs/pt/egoclip.json:49-54) over a list of
+ * tensors given as HOST arrays of device pointers (copied into kernel arguments in chunks), fused with
+ * the refresh of the split-bf16 weight planes the GEMMs read (w_hi/w_lo may be NULL per tensor).    */
+int egv_adamw_multi(int32_t count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                    egv_bf16* const* w_hi, egv_bf16* const* w_lo, const int64_t* numel,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                    int32_t correct_bias, float grad_scale, void* stream);
+
+/* ---- misc -----------------------------------------------------------------------------------------------
+ * gather rows: out[r,:] = x[idx_stride * r * ld ...] helper for CLS-row extraction is done with strides in
+ * egv_layernorm_fwd (ldx = S*D, rows = B).  relu on fp32 -> split planes: */
+int egv_relu_split(const float* x, int64_t ldx, int32_t rows, int32_t cols, egv_bf16* hi, egv_bf16* lo,
+                   int64_t ldo, void* stream);
+/* scatter rows of a small matrix into a zeroed big one: dst[r * ld_dst + c] = src[r, c] (CLS-row grads). */
+int egv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -65,18 +65,19 @@ def attn(q, k, v):
     return torch.einsum("bij,bjd->bid", a, v)
 
 
-def var_attention(x, sd, prefix, num_heads, mode, n, f):
-    """VarAttention.forward, model/video_transformer.py:100-137.
+def var_attention_core(qkv, num_heads, mode, n, f):
+    """The attention part of VarAttention.forward (model/video_transformer.py:104-133) on the fused
+    qkv projection [B, S, 3*D]: everything between the qkv Linear (:103) and the proj Linear (:135).
 
     mode 'space': patches regrouped '(b f) n d' (each frame attends within itself),
     mode 'time' : patches regrouped '(b n) f d' (each location attends across frames);
     in both the CLS key/value is prepended to every group (:117-121) and the CLS query
     attends over ALL keys (:112).  q is scaled BEFORE the CLS split (:106).
     """
-    B, S, D = x.shape
+    B, S, D3 = qkv.shape
+    D = D3 // 3
     h = num_heads
     d = D // h
-    qkv = F.linear(x, sd[prefix + "qkv.weight"], sd[prefix + "qkv.bias"])       # :103
     q, k, v = qkv.chunk(3, dim=-1)
 
     def heads(t):                                                               # :104 'b n (h d) -> (b h) n d'
@@ -107,8 +108,26 @@ def var_attention(x, sd, prefix, num_heads, mode, n, f):
     else:
         out = out.reshape(B * h, n, f, d).permute(0, 2, 1, 3).reshape(B * h, f * n, d)
     out = torch.cat((cls_out, out), dim=1)                                      # :130
-    out = out.reshape(B, h, S, d).permute(0, 2, 1, 3).reshape(B, S, D)          # :133
+    return out.reshape(B, h, S, d).permute(0, 2, 1, 3).reshape(B, S, D)         # :133
+
+
+def var_attention(x, sd, prefix, num_heads, mode, n, f):
+    """VarAttention.forward, model/video_transformer.py:100-137: qkv Linear -> attention core -> proj."""
+    qkv = F.linear(x, sd[prefix + "qkv.weight"], sd[prefix + "qkv.bias"])       # :103
+    out = var_attention_core(qkv, num_heads, mode, n, f)
     return F.linear(out, sd[prefix + "proj.weight"], sd[prefix + "proj.bias"])  # :135
+
+
+def text_attention_core(q, k, v, attention_mask, n_heads):
+    """DistilBERT eager attention (modeling_distilbert.py:122-147) on projected q,k,v [B, L, D]."""
+    B, L, D = q.shape
+    d = D // n_heads
+    sh = lambda t: t.view(B, L, n_heads, d).transpose(1, 2)
+    neg = torch.finfo(q.dtype).min
+    add_mask = torch.zeros(B, 1, 1, L, dtype=q.dtype).masked_fill(attention_mask[:, None, None, :] == 0, neg)
+    w = torch.matmul(sh(q), sh(k).transpose(2, 3)) * (d ** -0.5) + add_mask
+    w = F.softmax(w, dim=-1)
+    return torch.matmul(w, sh(v)).transpose(1, 2).reshape(B, L, D)
 
 
 def space_time_block(x, sd, p, cfg: VideoCfg, n, f, taps=None):

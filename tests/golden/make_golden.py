@@ -12,7 +12,7 @@ Fixtures
                 text/video embeds, CLS features, sim_matrix, NormSoftmaxLoss, EgoNCE (reference
                 class with `.cuda()` neutralised), block-0 taps (sub-sampled rows),
                 gradient slices of sentinel weights and of the embeddings.
-  tiny_video.npz  reference SpaceTimeTransformer(img 32, patch 16, dim 64, depth 2, heads 2,
+  tiny_video.npz  reference SpaceTimeTransformer(img 32, patch 16, dim 128, depth 2, heads 2 (head_dim 64),
                 num_frames 4) on [3,3,3,32,32] input (curr_frames 3 < num_frames 4): all tensors.
   gather_w2.npz reference AllGather_multi under gloo, world_size 2: loss + local embedding grads.
 """
@@ -107,7 +107,7 @@ def make_full(mm, ml):
 
 def make_tiny(mv):
     torch.manual_seed(0)
-    net = mv.SpaceTimeTransformer(img_size=32, patch_size=16, embed_dim=64, depth=2, num_heads=2,
+    net = mv.SpaceTimeTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2,
                                   num_frames=4, time_init="rand", num_classes=0)
     schema = {("video_model." + k): v.shape for k, v in net.state_dict().items()}
     sd = synth_state_dict(schema, seed=7)

@@ -71,7 +71,7 @@ def test_full_losses_and_grads_match_reference(full):
 def test_tiny_video_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, "tiny_video.npz"))
     sd = {k[2:]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("w:")}
-    cfg = O.VideoCfg(img_size=32, patch_size=16, embed_dim=64, depth=2, num_heads=2, num_frames=4)
+    cfg = O.VideoCfg(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_frames=4)
     taps = {}
     feats = O.video_encoder(torch.from_numpy(g["video"]), sd, cfg, taps=taps)
     assert rel(feats, g["feats"]) < 1e-5
