@@ -71,7 +71,7 @@ class _TextLayerFn(torch.autograd.Function):
         P = Precision.fwd_passes
         dev = x.device
         x2 = x.contiguous().view(M, D)
-        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, q_w, f1_w))
+        train = any(ctx.needs_input_grad)
 
         def W(p):
             return wc.get(p, need_t=False)[0]

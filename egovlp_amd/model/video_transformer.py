@@ -59,7 +59,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         P = Precision.fwd_passes
         dev = x.device
         x2 = x.contiguous().view(M, D)
-        train = torch.is_grad_enabled() and any(t.requires_grad for t in (x, n3w, tqkv_w, fc1_w))
+        train = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward; this is the reliable signal
 
         def W(p):
             return wc.get(p, need_t=False)[0]

@@ -177,9 +177,11 @@ def test_divided_attention_fwd_bwd(ops, passes, mode, B, T, n, H):
     qkv = torch.randn(B * S, 3 * H * 64, generator=g)
     out, lse = ops.divided_attn_fwd(qkv.cuda(), B, T, n, H, mode, passes)
     qd, ref = _ref_divided(qkv, B, T, n, H, mode)
-    tol = TOL[passes] if (mode == 0) else 2e-5          # time attention and the CLS row are exact-fp32 VALU kernels
+    # time attention and the CLS row are exact-fp32 VALU kernels, but with passes == 1 the OUTPUT is a single
+    # bf16 plane (2^-9 rounding), so only the bf16x3 mode can be held to the tight bound
+    tol = TOL[passes] if (mode == 0 or passes == 1) else 2e-5
     assert rel(out.float().view(B, S, -1)[:, 1:], ref[:, 1:]) < tol
-    assert rel(out.float().view(B, S, -1)[:, 0], ref[:, 0]) < 2e-5
+    assert rel(out.float().view(B, S, -1)[:, 0], ref[:, 0]) < (2e-5 if passes == 3 else TOL[1])
     d_out = torch.randn(B * S, H * 64, generator=g)
     ref.backward(d_out.view(B, S, -1).double())
     dqkv = ops.divided_attn_bwd(qkv.cuda(), d_out.cuda(), lse, B, T, n, H, mode, passes)
