@@ -96,7 +96,7 @@ extern "C" int egv_adamw_multi(int32_t count, float* const* p, const float* cons
     if (nt == 0) return EGV_OK;
     t.blk_start[nt] = nb;
     t.count = nt;
-    hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, s, t, lr, beta1, beta2, eps, weight_decay, step_size,
+    EGV_LAUNCH(adamw_kernel, dim3(nb), dim3(256), 0, s, t, lr, beta1, beta2, eps, weight_decay, step_size,
                        grad_scale);
     EGV_CHECK_LAUNCH();
     nt = 0;

@@ -254,17 +254,17 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
     auto k2 = attn_bwd_dkv_kernel<MODE, NF, 3>;
     (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
+    EGV_LAUNCH(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
     EGV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+    EGV_LAUNCH(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
   } else {
     auto k1 = attn_bwd_dq_kernel<MODE, NF, 1>;
     auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
     (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
+    EGV_LAUNCH(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
     EGV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+    EGV_LAUNCH(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;

@@ -134,11 +134,11 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
   if (passes == 3) {
     auto kern = attn_fwd_kernel<MODE, NKF, 3>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(ngroups), dim3(256), lds, s, g, oh, ol, ostride, lse);
+    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, ol, ostride, lse);
   } else {
     auto kern = attn_fwd_kernel<MODE, NKF, 1>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(ngroups), dim3(256), lds, s, g, oh, nullptr, ostride, lse);
+    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, nullptr, ostride, lse);
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;

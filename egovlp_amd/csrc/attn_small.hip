@@ -304,11 +304,11 @@ int egv_attn_time_fwd_impl(const float* qkv, int B, int T, int n, int H, bf16_t*
   const long ngroups = (long)B * n * H;
   const dim3 grid((unsigned)((ngroups + 3) / 4)), block(256);
   if (T <= 4)
-    hipLaunchKernelGGL(attn_time_fwd_kernel<4>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
+    EGV_LAUNCH(attn_time_fwd_kernel<4>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
   else if (T <= 8)
-    hipLaunchKernelGGL(attn_time_fwd_kernel<8>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
+    EGV_LAUNCH(attn_time_fwd_kernel<8>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
   else if (T <= 16)
-    hipLaunchKernelGGL(attn_time_fwd_kernel<16>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
+    EGV_LAUNCH(attn_time_fwd_kernel<16>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
   else
     return EGV_ERR_ARG;
   EGV_CHECK_LAUNCH();
@@ -319,11 +319,11 @@ int egv_attn_time_bwd_impl(const float* qkv, const float* d_out, const float* ls
                            float* dqkv, hipStream_t s) {
   const dim3 grid((unsigned)(B * H * ((n + 15) / 16))), block(256);
   if (T <= 4)
-    hipLaunchKernelGGL(attn_time_bwd_kernel<4>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
+    EGV_LAUNCH(attn_time_bwd_kernel<4>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
   else if (T <= 8)
-    hipLaunchKernelGGL(attn_time_bwd_kernel<8>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
+    EGV_LAUNCH(attn_time_bwd_kernel<8>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
   else if (T <= 16)
-    hipLaunchKernelGGL(attn_time_bwd_kernel<16>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
+    EGV_LAUNCH(attn_time_bwd_kernel<16>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
   else
     return EGV_ERR_ARG;
   EGV_CHECK_LAUNCH();
@@ -332,7 +332,7 @@ int egv_attn_time_bwd_impl(const float* qkv, const float* d_out, const float* ls
 
 int egv_attn_cls_fwd_impl(const float* qkv, int B, int S, int H, bf16_t* oh, bf16_t* ol, float* lse, hipStream_t s) {
   const size_t lds = (size_t)(((S + 3) & ~3) + 16 * 64) * sizeof(float);
-  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(256), lds, s, qkv, B, S, H, oh, ol, lse);
+  EGV_LAUNCH(attn_cls_fwd_kernel, dim3(B * H), dim3(256), lds, s, qkv, B, S, H, oh, ol, lse);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
@@ -340,7 +340,7 @@ int egv_attn_cls_fwd_impl(const float* qkv, int B, int S, int H, bf16_t* oh, bf1
 int egv_attn_cls_bwd_impl(const float* qkv, const float* d_out, const float* lse, int B, int S, int H, float* dqkv,
                           hipStream_t s) {
   const size_t lds = (size_t)(2 * ((S + 3) & ~3) + 16 * 64) * sizeof(float);
-  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(256), lds, s, qkv, d_out, lse, B, S, H, dqkv);
+  EGV_LAUNCH(attn_cls_bwd_kernel, dim3(B * H), dim3(256), lds, s, qkv, d_out, lse, B, S, H, dqkv);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

@@ -16,6 +16,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 #define EGV_ERR_ARG 1
 #define EGV_ERR_LAUNCH 2
 
+// hipGetLastError() is sticky per thread: an unrelated earlier runtime call of the host application (e.g. a failed
+// capability probe inside PyTorch) must not be reported as OUR launch failing, so clear it right before launching.
+#define EGV_LAUNCH(...)          \
+  do {                           \
+    (void)hipGetLastError();     \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define EGV_CHECK_LAUNCH()                                   \
   do {                                                       \
     hipError_t e__ = hipGetLastError();                      \

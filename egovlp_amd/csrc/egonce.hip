@@ -317,23 +317,23 @@ extern "C" int egv_egonce_fwd_bwd(const float* text, const float* video, const f
   float* rstat = stats + 4 * n;    // 3n
   float* cstat = rstat + 3 * n;    // 3n
   const float inv_tau = 1.0f / temperature;
-  hipLaunchKernelGGL(egonce_norm_kernel, dim3(n), dim3(256), 0, s, text, video, noun, verb, n, D, dn, dv, eps, tn, vn,
+  EGV_LAUNCH(egonce_norm_kernel, dim3(n), dim3(256), 0, s, text, video, noun, verb, n, D, dn, dv, eps, tn, vn,
                      stats);
   EGV_CHECK_LAUNCH();
   const size_t lds = (size_t)(D + (noun ? dn + dv : 0)) * sizeof(float);
-  hipLaunchKernelGGL(egonce_rows_kernel, dim3(n), dim3(256), lds, s, tn, vn, noun, verb, stats, n, D, dn, dv, inv_tau,
+  EGV_LAUNCH(egonce_rows_kernel, dim3(n), dim3(256), lds, s, tn, vn, noun, verb, stats, n, D, dn, dv, inv_tau,
                      use_noun, use_verb, x, mask, rstat);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(egonce_rowstat_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, rstat);
+  EGV_LAUNCH(egonce_rowstat_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, rstat);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(egonce_cols_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, cstat);
+  EGV_LAUNCH(egonce_cols_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, cstat);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(egonce_loss_kernel, dim3(1), dim3(256), 0, s, rstat, cstat, n, loss);
+  EGV_LAUNCH(egonce_loss_kernel, dim3(1), dim3(256), 0, s, rstat, cstat, n, loss);
   EGV_CHECK_LAUNCH();
   if (d_text || d_video) {
-    hipLaunchKernelGGL(egonce_grad_kernel, dim3(n), dim3(256), 0, s, x, mask, rstat, cstat, n, inv_tau, G);
+    EGV_LAUNCH(egonce_grad_kernel, dim3(n), dim3(256), 0, s, x, mask, rstat, cstat, n, inv_tau, G);
     EGV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(egonce_embgrad_kernel, dim3(n), dim3(256), 0, s, G, tn, vn, stats, n, D, eps, d_text, d_video);
+    EGV_LAUNCH(egonce_embgrad_kernel, dim3(n), dim3(256), 0, s, G, tn, vn, stats, n, D, eps, d_text, d_video);
     EGV_CHECK_LAUNCH();
   }
   return EGV_OK;
@@ -344,11 +344,11 @@ extern "C" int egv_sim_matrix_fwd(const float* a, const float* b, int32_t n, int
                                   float* an, float* bn, float* norms /* [n+m] */, float* out, void* stream) {
   if (!a || !b || !an || !bn || !norms || !out || n <= 0 || m <= 0 || D <= 0 || D > 8192) return EGV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rownorm_kernel, dim3(n), dim3(256), 0, s, a, D, eps, an, norms);
+  EGV_LAUNCH(rownorm_kernel, dim3(n), dim3(256), 0, s, a, D, eps, an, norms);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rownorm_kernel, dim3(m), dim3(256), 0, s, b, D, eps, bn, norms + n);
+  EGV_LAUNCH(rownorm_kernel, dim3(m), dim3(256), 0, s, b, D, eps, bn, norms + n);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dot_nt_kernel, dim3(n), dim3(256), (size_t)D * sizeof(float), s, an, bn, m, D, out);
+  EGV_LAUNCH(dot_nt_kernel, dim3(n), dim3(256), (size_t)D * sizeof(float), s, an, bn, m, D, out);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
@@ -358,11 +358,11 @@ extern "C" int egv_sim_matrix_bwd(const float* g, const float* an, const float* 
   if (!g || !an || !bn || !norms || n <= 0 || m <= 0 || D <= 0) return EGV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (da) {
-    hipLaunchKernelGGL(sim_bwd_kernel, dim3(n), dim3(256), 0, s, g, 0, n, m, an, bn, norms, D, eps, da);
+    EGV_LAUNCH(sim_bwd_kernel, dim3(n), dim3(256), 0, s, g, 0, n, m, an, bn, norms, D, eps, da);
     EGV_CHECK_LAUNCH();
   }
   if (db) {
-    hipLaunchKernelGGL(sim_bwd_kernel, dim3(m), dim3(256), 0, s, g, 1, m, n, bn, an, norms + n, D, eps, db);
+    EGV_LAUNCH(sim_bwd_kernel, dim3(m), dim3(256), 0, s, g, 1, m, n, bn, an, norms + n, D, eps, db);
     EGV_CHECK_LAUNCH();
   }
   return EGV_OK;
@@ -378,17 +378,17 @@ extern "C" int egv_egonce_from_sim(const float* x, const float* sim_v, const flo
   float* cstat = rstat + 3 * n;
   const float inv_tau = 1.0f / temperature;
   const long nn = (long)n * n;
-  hipLaunchKernelGGL(egonce_mask_from_sim_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, sim_v, sim_n, n,
+  EGV_LAUNCH(egonce_mask_from_sim_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, sim_v, sim_n, n,
                      use_noun, use_verb, mask);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(egonce_rowstat_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, rstat);
+  EGV_LAUNCH(egonce_rowstat_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, rstat);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(egonce_cols_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, cstat);
+  EGV_LAUNCH(egonce_cols_kernel, dim3(n), dim3(256), 0, s, x, mask, n, inv_tau, cstat);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(egonce_loss_kernel, dim3(1), dim3(256), 0, s, rstat, cstat, n, loss);
+  EGV_LAUNCH(egonce_loss_kernel, dim3(1), dim3(256), 0, s, rstat, cstat, n, loss);
   EGV_CHECK_LAUNCH();
   if (dx) {
-    hipLaunchKernelGGL(egonce_grad_kernel, dim3(n), dim3(256), 0, s, x, mask, rstat, cstat, n, inv_tau, dx);
+    EGV_LAUNCH(egonce_grad_kernel, dim3(n), dim3(256), 0, s, x, mask, rstat, cstat, n, inv_tau, dx);
     EGV_CHECK_LAUNCH();
   }
   return EGV_OK;

@@ -247,7 +247,7 @@ extern "C" int egv_split_f32(const float* x, int64_t ldx, int32_t rows, int32_t 
   }
   const int row_extent = t_hi ? (int)ldt : rows;  // cover the zero pad of the transposed planes
   dim3 grid((cols + 63) / 64, (row_extent + 63) / 64);
-  hipLaunchKernelGGL(split_transpose_kernel<false>, grid, dim3(256), 0, s, x, nullptr, nullptr, ldx, rows, cols, hi, lo,
+  EGV_LAUNCH(split_transpose_kernel<false>, grid, dim3(256), 0, s, x, nullptr, nullptr, ldx, rows, cols, hi, lo,
                      ldo, t_hi, t_lo, ldt, colsum);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -263,7 +263,7 @@ extern "C" int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int6
   }
   const int row_extent = t_hi ? (int)ldt : rows;
   dim3 grid((cols + 63) / 64, (row_extent + 63) / 64);
-  hipLaunchKernelGGL(split_transpose_kernel<true>, grid, dim3(256), 0, s, nullptr, hi, lo, ldx, rows, cols, nullptr,
+  EGV_LAUNCH(split_transpose_kernel<true>, grid, dim3(256), 0, s, nullptr, hi, lo, ldx, rows, cols, nullptr,
                      nullptr, 0, t_hi, t_lo, ldt, colsum);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -273,7 +273,7 @@ extern "C" int egv_relu_split(const float* x, int64_t ldx, int32_t rows, int32_t
                               int64_t ldo, void* stream) {
   if (!x || !hi || cols % 4 != 0) return EGV_ERR_ARG;
   const long total = (long)rows * (cols / 4);
-  hipLaunchKernelGGL(relu_split_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
+  EGV_LAUNCH(relu_split_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, rows,
                      cols, hi, lo, ldo);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -283,7 +283,7 @@ extern "C" int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32
                                 egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream) {
   if (!video || !a_hi || P % 4 != 0 || W % P != 0 || H % P != 0) return EGV_ERR_ARG;
   const long total = (long)BT * C * H * (W / 4);
-  hipLaunchKernelGGL(patch_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C,
+  EGV_LAUNCH(patch_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C,
                      H, W, P, a_hi, a_lo, lda);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -293,7 +293,7 @@ extern "C" int egv_assemble_tokens(const float* pe, const float* cls, const floa
                                    int32_t B, int32_t T, int32_t n, int32_t D, float* x, void* stream) {
   if (!pe || !cls || !pos || !temporal || !x || D % 4 != 0) return EGV_ERR_ARG;
   const long total = (long)B * (1 + (long)T * n) * (D / 4);
-  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pe, cls,
+  EGV_LAUNCH(assemble_tokens_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pe, cls,
                      pos, temporal, B, T, n, D, x);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -304,17 +304,17 @@ extern "C" int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, in
   if (!dx || D % 4 != 0 || T > T_model) return EGV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (d_pos && d_cls) {
-    hipLaunchKernelGGL(assemble_bwd_pos_kernel, dim3(n + 1), dim3(256), 0, s, dx, B, T, n, D, d_pos, d_cls);
+    EGV_LAUNCH(assemble_bwd_pos_kernel, dim3(n + 1), dim3(256), 0, s, dx, B, T, n, D, d_pos, d_cls);
     EGV_CHECK_LAUNCH();
   }
   if (d_temporal) {
-    hipLaunchKernelGGL(assemble_bwd_temporal_kernel, dim3(T_model, (D + 63) / 64), dim3(256), 0, s, dx, B, T, n, D,
+    EGV_LAUNCH(assemble_bwd_temporal_kernel, dim3(T_model, (D + 63) / 64), dim3(256), 0, s, dx, B, T, n, D,
                        T_model, d_temporal);
     EGV_CHECK_LAUNCH();
   }
   if (d_pe) {
     const long total = (long)B * T * n * (D / 4);
-    hipLaunchKernelGGL(assemble_bwd_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dx, B, T, n, D, d_pe);
+    EGV_LAUNCH(assemble_bwd_pe_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dx, B, T, n, D, d_pe);
     EGV_CHECK_LAUNCH();
   }
   return EGV_OK;
@@ -324,7 +324,7 @@ extern "C" int egv_embed_fwd(const int64_t* ids, const float* word, const float*
                              float* e, void* stream) {
   if (!ids || !word || !pos || !e || D % 4 != 0) return EGV_ERR_ARG;
   const long total = (long)B * L * (D / 4);
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, word, pos, B,
+  EGV_LAUNCH(embed_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, word, pos, B,
                      L, D, e);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -334,7 +334,7 @@ extern "C" int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, in
                              float* d_word, float* d_pos, void* stream) {
   if (!ids || !d_e || !d_word || !d_pos) return EGV_ERR_ARG;
   const long total = (long)B * L * D;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, d_e, B, L, D,
+  EGV_LAUNCH(embed_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, d_e, B, L, D,
                      (long)pad_id, d_word, d_pos);
   EGV_CHECK_LAUNCH();
   return EGV_OK;

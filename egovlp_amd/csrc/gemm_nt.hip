@@ -218,16 +218,16 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   dim3 grid(tiles, ks), block(256);
   hipStream_t s = (hipStream_t)stream;
   if (p.passes == 3) {
-    hipLaunchKernelGGL(gemm_nt_kernel<3>, grid, block, 2 * 4 * PLANE_BYTES, s, p);
+    EGV_LAUNCH(gemm_nt_kernel<3>, grid, block, 2 * 4 * PLANE_BYTES, s, p);
   } else {
-    hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 2 * 2 * PLANE_BYTES, s, p);
+    EGV_LAUNCH(gemm_nt_kernel<1>, grid, block, 2 * 2 * PLANE_BYTES, s, p);
   }
   EGV_CHECK_LAUNCH();
   if (ks > 1) {
     if (!p.out_f32 || p.ldo != p.N) return EGV_ERR_ARG;
     const long mn = (long)p.M * p.N;
     const int blocks = (int)((mn / 4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.out_f32, mn, ks,
+    EGV_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.out_f32, mn, ks,
                        p.accumulate);
     EGV_CHECK_LAUNCH();
   }

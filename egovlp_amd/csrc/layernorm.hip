@@ -167,7 +167,7 @@ extern "C" int egv_layernorm_fwd(const float* x, const float* x_add, int64_t ldx
                                  void* stream) {
   if (!x || !gamma || !beta || rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
   if (!y_hi && !y_f32) return EGV_ERR_ARG;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_add, ldx,
+  EGV_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, x_add, ldx,
                      gamma, beta, eps, rows, cols, sum_out, y_hi, y_lo, y_f32, ldy, mean, rstd);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -186,10 +186,10 @@ extern "C" int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
   const int parts = egv_layernorm_bwd_parts(rows);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, lddy, x, ldx, gamma, mean, rstd, rows,
+  EGV_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, lddy, x, ldx, gamma, mean, rstd, rows,
                      cols, add1, add2, dx, lddx, work);
   EGV_CHECK_LAUNCH();
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, work, parts, cols, dgamma,
+  EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, work, parts, cols, dgamma,
                      dbeta);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
