@@ -7,6 +7,12 @@ would void the parity claims.
 import ctypes as C
 import os
 
+# ORDER MATTERS: PyTorch-ROCm ships its own libamdhip64 (HIP 7.0) while libegovlp_hip.so was linked against
+# /opt/rocm's (7.2).  Both have SONAME libamdhip64.so.7, so whichever is loaded first serves the whole process.
+# The streams / device pointers we are handed belong to torch's runtime, so torch must be loaded first -- otherwise
+# two HIP runtimes coexist and every launch fails with hipErrorNoDevice (100).
+import torch  # noqa: F401  (must precede ctypes.CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EGOVLP_HIP_LIB", os.path.join(_HERE, "libegovlp_hip.so"))  # override: diagnostics only
 
