@@ -24,6 +24,8 @@
 // float4 and the stores are 16 B (fp32) or 8 B (bf16 planes) per lane.
 // Block ids are remapped XCD-aware (common.h) so the ~6-24 blocks that share an A row-panel, and
 // the weight panel they all stream, sit in one XCD's L2.
+#include <cstdlib>
+
 #include "common.h"
 #include "egovlp_hip.h"
 
@@ -205,6 +207,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
+int egv_gemm_nt_v2_launch(const egv_gemm_desc& p, hipStream_t s);  // gemm_nt_v2.hip
+
+// kernel choice: v2 (256x128 tile, 3-slot ring, counted waits) for the big token-major GEMMs, v1 (128x128, 2-slot)
+// when M is too small to fill 256-row tiles.  EGV_GEMM_KERNEL=1|2 forces one variant (A/B benchmarking only).
+static int gemm_variant(const egv_gemm_desc& p) {
+  static const int forced = [] {
+    const char* e = getenv("EGV_GEMM_KERNEL");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1 || forced == 2) return forced;
+  return (p.M >= 1024) ? 2 : 1;
+}
+
 extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const egv_gemm_desc& p = *d;
   if (!p.a_hi || !p.b_hi) return EGV_ERR_ARG;
@@ -217,7 +232,10 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (p.passes == 3) {
+  if (gemm_variant(p) == 2) {
+    const int rc = egv_gemm_nt_v2_launch(p, s);
+    if (rc) return rc;
+  } else if (p.passes == 3) {
     EGV_LAUNCH(gemm_nt_kernel<3>, grid, block, 2 * 4 * PLANE_BYTES, s, p);
   } else {
     EGV_LAUNCH(gemm_nt_kernel<1>, grid, block, 2 * 2 * PLANE_BYTES, s, p);

@@ -145,18 +145,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
+// second stage: work[parts][2][cols] -> dgamma/dbeta.  One block per 64 columns; the 4 waves split the parts, so
+// the reduction over up to 512 parts runs on (cols/64) x 256 threads instead of a 3-block serial loop.
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ work, int parts, int cols,
                                                                    float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float a = 0.f, b = 0.f;
-  for (int p = 0; p < parts; ++p) {
-    a += work[((long)p * 2 + 0) * cols + c];
-    b += work[((long)p * 2 + 1) * cols + c];
+  if (c < cols) {
+    for (int p = wave; p < parts; p += 4) {
+      a += work[((long)p * 2 + 0) * cols + c];
+      b += work[((long)p * 2 + 1) * cols + c];
+    }
   }
-  if (dgamma) dgamma[c] = a;
-  if (dbeta) dbeta[c] = b;
+  red[0][wave][lane] = a;
+  red[1][wave][lane] = b;
+  __syncthreads();
+  if (wave == 0 && c < cols) {
+    if (dgamma) dgamma[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    if (dbeta) dbeta[c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+  }
 }
 
 }  // namespace
@@ -189,7 +199,7 @@ extern "C" int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   EGV_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, lddy, x, ldx, gamma, mean, rstd, rows,
                      cols, add1, add2, dx, lddx, work);
   EGV_CHECK_LAUNCH();
-  EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, work, parts, cols, dgamma,
+  EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, work, parts, cols, dgamma,
                      dbeta);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
