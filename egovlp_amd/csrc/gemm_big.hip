@@ -1,0 +1,334 @@
+// gemm_big: the token-major GEMM of the EgoClip step (every qkv / proj / fc1 / fc2 forward, dgrad and wgrad of
+// the 12 SpaceTimeBlocks = ~95 % of the step's FLOPs), built around what bounds an MFMA GEMM on a CDNA4 CU:
+// LDS bytes per MFMA.  rocprofv3 on the 128x128 and 256x128 kernels (gemm_nt.hip, gemm_nt_v2.hip; 580-670 TF) showed
+// the LDS array -- fragment reads plus LDS-DMA writes -- busy about as long as the matrix pipe, so this kernel
+//   * uses a (64*MF) x 256 block tile, MF = 5 (320 rows) or 4 (256 rows): 8 waves as 4 (M) x 2 (N), each wave
+//     (16*MF) x 128 = MF x 8 MFMA 16x16x32 fragments (160 / 128 fp32 accumulator registers); per 64-deep k-tile a wave
+//     issues 2*(MF+8) ds_read_b128 for 16*MF MFMAs (MF = 5: 26 reads / 80 MFMAs; 128x128: 16 / 32);
+//   * k-tile = 64 bf16 = one full 128-B line per row per DMA piece (the BK = 32 kernels fetched half lines);
+//   * two LDS stages of (64*MF + 256) x 128 B (144 KiB at MF = 5) filled by LDS-DMA (global_load_lds_dwordx4);
+//     ONE barrier per k-tile.  The DMA of tile t+2 is issued right after the barrier that retires tile t's buffer
+//     and is waited for a whole k-tile of MFMAs later;
+//   * fragments are register double-buffered in 2*8/NC "phases" per k-tile: while phase p multiplies, the
+//     ds_reads of phase p+1 (the next NC B-fragments, and the next k-step's A-fragments when it changes) are in
+//     flight -- including across the tile boundary, where they read the stage the barrier just published.
+// Tile-count quantisation decides MF: M = 25 120 tokens (B = 32, T = 4) gives 79 x 3 = 237 tiles of 320x256 for the
+// N = 768 GEMMs (one round on 256 CUs at 93 %), where 256x256 would need 297 tiles = two rounds at 58 %.
+//
+// Operand layouts ("trans" in egv_gemm_desc):
+//   NT  A[M,K], B[N,K], contraction index contiguous: forward and dgrad (weights are cached transposed for dgrad).
+//       LDS image: 128-B rows, 16-B chunk index XOR (row & 7) (conflict-free ds_read_b128, see attn_common.h);
+//       the DMA destination is lane-linear, so the permutation is applied to the per-lane SOURCE address.
+//   TN  A stored [K, M], B stored [K, N] (wgrad: dW = dY^T X with K = tokens): the k-major tiles are staged as they
+//       lie in HBM ([64 k][256] bf16, 512-B rows, 32-B units XOR (k & 7)) and the MFMA fragments are fetched with
+//       the CDNA4 transpose read ds_read_b64_tr_b16 -- no transposed copy of dY or X is ever written to HBM (the
+//       previous design spent 7 ms / step in transpose kernels).  The k-permutation of a transpose-read fragment
+//       (k = 4g+j, 16+4g+j) is the same for both operands, which is all a dot product needs.  Rows past K are
+//       fetched from a zero page.  Optionally the same pass produces colsum[m] = sum_k A[k,m] (bias gradient) with
+//       one extra MFMA per A-fragment against an all-ones fragment.
+// bf16x3 (fp32-grade) products run as three k-segments over the split planes, (A_hi,B_lo), (A_lo,B_hi), (A_hi,B_hi),
+// into the same accumulators: one code path, the small terms first.
+// The last tile row/column is shifted inwards (m0 = M - BM) instead of being predicated: the overlapping rows are
+// computed twice with bit-identical results, so the duplicate stores are benign and no lane ever needs a clamp.
+#include <cstdlib>
+
+#include "common.h"
+#include "egovlp_hip.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int KT = 64;    // contraction depth of one LDS tile
+constexpr int NFW = 8;    // 16-column fragments per wave
+constexpr int BNB = 256;  // block tile columns
+
+typedef __attribute__((ext_vector_type(4))) short s16x4v;
+typedef __attribute__((ext_vector_type(8))) short s16x8v;
+
+__device__ uint4 g_zero_page[64];  // 1 KiB of zeros: DMA source for k-rows past the end (TN)
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8_t lds_b128(const char* p) { return *(const bf16x8_t*)p; }
+
+// transpose-read fragment: rows r, r+1, r+2, r+3 (this 16-lane group's) and the same +16, 16 columns
+__device__ __forceinline__ bf16x8_t lds_tr2(const char* p) {
+  const s16x4v x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(p));
+  const s16x4v y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(p + 16 * 512));
+  const s16x8v z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+  return __builtin_bit_cast(bf16x8_t, z);
+}
+
+template <int MF, int NC, bool TN>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = MF * 64;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = BNB * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NCH = NFW / NC;               // phases per 32-deep k-step
+  constexpr int GA = TN ? 4 : MF;             // DMA pieces per wave per tile: A, B
+  constexpr int GB = 4;
+  static_assert(!TN || MF == 4, "TN tiles are 256x256");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_n = (p.N + BNB - 1) / BNB;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int tm = wg / tiles_n, tn = wg % tiles_n;
+  const int m0 = min(tm * BM, p.M - BM);      // shifted, never predicated (host guarantees M >= BM, N >= 256)
+  const int n0 = min(tn * BNB, p.N - BNB);
+
+  const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+  const int z = blockIdx.y;
+  const int nkt_total = (p.K + KT - 1) / KT;
+  const int kt_per = (nkt_total + ksplit - 1) / ksplit;
+  const int kt_begin = z * kt_per;
+  const int kt_end = min(nkt_total, kt_begin + kt_per);
+  const int nkt = max(kt_end - kt_begin, 0);
+  const int nseg = (p.passes == 3) ? 3 : 1;
+  const int nt = nkt * nseg;
+
+  // k-segments: (A_hi,B_lo), (A_lo,B_hi), (A_hi,B_hi) for passes == 3; (A_hi,B_hi) alone otherwise
+  auto seg_a = [&](int s) -> const bf16_t* { return (nseg == 3 && s == 1) ? p.a_lo : p.a_hi; };
+  auto seg_b = [&](int s) -> const bf16_t* { return (nseg == 3 && s == 0) ? p.b_lo : p.b_hi; };
+
+  // ---- DMA (global -> LDS) source offsets, in elements, relative to the tile origin of the current k-tile -----
+  long a_voff, b_voff;
+  int tn_col = 0;   // TN: this lane's source column (elements) before the per-piece unit XOR
+  if (!TN) {
+    const int chunk = (lane & 7) ^ (lane >> 3);                 // LDS position (lane&7) holds source chunk pos^(row&7)
+    a_voff = (long)(wave * MF * 8 + (lane >> 3)) * p.lda + chunk * 8;
+    b_voff = (long)(wave * 4 * 8 + (lane >> 3)) * p.ldb + chunk * 8;
+  } else {
+    // piece I = wave*4 + q covers k-rows 2I, 2I+1 of the tile; this lane: row 2I + (lane>>5), LDS chunk lane&31.
+    // source 32-B unit = (LDS unit) ^ (row & 7) = ((lane&31)>>1) ^ ((2q + (lane>>5)) & 7); the q part is XOR-ed in per piece.
+    const int r = lane >> 5;
+    const int u = ((lane & 31) >> 1) ^ r;
+    tn_col = ((u << 1) | (lane & 1)) * 8;
+    a_voff = (long)(wave * 8 + r) * p.lda;
+    b_voff = (long)(wave * 8 + r) * p.ldb;
+  }
+
+  int st_seg = 0, st_kt = kt_begin;   // the next tile to be staged
+  auto stage = [&](int buf) {
+    char* lds = smem + buf * STAGE;
+    if (!TN) {
+      const bf16_t* ab = seg_a(st_seg) + (long)m0 * p.lda + (long)st_kt * KT;
+      const bf16_t* bb = seg_b(st_seg) + (long)n0 * p.ldb + (long)st_kt * KT;
+#pragma unroll
+      for (int q = 0; q < GA; ++q) glds16(ab + a_voff + (long)q * 8 * p.lda, lds + (wave * GA + q) * 1024);
+#pragma unroll
+      for (int q = 0; q < GB; ++q) glds16(bb + b_voff + (long)q * 8 * p.ldb, lds + A_BYTES + (wave * GB + q) * 1024);
+    } else {
+      const bf16_t* ab = seg_a(st_seg) + (long)st_kt * KT * p.lda + m0;
+      const bf16_t* bb = seg_b(st_seg) + (long)st_kt * KT * p.ldb + n0;
+      const int krow = st_kt * KT + wave * 8 + (lane >> 5);     // + 2q
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = krow + 2 * q < p.K;
+        const int col = tn_col ^ (((2 * q) & 7) << 4);   // 32-B unit (16 elements) index ^= (2q) & 7
+        const bf16_t* sa = ab + a_voff + (long)(2 * q) * p.lda + col;
+        const bf16_t* sb = bb + b_voff + (long)(2 * q) * p.ldb + col;
+        const void* za = (const char*)g_zero_page + lane * 16;
+        glds16(ok ? (const void*)sa : za, lds + (wave * 4 + q) * 1024);
+        glds16(ok ? (const void*)sb : za, lds + A_BYTES + (wave * 4 + q) * 1024);
+      }
+    }
+    if (++st_kt == kt_end) {
+      st_kt = kt_begin;
+      ++st_seg;
+    }
+  };
+
+  // ---- fragment read offsets (bytes within a stage) ---------------------------------------------------------
+  int a_rd0, a_rd1, b_rd0, b_rd1;   // NT: k-step 0 / 1 bases;  TN: a_rd0 / b_rd0 only (k-step is an immediate)
+  int tn_r7 = 0;
+  if (!TN) {
+    const int c0 = ((lane >> 4) ^ (lane & 7)) * 16;             // chunk (g + 4*ks) ^ (row&7), row&7 == lane&7
+    const int rowb = (lane & 15) * 128;
+    a_rd0 = (wm * MF * 16) * 128 + rowb + c0;
+    a_rd1 = (wm * MF * 16) * 128 + rowb + (c0 ^ 64);
+    b_rd0 = A_BYTES + (wn * 128) * 128 + rowb + c0;
+    b_rd1 = A_BYTES + (wn * 128) * 128 + rowb + (c0 ^ 64);
+  } else {
+    const int g = lane >> 4, pp = lane & 15;
+    tn_r7 = 4 * (g & 1) + (pp >> 2);
+    const int rowoff = (4 * g + (pp >> 2)) * 512 + (pp & 3) * 8;
+    a_rd0 = rowoff;
+    b_rd0 = A_BYTES + rowoff;
+    a_rd1 = b_rd1 = 0;
+  }
+
+  bf16x8_t A[2][MF], Bq[2][NC];
+  auto load_a = [&](int sb, int ks, bf16x8_t (&dst)[MF]) {
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+      if (!TN) dst[f] = lds_b128(smem + sb + (ks ? a_rd1 : a_rd0) + f * 2048);
+      else dst[f] = lds_tr2(smem + sb + a_rd0 + ks * (32 * 512) + (((wm * 4 + f) ^ tn_r7) << 5));
+    }
+  };
+  auto load_b = [&](int sb, int ks, int c, bf16x8_t (&dst)[NC]) {
+#pragma unroll
+    for (int jj = 0; jj < NC; ++jj) {
+      const int j = c * NC + jj;
+      if (!TN) dst[jj] = lds_b128(smem + sb + (ks ? b_rd1 : b_rd0) + j * 2048);
+      else dst[jj] = lds_tr2(smem + sb + b_rd0 + ks * (32 * 512) + (((wn * 8 + j) ^ tn_r7) << 5));
+    }
+  };
+
+  f32x4_t acc[MF][NFW];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // bias-gradient accumulators (TN, first tile column, first wave column only)
+  const bool do_cs = TN && p.colsum != nullptr && tn == 0 && wn == 0;
+  f32x4_t cs[MF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i) cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const s16x8v ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  if (nt > 0) {
+    stage(0);
+    if (nt > 1) {
+      stage(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    load_b(0, 0, 0, Bq[0]);
+    load_a(0, 0, A[0]);
+  }
+
+  int cur_seg = 0, cur_kt = kt_begin;
+  for (int t = 0; t < nt; ++t) {
+    const int sb = (t & 1) * STAGE;
+    const bool cs_on = do_cs && (nseg == 1 || cur_seg >= 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ph = ks * NCH + c;
+        const bool last = (ph == 2 * NCH - 1);
+        // hipcc waits lgkmcnt(0) right before the first MFMA that consumes a prefetched fragment, so the prefetch of
+        // phase p+1 is issued AFTER the first MFMA of phase p (it then has the rest of the phase to land) -- issued
+        // before it, every phase would start by waiting for the reads it had just issued (seen in the .s).
+        if (c == 0 && cs_on) {
+#pragma unroll
+          for (int i = 0; i < MF; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[ks & 1][i], cs[i], 0, 0, 0);
+        }
+        acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][0], A[ks & 1][0], acc[0][c * NC], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (last) {
+          if (t + 1 < nt) {
+            // tile t+1 (this wave's DMA pieces) landed; all of this wave's reads of stage t&1 have returned
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < nt) stage(t & 1);
+            load_b(STAGE - sb, 0, 0, Bq[0]);
+            load_a(STAGE - sb, 0, A[0]);
+          }
+        } else {
+          const int ks2 = (c + 1 < NCH) ? ks : ks + 1;
+          const int c2 = (c + 1 < NCH) ? c + 1 : 0;
+          load_b(sb, ks2, c2, Bq[(ph + 1) & 1]);
+          if (c2 == 0) load_a(sb, ks2, A[ks2 & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < NC; ++jj)
+#pragma unroll
+          for (int i = 0; i < MF; ++i)
+            if (jj + i > 0)
+              acc[i][c * NC + jj] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][jj], A[ks & 1][i], acc[i][c * NC + jj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (++cur_kt == kt_end) {
+      cur_kt = kt_begin;
+      ++cur_seg;
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  const int lm = lane & 15;
+  const int ln = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < MF; ++i) {
+    const int m = m0 + wm * MF * 16 + i * 16 + lm;
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) egv_gemm_store4(p, acc[i][j], m, n0 + wn * 128 + j * 16 + ln, z, ksplit);
+    if (do_cs && ln == 0) {
+      if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
+      else p.colsum[m] = cs[i][0];
+    }
+  }
+}
+
+template <int MF, int NC, bool TN>
+int launch_big(const egv_gemm_desc& p, hipStream_t s) {
+  constexpr int BM = MF * 64;
+  constexpr int lds = 2 * (BM * 128 + BNB * 128);
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNB - 1) / BNB);
+  const int ks = p.ksplit > 1 ? p.ksplit : 1;
+  auto k = gemm_big_kernel<MF, NC, TN>;
+  static bool attr_set = false;   // idempotent; a race only repeats the call
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return EGV_ERR_LAUNCH + (int)hipGetLastError();
+    attr_set = true;
+  }
+  EGV_LAUNCH(k, dim3(tiles, ks), dim3(512), lds, s, p);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+}  // namespace
+
+// Can the big kernel run this problem?  (NT: K % 64 == 0; both: M, N at least one tile, 16-B aligned rows.)
+bool egv_gemm_big_supports(const egv_gemm_desc& p) {
+  if (p.M < 256 || p.N < BNB || p.N % 4 != 0) return false;
+  if (p.lda % 8 != 0 || p.ldb % 8 != 0) return false;
+  if (p.trans) return p.M % 8 == 0 && p.N % 8 == 0;
+  return p.K % KT == 0;
+}
+
+// rows per block tile (256 or 320) that minimise (rounds on 256 CUs) x (tile cost)
+int egv_gemm_big_pick_mf(const egv_gemm_desc& p) {
+  if (p.trans || p.M < 320) return 4;
+  const int ks = p.ksplit > 1 ? p.ksplit : 1;
+  const int tn = (p.N + BNB - 1) / BNB;
+  long best = -1;
+  int best_mf = 4;
+  for (int mf = 4; mf <= 5; ++mf) {
+    const long tiles = (long)((p.M + mf * 64 - 1) / (mf * 64)) * tn * ks;
+    const long cost = ((tiles + 255) / 256) * mf;
+    if (best < 0 || cost < best || (cost == best && mf == 5)) {
+      best = cost;
+      best_mf = mf;
+    }
+  }
+  return best_mf;
+}
+
+// variant: 0 = auto; 4 / 5 force MF; +10 selects the 4-fragment phase (NC = 4) where it exists (diagnostics)
+int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant) {
+  if (p.trans) return launch_big<4, 2, true>(p, s);
+  int mf = (variant % 10 == 4 || variant % 10 == 5) ? variant % 10 : egv_gemm_big_pick_mf(p);
+  if (p.M < mf * 64) mf = 4;
+  if (mf == 5) return launch_big<5, 2, false>(p, s);
+  return (variant >= 10) ? launch_big<4, 4, false>(p, s) : launch_big<4, 2, false>(p, s);
+}

@@ -207,17 +207,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-int egv_gemm_nt_v2_launch(const egv_gemm_desc& p, hipStream_t s);  // gemm_nt_v2.hip
+int egv_gemm_nt_v2_launch(const egv_gemm_desc& p, hipStream_t s);          // gemm_nt_v2.hip
+int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant);  // gemm_big.hip
+bool egv_gemm_big_supports(const egv_gemm_desc& p);
 
-// kernel choice: v2 (256x128 tile, 3-slot ring, counted waits) for the big token-major GEMMs, v1 (128x128, 2-slot)
-// when M is too small to fill 256-row tiles.  EGV_GEMM_KERNEL=1|2 forces one variant (A/B benchmarking only).
+// kernel choice: gemm_big (320/256 x 256 tile, k-tile 64) for the token-major GEMMs and every TN (wgrad) problem;
+// v1 (128x128, 2-stage) when M is too small to fill big tiles (DistilBERT, projections); v2 (256x128, BK = 32) only
+// where K is not a multiple of 64.  EGV_GEMM_KERNEL = 1 | 2 | 3 (big, auto MF) | 4 | 5 (big, MF forced) | 14 (big,
+// MF = 4, 4-fragment phases) forces one variant -- A/B benchmarking only.
 static int gemm_variant(const egv_gemm_desc& p) {
   static const int forced = [] {
     const char* e = getenv("EGV_GEMM_KERNEL");
     return e ? atoi(e) : 0;
   }();
+  const bool big_ok = egv_gemm_big_supports(p);
+  if (p.trans) return big_ok ? 3 : -1;
   if (forced == 1 || forced == 2) return forced;
-  return (p.M >= 1024) ? 2 : 1;
+  if (forced >= 3 && big_ok) return forced;
+  // big tiles only when there are enough of them to occupy the chip (DistilBERT's M = 1024 GEMMs make 12)
+  const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
+  if (big_ok && big_tiles >= 128) return 3;
+  return (p.M >= 4096) ? 2 : 1;
 }
 
 extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
@@ -226,13 +236,20 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   if (p.passes != 1 && p.passes != 3) return EGV_ERR_ARG;
   if (p.passes == 3 && (!p.a_lo || !p.b_lo)) return EGV_ERR_ARG;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EGV_ERR_ARG;
-  if (p.K % BK != 0 || p.N % 4 != 0 || ((p.lda % 8 != 0 || p.ldb % 8 != 0) && !getenv("EGV_BLOCKED"))) return EGV_ERR_ARG;
+  if (p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return EGV_ERR_ARG;
+  if (!p.trans && p.K % BK != 0) return EGV_ERR_ARG;
   if (p.ksplit > 1 && !p.partial) return EGV_ERR_ARG;
+  if (p.colsum && !p.trans) return EGV_ERR_ARG;
+  const int variant = gemm_variant(p);
+  if (variant < 0) return EGV_ERR_ARG;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (gemm_variant(p) == 2) {
+  if (variant >= 3) {
+    const int rc = egv_gemm_big_launch(p, s, variant);
+    if (rc) return rc;
+  } else if (variant == 2) {
     const int rc = egv_gemm_nt_v2_launch(p, s);
     if (rc) return rc;
   } else if (p.passes == 3) {
@@ -248,6 +265,12 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
     EGV_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.out_f32, mn, ks,
                        p.accumulate);
     EGV_CHECK_LAUNCH();
+    if (p.colsum) {   // the ksplit x M column-sum slab sits behind the ksplit x M x N product slab
+      if (p.M % 4 != 0) return EGV_ERR_ARG;
+      EGV_LAUNCH(splitk_reduce_kernel, dim3((p.M / 4 + 255) / 256), dim3(256), 0, s, p.partial + (long)ks * mn,
+                 p.colsum, (long)p.M, ks, 0);
+      EGV_CHECK_LAUNCH();
+    }
   }
   return EGV_OK;
 }

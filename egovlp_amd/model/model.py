@@ -64,8 +64,8 @@ class _ProjFn(torch.autograd.Function):
         x2d, w = ctx.saved_tensors
         Pb = Precision.bwd_passes
         dy = dy.contiguous()
-        dy_pl, dy_t, db = ops.split_f32(dy, Pb, want_rowmajor=True, want_transposed=True, want_colsum=True)
-        _, dW, _ = _lin_bwd(None, ctx.a, None, Pb, need_dx=False, dy_planes=dy_pl, dy_t=dy_t, db=db)
+        dy_pl = ops.split_f32(dy, Pb)[0]
+        _, dW, db = _lin_bwd(dy_pl, ctx.a, None, Pb, need_dx=False)
         dx = torch.empty((x2d.shape[0], x2d.shape[1]), dtype=torch.float32, device=dy.device)
         wt = ctx.wc.get(w, need_t=True)[1]
         if ctx.relu:

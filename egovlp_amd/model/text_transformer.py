@@ -119,16 +119,12 @@ class _TextLayerFn(torch.autograd.Function):
 
         d_s2, d_ln2w, d_ln2b = ops.layernorm_bwd(G, s2, ln2_w, mean2, rstd2)
         # FFN
-        g_pl, g_t, d_f2b = ops.split_f32(d_s2, Pb, want_rowmajor=True, want_transposed=True, want_colsum=True)
+        g_pl = ops.split_f32(d_s2, Pb)[0]
         Hd = f1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(g_pl, Wt(f2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
-        _, d_f2w, _ = _lin_bwd(None, h, None, Pb, need_dx=False, dy_planes=g_pl, dy_t=g_t, db=d_f2b)
-        dZ_t, d_f1b = ops.transpose_planes(dZ, Pb, want_colsum=True)
-        x_t, _ = ops.transpose_planes(sa_pl, Pb)
-        d_f1w = torch.empty((Hd, D), dtype=torch.float32, device=G.device)
-        Kc = ops.pad32(M)
-        ops.gemm_nt(dZ_t, x_t, passes=Pb, out_f32=d_f1w, ksplit=ops.pick_ksplit(Hd, D, Kc), K=Kc)
+        _, d_f2w, d_f2b = _lin_bwd(g_pl, h, None, Pb, need_dx=False)
+        _, d_f1w, d_f1b = _lin_bwd(dZ, sa_pl, None, Pb, need_dx=False)
         d_sa = torch.empty((M, D), dtype=torch.float32, device=G.device)     # = d_s2 + dZ . W1
         ops.gemm_nt(dZ, Wt(f1_w), passes=Pb, residual=d_s2, out_f32=d_sa, K=Hd)
         d_s1, d_ln1w, d_ln1b = ops.layernorm_bwd(d_sa, s1, ln1_w, mean1, rstd1)
@@ -136,13 +132,11 @@ class _TextLayerFn(torch.autograd.Function):
         d_ctx, d_ow, d_ob = _lin_bwd(d_s1, c_pl, Wt(o_w), Pb)
         dq, dk, dv = ops.text_attn_bwd(q, k, v, mask, d_ctx, lse, B, L, H, Pb)
         # q/k/v projections; dx = d_s1 + dq.Wq + dk.Wk + dv.Wv chained through the residual epilogue
-        xt, _ = ops.transpose_planes(x_pl, Pb)
         acc = d_s1
         grads = []
         for dy, w in ((dq, q_w), (dk, k_w), (dv, v_w)):
-            dy_pl, dy_t, db = ops.split_f32(dy, Pb, want_rowmajor=True, want_transposed=True, want_colsum=True)
-            dw = torch.empty((D, D), dtype=torch.float32, device=G.device)
-            ops.gemm_nt(dy_t, xt, passes=Pb, out_f32=dw, ksplit=ops.pick_ksplit(D, D, Kc), K=Kc)
+            dy_pl = ops.split_f32(dy, Pb)[0]
+            _, dw, db = _lin_bwd(dy_pl, x_pl, None, Pb, need_dx=False)
             nxt = torch.empty((M, D), dtype=torch.float32, device=G.device)
             ops.gemm_nt(dy_pl, Wt(w), passes=Pb, residual=acc, out_f32=nxt, K=D)
             acc = nxt

@@ -22,21 +22,23 @@ from ..ops import ACT_GELU, ACT_GELU_BWD, Planes, Precision
 from ..weights import WeightCache
 
 
-def _lin_bwd(dy_f32, x_pl: Planes, wt: Planes, Pb, need_dx=True, dy_planes=None, dy_t=None, db=None):
-    """Backward of y = x W^T + b given dy (fp32 [M,N]) or already-split dy planes.
+def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True):
+    """Backward of y = x W^T + b.  `dy` is fp32 [M,N] (split to bf16 planes here, one pass, no transpose) or
+    already-split row-major Planes.  The SAME row-major planes feed both gradients: dgrad contracts over N
+    (dy . W, weights cached transposed) and wgrad contracts over the M token rows with the TN kernel
+    (dy^T x via the CDNA4 transpose read, bias gradient from the same pass).
     -> (dx fp32 [M,K] | None, dW fp32 [N,K], db [N])."""
+    if not isinstance(dy, Planes):
+        dy = ops.split_f32(dy, Pb)[0]
     M, K = x_pl.rows, x_pl.cols
-    if dy_planes is None or dy_t is None:
-        dy_planes, dy_t, db = ops.split_f32(dy_f32, Pb, want_rowmajor=need_dx, want_transposed=True, want_colsum=True)
-    N = dy_t.rows
-    x_t, _ = ops.transpose_planes(x_pl, Pb)
-    dW = torch.empty((N, K), dtype=torch.float32, device=x_pl.hi.device)
-    Kc = ops.pad32(M)
-    ops.gemm_nt(dy_t, x_t, passes=Pb, out_f32=dW, ksplit=ops.pick_ksplit(N, K, Kc), K=Kc)
+    N = dy.cols
+    dev = x_pl.hi.device
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True)
     dx = None
     if need_dx:
-        dx = torch.empty((M, K), dtype=torch.float32, device=x_pl.hi.device)
-        ops.gemm_nt(dy_planes, wt, passes=Pb, out_f32=dx, K=N)
+        dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+        ops.gemm_nt(dy, wt, passes=Pb, out_f32=dx, K=N)
     return dx, dW, db
 
 
@@ -111,13 +113,12 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
             return wc.get(p, need_t=True)[1]
 
         # ---- MLP backward.  dZ = (G . W2) * gelu'(z) comes out of the fc2-dgrad epilogue already split.
-        G_pl, G_t, d_fc2_b = ops.split_f32(G, Pb, want_rowmajor=True, want_transposed=True, want_colsum=True)
+        G_pl = ops.split_f32(G, Pb)[0]
         Hd = fc1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
-        _, d_fc2_w, _ = _lin_bwd(None, h, None, Pb, need_dx=False, dy_planes=G_pl, dy_t=G_t, db=d_fc2_b)
-        dZ_t, d_fc1_b = ops.transpose_planes(dZ, Pb, want_colsum=True)
-        d_n2, d_fc1_w, _ = _lin_bwd(None, n2, Wt(fc1_w), Pb, dy_planes=dZ, dy_t=dZ_t, db=d_fc1_b)
+        _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False)
+        d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb)
         # d_sr = G + LN2'(d_n2)
         d_sr, d_n2w, d_n2b = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G)
         # ---- spatial attention backward

@@ -134,11 +134,50 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     if ksplit > 1:
         partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device)
     d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
+    d.trans, d.colsum = 0, None
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * K,
                           lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"))
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
+
+
+def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=None):
+    """C[M,N] = A^T . B with both operands stored k-major: A is [K, M] (a.rows = K, a.cols = M), B is [K, N].
+    This is the weight gradient dW = dY^T X with K = #tokens; neither operand is ever transposed in HBM
+    (egv_gemm_nt, trans = 1).  -> colsum[M] = sum_k A[k, :] (the bias gradient) when want_colsum."""
+    Kd, M, N = a.rows, a.cols, b.cols
+    if b.rows != Kd:
+        raise ValueError("gemm_tn: operands disagree on the contraction length")
+    dev = a.hi.device
+    if M < 256 or N < 256 or M % 8 or N % 8:
+        # below one 256x256 output tile (toy widths only; every EgoClip linear is >= 256 wide): transpose both
+        # operands explicitly and run the small-tile NT kernel
+        a_t, cs = transpose_planes(a, passes, want_colsum=want_colsum)
+        b_t, _ = transpose_planes(b, passes)
+        Kc = pad32(Kd)
+        gemm_nt(a_t, b_t, passes=passes, out_f32=out_f32, ksplit=pick_ksplit(M, N, Kc), K=Kc)
+        return cs
+    if ksplit is None:
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        nkt = (Kd + 63) // 64
+        ksplit = max(1, min(256 // max(tiles, 1), nkt // 2))
+    d = GemmDesc()
+    d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
+    d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
+    d.M, d.N, d.K, d.passes = M, N, Kd, passes
+    d.alpha, d.act = 1.0, ACT_NONE
+    d.out_f32, d.ldo = _p(out_f32), out_f32.stride(0)
+    cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
+    partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
+    d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
+    d.trans, d.colsum = 1, _p(cs)
+    if KERNEL_TIMER is not None:
+        KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * Kd,
+                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"))
+    else:
+        check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)")
+    return cs
 
 
 def pick_ksplit(M, N, K):

@@ -55,6 +55,12 @@ typedef struct egv_gemm_desc {
   egv_bf16* out_hi; egv_bf16* out_lo; int64_t ldoh;
   int32_t ksplit, accumulate;
   float* partial;
+  int32_t trans;    /* 0: A[M,K], B[N,K] (contraction index contiguous).  1 ("TN", wgrad): A is stored [K, lda] with
+                       its M rows as COLUMNS and B is stored [K, ldb] with N columns, C[m,n] = sum_k A[k,m] B[k,n] --
+                       no transposed copy of either operand is ever made (CDNA4 transpose-read from LDS).  Requires
+                       M >= 256, N >= 256, both multiples of 8; K is arbitrary (rows past K are zero-filled).        */
+  float* colsum;    /* trans == 1 only, optional: colsum[m] = sum_k A[k,m] (the bias gradient), from the same pass;
+                       with ksplit > 1, partial must hold ksplit*M*N + ksplit*M floats.                              */
 } egv_gemm_desc;
 int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
 

@@ -36,11 +36,28 @@ def test_ctypes_prototypes_match_header_symbol_set():
     assert sorted(_lib.PROTOTYPES.keys()) == declared_symbols()
 
 
-def test_gemm_desc_layout_matches_header():
+def test_gemm_desc_layout_matches_header(tmp_path):
+    """Compile the header with the host C compiler and compare sizeof / offsetof of every field of egv_gemm_desc
+    with the ctypes mirror the Python host side uses."""
+    import shutil
+    import subprocess
     from egovlp_amd._lib import GemmDesc
-    # 3x(ptr,ptr,i64) ... the struct is plain C: check total size = sum with natural alignment
-    assert ctypes.sizeof(GemmDesc) == 176
+    assert ctypes.sizeof(GemmDesc) == 192
     assert GemmDesc.M.offset == 48 and GemmDesc.bias.offset == 72 and GemmDesc.partial.offset == 168
+    assert GemmDesc.trans.offset == 176 and GemmDesc.colsum.offset == 184
+    if shutil.which("gcc") is None:
+        pytest.skip("no host C compiler")
+    fields = [f[0] for f in GemmDesc._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "egovlp_hip.h"\nint main(void){\n'
+                   'printf("%zu\\n", sizeof(egv_gemm_desc));\n'
+                   + "".join('printf("%%zu\\n", offsetof(egv_gemm_desc, %s));\n' % f for f in fields)
+                   + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(GemmDesc)
+    assert out[1:] == [getattr(GemmDesc, f).offset for f in fields]
 
 
 def test_product_raises_without_gpu_tensors():

@@ -132,6 +132,42 @@ def test_gemm_splitk_wgrad_shape(ops, passes):
     assert rel(db, dy.sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("passes", [3, 1])
+@pytest.mark.parametrize("M,N,K", [(1570, 768, 768), (1024, 256, 64), (2011, 512, 192), (1100, 320, 128), (1300, 2304, 128),
+                                   (25120, 768, 64)])
+def test_gemm_big_tiles(ops, passes, M, N, K):
+    """gemm_big.hip (320x256 / 256x256 tiles, k-tile 64): ragged last tile row / column (shifted inwards, computed
+    twice); the last shape is the EgoClip token count, where the 320-row tile (MF = 5) is selected."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g) * 0.05
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    pl = ops.empty_planes(M, N, passes, "cuda")
+    ops.gemm_nt(planes_from(ops, a, passes), planes_from(ops, b, passes), passes=passes, bias=bias.cuda(),
+                residual=res.cuda(), out_f32=out, out_planes=pl)
+    ref = a.double() @ b.double().t() + bias + res
+    assert rel(out, ref) < TOL[passes]
+    assert rel(pl.float(), ref) < TOL[passes] * 2 + 1e-5
+
+
+@pytest.mark.parametrize("passes", [3, 1])
+@pytest.mark.parametrize("Mtok,N,K,ksplit", [(6280, 768, 256, None), (1000, 256, 768, 1), (130, 512, 256, 2), (25120, 256, 256, 28)])
+def test_gemm_tn_wgrad(ops, passes, Mtok, N, K, ksplit):
+    """dW = dY^T X straight from the row-major operands (CDNA4 transpose-read), zero-filled ragged k-tail,
+    split-K + reduce, bias gradient from the same pass."""
+    g = torch.Generator().manual_seed(Mtok + N)
+    dy, x = torch.randn(Mtok, N, generator=g), torch.randn(Mtok, K, generator=g) + 0.25
+    dyp, xp = planes_from(ops, dy, passes), planes_from(ops, x, passes)
+    dw = torch.full((N, K), float("nan"), device="cuda")
+    db = ops.gemm_tn(dyp, xp, passes=passes, out_f32=dw, want_colsum=True, ksplit=ksplit)
+    assert rel(dw, dy.double().t() @ x.double()) < TOL[passes]
+    assert rel(db, dy.double().sum(0)) < (1e-5 if passes == 3 else 5e-3)
+    dw2 = torch.empty(N, K, device="cuda")
+    assert ops.gemm_tn(dyp, xp, passes=passes, out_f32=dw2, ksplit=ksplit) is None
+    assert torch.equal(dw, dw2)
+
+
 # ---------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("cols", [64, 768, 1024])
 def test_layernorm_fwd_bwd(ops, cols):
