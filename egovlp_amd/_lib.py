@@ -48,7 +48,7 @@ PROTOTYPES = {
     "egv_transpose_planes": (i32, [c_p, c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p]),
     "egv_layernorm_fwd": (i32, [c_p, c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
     "egv_layernorm_bwd_parts": (i32, [i32]),
-    "egv_layernorm_bwd": (i32, [c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p, c_p]),
+    "egv_layernorm_bwd": (i32, [c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_patch_gather": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, i64, c_p]),
     "egv_assemble_tokens": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p]),
     "egv_assemble_tokens_bwd": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),

@@ -176,22 +176,24 @@ __global__ __launch_bounds__(256) void assemble_bwd_pos_kernel(const float* __re
 }
 __global__ __launch_bounds__(256) void assemble_bwd_temporal_kernel(const float* __restrict__ dx, int B, int T, int n,
                                                                     int D, int T_model, float* __restrict__ d_temporal) {
-  // grid (T_model, ceil(D/64)); block 256 = 4 row-groups x 64 channels; LDS reduce over the 4 groups
+  // grid (T, ceil(D/64), slices); block 256 = 4 row-groups x 64 channels over this slice's (b, i) rows; LDS reduce over
+  // the 4 groups, one atomicAdd per channel per block into d_temporal (zeroed by the launcher, rows >= T stay zero).
   __shared__ float red[4][64];
   const int f = blockIdx.x;
   const int d = blockIdx.y * 64 + (threadIdx.x & 63);
   const int g = threadIdx.x >> 6;
   const long S = 1 + (long)T * n;
   float s = 0.f;
-  if (f < T && d < D) {
-    for (int bi = g; bi < B * n; bi += 4) {
+  if (d < D) {
+    for (int bi = blockIdx.z * 4 + g; bi < B * n; bi += 4 * gridDim.z) {
       const int b = bi / n, i = bi % n;
       s += dx[((long)b * S + 1 + (long)f * n + i) * D + d];
     }
   }
   red[g][threadIdx.x & 63] = s;
   __syncthreads();
-  if (g == 0 && d < D) d_temporal[(long)f * D + d] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (g == 0 && d < D)
+    atomicAdd(d_temporal + (long)f * D + d, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void assemble_bwd_pe_kernel(const float* __restrict__ dx, int B, int T, int n, int D,
                                                               float* __restrict__ d_pe) {
@@ -308,8 +310,9 @@ extern "C" int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, in
     EGV_CHECK_LAUNCH();
   }
   if (d_temporal) {
-    EGV_LAUNCH(assemble_bwd_temporal_kernel, dim3(T_model, (D + 63) / 64), dim3(256), 0, s, dx, B, T, n, D,
-                       T_model, d_temporal);
+    if (hipMemsetAsync(d_temporal, 0, sizeof(float) * (size_t)T_model * D, s) != hipSuccess) return EGV_ERR_LAUNCH;
+    EGV_LAUNCH(assemble_bwd_temporal_kernel, dim3(T, (D + 63) / 64, 32), dim3(256), 0, s, dx, B, T, n, D, T_model,
+               d_temporal);
     EGV_CHECK_LAUNCH();
   }
   if (d_pe) {

@@ -63,7 +63,7 @@ __device__ __forceinline__ bf16x8_t lds_tr2(const char* p) {
 }
 
 template <int MF, int NC, bool TN>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p) {
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int desync) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = MF * 64;
   constexpr int A_BYTES = BM * 128;
@@ -199,6 +199,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p)
   const s16x8v ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
+  // EXPERIMENT (EGV_DESYNC=n): all CUs run their tiles in lockstep, so every round ends in a chip-wide store burst
+  // during which no MFMA issues.  Delaying every other first-round block by ~half a tile staggers the CUs.
+  if (desync > 0 && desync < 100 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    for (int i = 0; i < desync * nt / 4; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   if (nt > 0) {
     stage(0);
     if (nt > 1) {
@@ -270,7 +275,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p)
   for (int i = 0; i < MF; ++i) {
     const int m = m0 + wm * MF * 16 + i * 16 + lm;
 #pragma unroll
-    for (int j = 0; j < NFW; ++j) egv_gemm_store4(p, acc[i][j], m, n0 + wn * 128 + j * 16 + ln, z, ksplit);
+    for (int j = 0; j < NFW; ++j) {
+      if (desync == 100) {   // EXPERIMENT: main loop only (accumulators kept live, nothing stored)
+        asm volatile("" ::"v"(acc[i][j]));
+        continue;
+      }
+      egv_gemm_store4(p, acc[i][j], m, n0 + wn * 128 + j * 16 + ln, z, ksplit);
+    }
     if (do_cs && ln == 0) {
       if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
       else p.colsum[m] = cs[i][0];
@@ -291,7 +302,8 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s) {
       return EGV_ERR_LAUNCH + (int)hipGetLastError();
     attr_set = true;
   }
-  EGV_LAUNCH(k, dim3(tiles, ks), dim3(512), lds, s, p);
+  static const int desync = getenv("EGV_DESYNC") ? atoi(getenv("EGV_DESYNC")) : 0;
+  EGV_LAUNCH(k, dim3(tiles, ks), dim3(512), lds, s, p, desync);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int cols, const float* __restrict__ add1,
-    const float* __restrict__ add2, float* __restrict__ dx, long lddx, float* __restrict__ work) {
+    const float* __restrict__ add2, float* __restrict__ dx, long lddx, bf16_t* __restrict__ dxh,
+    bf16_t* __restrict__ dxl, float* __restrict__ work) {
   __shared__ float red[2][4][MAXV * 256];  // [dgamma/dbeta][wave][col]  32 KiB
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -126,6 +127,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         if (add1) o += *(const f32x4_t*)(add1 + (long)row * lddx + c4 * 4);
         if (add2) o += *(const f32x4_t*)(add2 + (long)row * lddx + c4 * 4);
         *(f32x4_t*)(dx + (long)row * lddx + c4 * 4) = o;
+        if (dxh) {   // the same gradient as the next GEMM's operand (row-major split-bf16 planes, ld = cols)
+          bf16_t h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_bf16(o[e], h[e], l[e]);
+          *(u32x2_t*)(dxh + (long)row * cols + c4 * 4) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+          if (dxl) *(u32x2_t*)(dxl + (long)row * cols + c4 * 4) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+        }
       }
     }
   }
@@ -145,27 +153,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   }
 }
 
-// second stage: work[parts][2][cols] -> dgamma/dbeta.  One block per 64 columns; the 4 waves split the parts, so
-// the reduction over up to 512 parts runs on (cols/64) x 256 threads instead of a 3-block serial loop.
+// second stage: work[parts][2][cols] -> dgamma/dbeta (zeroed by the launcher).  grid (cols/64, ceil(parts/64)): a block
+// sums 64 parts (16 per wave, all loads in flight at once), one atomicAdd per column per block.
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ work, int parts, int cols,
                                                                    float* __restrict__ dgamma,
                                                                    float* __restrict__ dbeta) {
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int p0 = blockIdx.y * 64 + wave * 16;
   float a = 0.f, b = 0.f;
   if (c < cols) {
-    for (int p = wave; p < parts; p += 4) {
-      a += work[((long)p * 2 + 0) * cols + c];
-      b += work[((long)p * 2 + 1) * cols + c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = p0 + i;
+      if (p < parts) {
+        a += work[((long)p * 2 + 0) * cols + c];
+        b += work[((long)p * 2 + 1) * cols + c];
+      }
     }
   }
   red[0][wave][lane] = a;
   red[1][wave][lane] = b;
   __syncthreads();
   if (wave == 0 && c < cols) {
-    if (dgamma) dgamma[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    if (dbeta) dbeta[c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    if (dgamma) atomicAdd(dgamma + c, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+    if (dbeta) atomicAdd(dbeta + c, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
   }
 }
 
@@ -190,17 +203,19 @@ extern "C" int egv_layernorm_bwd_parts(int32_t rows) {
 
 extern "C" int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, int32_t rows, int32_t cols, const float* add1,
-                                 const float* add2, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* work,
-                                 void* stream) {
+                                 const float* add2, float* dx, int64_t lddx, egv_bf16* dx_hi, egv_bf16* dx_lo,
+                                 float* dgamma, float* dbeta, float* work, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !work) return EGV_ERR_ARG;
   if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
   const int parts = egv_layernorm_bwd_parts(rows);
   hipStream_t s = (hipStream_t)stream;
   EGV_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, lddy, x, ldx, gamma, mean, rstd, rows,
-                     cols, add1, add2, dx, lddx, work);
+                     cols, add1, add2, dx, lddx, dx_hi, dx_lo, work);
   EGV_CHECK_LAUNCH();
-  EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, work, parts, cols, dgamma,
-                     dbeta);
+  if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * cols, s) != hipSuccess) return EGV_ERR_LAUNCH;
+  if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * cols, s) != hipSuccess) return EGV_ERR_LAUNCH;
+  EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 63) / 64, (parts + 63) / 64), dim3(256), 0, s, work, parts,
+             cols, dgamma, dbeta);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

@@ -42,6 +42,20 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True):
     return dx, dW, db
 
 
+# Gradient hand-off between consecutive blocks' backward passes: the LayerNorm-backward kernel that produces a block's
+# input gradient d_x also emits it as split-bf16 planes (the format the previous block's GEMMs consume).  autograd only
+# carries the fp32 tensor, so the planes ride along keyed by its storage pointer; a miss (autograd copied or accumulated
+# the gradient) just falls back to one egv_split_f32 pass.
+_GRAD_PLANES = {}
+
+
+def _take_grad_planes(g2d, Pb):
+    ent = _GRAD_PLANES.pop(g2d.data_ptr(), None)
+    if ent is not None and ent[0] == Pb and ent[1].rows == g2d.shape[0] and ent[1].cols == g2d.shape[1]:
+        return ent[1]
+    return ops.split_f32(g2d, Pb)[0]
+
+
 class _SpaceTimeBlockFn(torch.autograd.Function):
     """SpaceTimeBlock.forward, model/video_transformer.py:163-177:
          t  = timeattn(norm3(x));  tr = x + t
@@ -113,25 +127,28 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
             return wc.get(p, need_t=True)[1]
 
         # ---- MLP backward.  dZ = (G . W2) * gelu'(z) comes out of the fc2-dgrad epilogue already split.
-        G_pl = ops.split_f32(G, Pb)[0]
+        G_pl = _take_grad_planes(G, Pb)
+        _GRAD_PLANES.clear()
         Hd = fc1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
         _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False)
         d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb)
         # d_sr = G + LN2'(d_n2)
-        d_sr, d_n2w, d_n2b = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G)
+        d_sr, d_n2w, d_n2b, d_sr_pl = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G, planes_passes=Pb)
         # ---- spatial attention backward
-        d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr, a_s, Wt(sproj_w), Pb)
+        d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb)
         d_qkv_s = ops.divided_attn_bwd(qkv_s, d_as, lse_s, B, T, n, H, 0, Pb)
         d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb)
-        d_tr, d_n1w, d_n1b = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1)
+        d_tr, d_n1w, d_n1b, d_tr_pl = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1, planes_passes=Pb)
         # ---- temporal attention backward
-        d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr, a_t, Wt(tproj_w), Pb)
+        d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb)
         d_qkv_t = ops.divided_attn_bwd(qkv_t, d_at, lse_t, B, T, n, H, 1, Pb)
         d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb)
         # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
-        d_x, d_n3w, d_n3b = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr)
+        d_x, d_n3w, d_n3b, d_x_pl = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr,
+                                                       planes_passes=Pb)
+        _GRAD_PLANES[d_x.data_ptr()] = (Pb, d_x_pl)
         S = 1 + T * n
         return (d_x.view(B, S, D), None, None,
                 d_n3w, d_n3b, d_tqkv_w, d_tqkv_b, d_tproj_w, d_tproj_b,
@@ -147,6 +164,7 @@ class _PatchTokensFn(torch.autograd.Function):
     def forward(ctx, video, geom, wc, proj_w, proj_b, cls_token, pos_embed, temporal_embed):
         B, T, n, P_, D, T_model = geom
         Pp = Precision.fwd_passes
+        _GRAD_PLANES.clear()
         a = ops.patch_gather(video.contiguous(), P_, Pp)
         pe = torch.empty((a.rows, D), dtype=torch.float32, device=video.device)
         ops.gemm_nt(a, wc.get(proj_w, need_t=False)[0], passes=Pp, bias=proj_b, out_f32=pe)
@@ -159,6 +177,7 @@ class _PatchTokensFn(torch.autograd.Function):
     def backward(ctx, dx):
         B, T, n, P_, D, T_model = ctx.geom
         Pb = Precision.bwd_passes
+        _GRAD_PLANES.clear()      # block 0's input-gradient planes have no consumer
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
         _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False)
         return None, None, None, d_w.view(ctx.wshape), d_b, d_cls, d_pos, d_tmp

@@ -243,8 +243,9 @@ def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, 
     return pl, yf, mean, rstd, s
 
 
-def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=None, ldx=None, dx=None, lddx=None):
-    """-> (dx [rows, cols] (= add1 + add2 + LN-backward), dgamma, dbeta)."""
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=None, ldx=None, dx=None, lddx=None,
+                  planes_passes=0):
+    """-> (dx [rows, cols] (= add1 + add2 + LN-backward), dgamma, dbeta[, Planes of dx when planes_passes in (1, 3)])."""
     cols = dy2d.shape[-1]
     rows = dy2d.shape[0] if rows is None else rows
     ldx = x2d.stride(0) if ldx is None else ldx
@@ -256,9 +257,13 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
     db = torch.empty(cols, dtype=torch.float32, device=dev)
     parts = _lib.lib().egv_layernorm_bwd_parts(rows)
     work = torch.empty(2 * cols * parts, dtype=torch.float32, device=dev)
+    pl = empty_planes(rows, cols, planes_passes, dev) if planes_passes else None
     check(_lib.lib().egv_layernorm_bwd(_p(dy2d), dy2d.stride(0), _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
-                                       cols, _p(add1), _p(add2), _p(dx), lddx, _p(dg), _p(db), _p(work), _stream()),
+                                       cols, _p(add1), _p(add2), _p(dx), lddx, _p(pl.hi) if pl else None,
+                                       _p(pl.lo) if pl else None, _p(dg), _p(db), _p(work), _stream()),
           "egv_layernorm_bwd")
+    if planes_passes:
+        return dx, dg, db, pl
     return dx, dg, db
 
 

@@ -85,12 +85,13 @@ int egv_layernorm_fwd(const float* x, const float* x_add, int64_t ldx, const flo
                       egv_bf16* y_hi, egv_bf16* y_lo, float* y_f32, int64_t ldy,
                       float* mean, float* rstd, void* stream);
 /* dx[r,:] = (add1 + add2)[r,:] + LN'(dy; x, gamma, mean, rstd)[r,:];  dgamma/dbeta [cols] overwritten.
- * `work` must hold 2 * cols * egv_layernorm_bwd_parts(rows) floats.                                */
+ * dx_hi/dx_lo (optional, contiguous [rows, cols]): the same dx as split-bf16 planes, i.e. already in the operand
+ * format of the dgrad / wgrad GEMMs that consume it.  `work`: 2 * cols * egv_layernorm_bwd_parts(rows) floats.     */
 int egv_layernorm_bwd_parts(int32_t rows);
 int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, int32_t rows, int32_t cols,
                       const float* add1, const float* add2, float* dx, int64_t lddx,
-                      float* dgamma, float* dbeta, float* work, void* stream);
+                      egv_bf16* dx_hi, egv_bf16* dx_lo, float* dgamma, float* dbeta, float* work, void* stream);
 
 /* ---- video tokens -------------------------------------------------------------------------------
  * Patch gather for the 16x16/s16 conv (model/video_transformer.py:70-77): video [B*T,C,H,W] fp32 ->

@@ -182,8 +182,9 @@ def test_layernorm_fwd_bwd(ops, cols):
     assert rel(yf, ref) < 2e-6 and rel(pl.float(), ref) < 1e-5
     dy, add = torch.randn(rows, cols, generator=g), torch.randn(rows, cols, generator=g)
     ref.backward(dy.double())
-    dx, dg, db = ops.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), mean, rstd, add1=add.cuda())
+    dx, dg, db, dxp = ops.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), mean, rstd, add1=add.cuda(), planes_passes=3)
     assert rel(dx, xd.grad + add) < 1e-5
+    assert rel(dxp.float(), xd.grad + add) < 1e-5 and torch.equal(dxp.hi.float(), dx.to(torch.bfloat16).float())
     assert rel(dg, wd.grad) < 1e-5 and rel(db, bd.grad) < 1e-5
 
 

@@ -22,7 +22,11 @@ for passes in passes_list:
             b = ops.split_f32(torch.rand(n, k, device="cuda") * 2 - 1, passes)[0]
             out = torch.empty(m, n, device="cuda")
             bias = torch.zeros(n, device="cuda")
-            run = lambda: ops.gemm_nt(a, b, passes=passes, out_f32=out, bias=bias)
+            if os.environ.get("BENCH_OUT") == "bf16":
+                outp = ops.empty_planes(m, n, 1, "cuda")
+                run = lambda: ops.gemm_nt(a, b, passes=passes, out_planes=outp, bias=bias)
+            else:
+                run = lambda: ops.gemm_nt(a, b, passes=passes, out_f32=out, bias=bias)
         else:
             a = ops.split_f32(torch.rand(k, m, device="cuda") * 2 - 1, passes)[0]
             b = ops.split_f32(torch.rand(k, n, device="cuda") * 2 - 1, passes)[0]
