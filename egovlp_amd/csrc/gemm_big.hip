@@ -1,17 +1,27 @@
 // gemm_big: the token-major GEMM of the EgoClip step (every qkv / proj / fc1 / fc2 forward, dgrad and wgrad of
-// the 12 SpaceTimeBlocks = ~95 % of the step's FLOPs), built around what bounds an MFMA GEMM on a CDNA4 CU:
-// LDS bytes per MFMA.  rocprofv3 on the 128x128 and 256x128 kernels (gemm_nt.hip, gemm_nt_v2.hip; 580-670 TF) showed
-// the LDS array -- fragment reads plus LDS-DMA writes -- busy about as long as the matrix pipe, so this kernel
-//   * uses a (64*MF) x 256 block tile, MF = 5 (320 rows) or 4 (256 rows): 8 waves as 4 (M) x 2 (N), each wave
+// the 12 SpaceTimeBlocks = ~95 % of the step's FLOPs), built around what bounds an MFMA GEMM on a CDNA4 CU.
+//
+// (1) LDS bytes per MFMA.  rocprofv3 on the 128x128 and 256x128 kernels (gemm_nt.hip, gemm_nt_v2.hip; 580-670 TF)
+//     showed the LDS array -- fragment reads plus LDS-DMA writes -- busy about as long as the matrix pipe, so:
+//   * (64*MF) x 256 block tile, MF = 5 (320 rows) or 4 (256 rows): 8 waves as 4 (M) x 2 (N), each wave
 //     (16*MF) x 128 = MF x 8 MFMA 16x16x32 fragments (160 / 128 fp32 accumulator registers); per 64-deep k-tile a wave
 //     issues 2*(MF+8) ds_read_b128 for 16*MF MFMAs (MF = 5: 26 reads / 80 MFMAs; 128x128: 16 / 32);
 //   * k-tile = 64 bf16 = one full 128-B line per row per DMA piece (the BK = 32 kernels fetched half lines);
 //   * two LDS stages of (64*MF + 256) x 128 B (144 KiB at MF = 5) filled by LDS-DMA (global_load_lds_dwordx4);
-//     ONE barrier per k-tile.  The DMA of tile t+2 is issued right after the barrier that retires tile t's buffer
-//     and is waited for a whole k-tile of MFMAs later;
-//   * fragments are register double-buffered in 2*8/NC "phases" per k-tile: while phase p multiplies, the
-//     ds_reads of phase p+1 (the next NC B-fragments, and the next k-step's A-fragments when it changes) are in
-//     flight -- including across the tile boundary, where they read the stage the barrier just published.
+//     ONE barrier per k-tile; the DMA of tile t+2 is issued right after the barrier that retires tile t's buffer;
+//   * fragments are register double-buffered in 8 "phases" per k-tile: while phase p multiplies, the ds_reads of
+//     phase p+1 are in flight -- including across the k-tile boundary.
+// (2) Instruction fetch.  A per-block timeline (tools/gemm_trace.py, s_memrealtime stamps) of the first version showed
+//     11 us between kernel entry and the first MFMA and 20 us of epilogue per output tile -- next to 23 us of main loop
+//     for K = 768 -- with the stores compiled out: straight-line code that runs once per workgroup (a 40x unrolled,
+//     9-way branching epilogue was > 100 KB) is fetched cold, one cache line at a time, every time.  Hence
+//   * PERSISTENT workgroups: grid = min(#tiles, 256), each workgroup walks tiles v = b, b + G, ... (the order the
+//     dispatcher would have used, so the XCD-aware tile map is unchanged) and its code stays in the instruction cache;
+//   * a compact epilogue: accumulator fragments go through LDS 16 columns at a time and a ROLLED loop applies the
+//     epilogue to whole 64-B row segments; the epilogue flavour is a template parameter (EPI) so each instance carries
+//     only its own math;
+//   * the first k-tile of the NEXT output tile is in flight (LDS stage 0) while the epilogue of the current one drains
+//     through stage 1.
 // Tile-count quantisation decides MF: M = 25 120 tokens (B = 32, T = 4) gives 79 x 3 = 237 tiles of 320x256 for the
 // N = 768 GEMMs (one round on 256 CUs at 93 %), where 256x256 would need 297 tiles = two rounds at 58 %.
 //
@@ -34,13 +44,20 @@
 
 #include "common.h"
 #include "egovlp_hip.h"
-#include "gemm_epilogue.h"
 
 namespace {
 
 constexpr int KT = 64;    // contraction depth of one LDS tile
 constexpr int NFW = 8;    // 16-column fragments per wave
 constexpr int BNB = 256;  // block tile columns
+constexpr int NC = 2;     // B fragments per phase
+
+// epilogue flavours (template parameter: each kernel instance carries only its own epilogue code)
+enum { EPI_RAW = 0,      // store the accumulators (split-K partial slab, or plain fp32 output)
+       EPI_LINEAR = 1,   // + bias, + residual -> fp32 and/or planes
+       EPI_GELU = 2,     // + bias, pre-activation -> aux_out, gelu -> fp32 and/or planes
+       EPI_GELU_BWD = 3, // * gelu'(aux_in) -> fp32 and/or planes
+       EPI_GENERIC = 4 };// everything at run time (alpha, ReLU', ...)
 
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
 typedef __attribute__((ext_vector_type(8))) short s16x8v;
@@ -62,8 +79,42 @@ __device__ __forceinline__ bf16x8_t lds_tr2(const char* p) {
   return __builtin_bit_cast(bf16x8_t, z);
 }
 
-template <int MF, int NC, bool TN>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int desync) {
+// One 4-column piece of one output row: alpha, + bias, activation, + residual, stores (include/egovlp_hip.h order).
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int m, int n, int z, int ksplit) {
+  if (EPI == EPI_RAW) {
+    if (ksplit > 1) *(f32x4_t*)(p.partial + ((long)z * p.M + m) * p.N + n) = v;
+    else *(f32x4_t*)(p.out_f32 + (long)m * p.ldo + n) = v;
+    return;
+  }
+  if (EPI == EPI_GENERIC && p.alpha != 1.0f) v *= p.alpha;
+  if (EPI != EPI_GELU_BWD && p.bias) v += *(const f32x4_t*)(p.bias + n);
+  if (EPI == EPI_GELU || (EPI == EPI_GENERIC && p.act == EGV_ACT_GELU)) {
+    if (p.aux_out) *(f32x4_t*)(p.aux_out + (long)m * p.ldaux + n) = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+  } else if (EPI == EPI_GELU_BWD || (EPI == EPI_GENERIC && p.act == EGV_ACT_GELU_BWD)) {
+    const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(zv[e]);
+  } else if (EPI == EPI_GENERIC && p.act == EGV_ACT_RELU_BWD) {
+    const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = zv[e] > 0.f ? v[e] : 0.f;
+  }
+  if (p.residual) v += *(const f32x4_t*)(p.residual + (long)m * p.ldr + n);
+  if (p.out_f32) *(f32x4_t*)(p.out_f32 + (long)m * p.ldo + n) = v;
+  if (p.out_hi) {
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+    *(u32x2_t*)(p.out_hi + (long)m * p.ldoh + n) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+    if (p.out_lo) *(u32x2_t*)(p.out_lo + (long)m * p.ldoh + n) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+  }
+}
+
+template <int MF, bool TN, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = MF * 64;
   constexpr int A_BYTES = BM * 128;
@@ -72,30 +123,26 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   constexpr int NCH = NFW / NC;               // phases per 32-deep k-step
   constexpr int GA = TN ? 4 : MF;             // DMA pieces per wave per tile: A, B
   constexpr int GB = 4;
+  constexpr int EP_LD = 20;                   // epilogue staging: [16*MF rows][16 cols + 4 pad] floats per wave
+  constexpr int EP_WAVE = MF * 16 * EP_LD * 4;
   static_assert(!TN || MF == 4, "TN tiles are 256x256");
+  static_assert(8 * EP_WAVE <= STAGE, "epilogue staging must fit in one LDS stage");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  // DIAGNOSTIC (EGV_GEMM_DBG=200, tools/gemm_trace.py): per-tile 100 MHz timestamps into p.aux_out
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
 
   const int tiles_n = (p.N + BNB - 1) / BNB;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int nwg = tiles_m * tiles_n;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  const int tm = wg / tiles_n, tn = wg % tiles_n;
-  const int m0 = min(tm * BM, p.M - BM);      // shifted, never predicated (host guarantees M >= BM, N >= 256)
-  const int n0 = min(tn * BNB, p.N - BNB);
-
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-  const int z = blockIdx.y;
+  const int total = nwg * ksplit;
   const int nkt_total = (p.K + KT - 1) / KT;
   const int kt_per = (nkt_total + ksplit - 1) / ksplit;
-  const int kt_begin = z * kt_per;
-  const int kt_end = min(nkt_total, kt_begin + kt_per);
-  const int nkt = max(kt_end - kt_begin, 0);
   const int nseg = (p.passes == 3) ? 3 : 1;
-  const int nt = nkt * nseg;
 
   // k-segments: (A_hi,B_lo), (A_lo,B_hi), (A_hi,B_hi) for passes == 3; (A_hi,B_hi) alone otherwise
   auto seg_a = [&](int s) -> const bf16_t* { return (nseg == 3 && s == 1) ? p.a_lo : p.a_hi; };
@@ -117,37 +164,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     a_voff = (long)(wave * 8 + r) * p.lda;
     b_voff = (long)(wave * 8 + r) * p.ldb;
   }
-
-  int st_seg = 0, st_kt = kt_begin;   // the next tile to be staged
-  auto stage = [&](int buf) {
-    char* lds = smem + buf * STAGE;
-    if (!TN) {
-      const bf16_t* ab = seg_a(st_seg) + (long)m0 * p.lda + (long)st_kt * KT;
-      const bf16_t* bb = seg_b(st_seg) + (long)n0 * p.ldb + (long)st_kt * KT;
-#pragma unroll
-      for (int q = 0; q < GA; ++q) glds16(ab + a_voff + (long)q * 8 * p.lda, lds + (wave * GA + q) * 1024);
-#pragma unroll
-      for (int q = 0; q < GB; ++q) glds16(bb + b_voff + (long)q * 8 * p.ldb, lds + A_BYTES + (wave * GB + q) * 1024);
-    } else {
-      const bf16_t* ab = seg_a(st_seg) + (long)st_kt * KT * p.lda + m0;
-      const bf16_t* bb = seg_b(st_seg) + (long)st_kt * KT * p.ldb + n0;
-      const int krow = st_kt * KT + wave * 8 + (lane >> 5);     // + 2q
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ok = krow + 2 * q < p.K;
-        const int col = tn_col ^ (((2 * q) & 7) << 4);   // 32-B unit (16 elements) index ^= (2q) & 7
-        const bf16_t* sa = ab + a_voff + (long)(2 * q) * p.lda + col;
-        const bf16_t* sb = bb + b_voff + (long)(2 * q) * p.ldb + col;
-        const void* za = (const char*)g_zero_page + lane * 16;
-        glds16(ok ? (const void*)sa : za, lds + (wave * 4 + q) * 1024);
-        glds16(ok ? (const void*)sb : za, lds + A_BYTES + (wave * 4 + q) * 1024);
-      }
-    }
-    if (++st_kt == kt_end) {
-      st_kt = kt_begin;
-      ++st_seg;
-    }
-  };
 
   // ---- fragment read offsets (bytes within a stage) ---------------------------------------------------------
   int a_rd0, a_rd1, b_rd0, b_rd1;   // NT: k-step 0 / 1 bases;  TN: a_rd0 / b_rd0 only (k-step is an immediate)
@@ -185,127 +201,230 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     }
   };
 
-  f32x4_t acc[MF][NFW];
-#pragma unroll
-  for (int i = 0; i < MF; ++i)
-#pragma unroll
-    for (int j = 0; j < NFW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // bias-gradient accumulators (TN, first tile column, first wave column only)
-  const bool do_cs = TN && p.colsum != nullptr && tn == 0 && wn == 0;
-  f32x4_t cs[MF];
-#pragma unroll
-  for (int i = 0; i < MF; ++i) cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const s16x8v ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
-  // EXPERIMENT (EGV_DESYNC=n): all CUs run their tiles in lockstep, so every round ends in a chip-wide store burst
-  // during which no MFMA issues.  Delaying every other first-round block by ~half a tile staggers the CUs.
-  if (desync > 0 && desync < 100 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-    for (int i = 0; i < desync * nt / 4; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  if (nt > 0) {
-    stage(0);
-    if (nt > 1) {
-      stage(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
+  // ---- per-output-tile state (all wave-uniform) ----------------------------------------------------------------
+  int m0, n0, z, tn, kt_begin, kt_end, nt;    // current tile
+  int st_seg, st_kt;                          // next k-tile to be staged (of the tile being staged)
+  int sm0, sn0, skt_begin, skt_end;           // origin / k-range of the tile being staged
+  auto decode = [&](int v, int& om0, int& on0, int& oz, int& otn, int& okb, int& oke) {
+    oz = v / nwg;
+    const int wg = xcd_remap(v - oz * nwg, nwg);
+    const int tm = wg / tiles_n;
+    otn = wg - tm * tiles_n;
+    om0 = min(tm * BM, p.M - BM);      // shifted, never predicated (host guarantees M >= BM, N >= 256)
+    on0 = min(otn * BNB, p.N - BNB);
+    okb = oz * kt_per;
+    oke = min(nkt_total, okb + kt_per);
+  };
+
+  auto stage = [&](int buf) {   // one k-tile of tile (sm0, sn0) -> LDS stage `buf`
+    char* lds = smem + buf * STAGE;
+    if (!TN) {
+      const bf16_t* ab = seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * KT;
+      const bf16_t* bb = seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * KT;
+#pragma unroll
+      for (int q = 0; q < GA; ++q) glds16(ab + a_voff + (long)q * 8 * p.lda, lds + (wave * GA + q) * 1024);
+#pragma unroll
+      for (int q = 0; q < GB; ++q) glds16(bb + b_voff + (long)q * 8 * p.ldb, lds + A_BYTES + (wave * GB + q) * 1024);
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const bf16_t* ab = seg_a(st_seg) + (long)st_kt * KT * p.lda + sm0;
+      const bf16_t* bb = seg_b(st_seg) + (long)st_kt * KT * p.ldb + sn0;
+      const int krow = st_kt * KT + wave * 8 + (lane >> 5);     // + 2q
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = krow + 2 * q < p.K;
+        const int col = tn_col ^ (((2 * q) & 7) << 4);   // 32-B unit (16 elements) index ^= (2q) & 7
+        const bf16_t* sa = ab + a_voff + (long)(2 * q) * p.lda + col;
+        const bf16_t* sb = bb + b_voff + (long)(2 * q) * p.ldb + col;
+        const void* za = (const char*)g_zero_page + lane * 16;
+        glds16(ok ? (const void*)sa : za, lds + (wave * 4 + q) * 1024);
+        glds16(ok ? (const void*)sb : za, lds + A_BYTES + (wave * 4 + q) * 1024);
+      }
     }
-    __builtin_amdgcn_s_barrier();
-    load_b(0, 0, 0, Bq[0]);
-    load_a(0, 0, A[0]);
-  }
+    if (++st_kt == skt_end) {
+      st_kt = skt_begin;
+      ++st_seg;
+    }
+  };
 
-  int cur_seg = 0, cur_kt = kt_begin;
-  for (int t = 0; t < nt; ++t) {
-    const int sb = (t & 1) * STAGE;
-    const bool cs_on = do_cs && (nseg == 1 || cur_seg >= 1);
+  int v = blockIdx.x;
+  if (v >= total) return;
+  decode(v, m0, n0, z, tn, kt_begin, kt_end);
+  nt = max(kt_end - kt_begin, 0) * nseg;
+  sm0 = m0; sn0 = n0; skt_begin = kt_begin; skt_end = kt_end; st_seg = 0; st_kt = kt_begin;
+  if (nt > 0) stage(0);
+
+  for (;;) {
+    if (dbg == 200) ts0 = __builtin_amdgcn_s_memrealtime();
+    // ================= main loop of tile v: k-tile 0 is in flight or landed in stage 0 ==========================
+    f32x4_t acc[MF][NFW];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int ph = ks * NCH + c;
-        const bool last = (ph == 2 * NCH - 1);
-        // hipcc waits lgkmcnt(0) right before the first MFMA that consumes a prefetched fragment, so the prefetch of
-        // phase p+1 is issued AFTER the first MFMA of phase p (it then has the rest of the phase to land) -- issued
-        // before it, every phase would start by waiting for the reads it had just issued (seen in the .s).
-        if (c == 0 && cs_on) {
+      for (int j = 0; j < NFW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = TN && p.colsum != nullptr && tn == 0 && wn == 0;
+    f32x4_t cs[MF];
 #pragma unroll
-          for (int i = 0; i < MF; ++i) cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[ks & 1][i], cs[i], 0, 0, 0);
-        }
-        acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][0], A[ks & 1][0], acc[0][c * NC], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (last) {
-          if (t + 1 < nt) {
-            // tile t+1 (this wave's DMA pieces) landed; all of this wave's reads of stage t&1 have returned
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < nt) stage(t & 1);
-            load_b(STAGE - sb, 0, 0, Bq[0]);
-            load_a(STAGE - sb, 0, A[0]);
+    for (int i = 0; i < MF; ++i) cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    if (nt > 0) {
+      if (nt > 1) {
+        stage(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      load_b(0, 0, 0, Bq[0]);
+      load_a(0, 0, A[0]);
+    }
+    if (dbg == 200) ts1 = __builtin_amdgcn_s_memrealtime();
+
+    int cur_seg = 0, cur_kt = kt_begin;
+    for (int t = 0; t < nt; ++t) {
+      const int sb = (t & 1) * STAGE;
+      const bool cs_on = do_cs && (nseg == 1 || cur_seg >= 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int ph = ks * NCH + c;
+          const bool last = (ph == 2 * NCH - 1);
+          // hipcc waits lgkmcnt(0) right before the first MFMA that consumes a prefetched fragment, so the prefetch of
+          // phase p+1 is issued AFTER the first MFMA of phase p (it then has the rest of the phase to land) -- issued
+          // before it, every phase would start by waiting for the reads it had just issued (seen in the .s).
+          if (c == 0 && cs_on) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+              cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[ks & 1][i], cs[i], 0, 0, 0);
           }
-        } else {
-          const int ks2 = (c + 1 < NCH) ? ks : ks + 1;
-          const int c2 = (c + 1 < NCH) ? c + 1 : 0;
-          load_b(sb, ks2, c2, Bq[(ph + 1) & 1]);
-          if (c2 == 0) load_a(sb, ks2, A[ks2 & 1]);
+          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][0], A[ks & 1][0], acc[0][c * NC], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (last) {
+            if (t + 1 < nt) {
+              // tile t+1 (this wave's DMA pieces) landed; all of this wave's reads of stage t&1 have returned
+              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              if (t + 2 < nt) stage(t & 1);
+              load_b(STAGE - sb, 0, 0, Bq[0]);
+              load_a(STAGE - sb, 0, A[0]);
+            }
+          } else {
+            const int ks2 = (c + 1 < NCH) ? ks : ks + 1;
+            const int c2 = (c + 1 < NCH) ? c + 1 : 0;
+            load_b(sb, ks2, c2, Bq[(ph + 1) & 1]);
+            if (c2 == 0) load_a(sb, ks2, A[ks2 & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jj = 0; jj < NC; ++jj)
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+              if (jj + i > 0)
+                acc[i][c * NC + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][jj], A[ks & 1][i],
+                                                                              acc[i][c * NC + jj], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jj = 0; jj < NC; ++jj)
-#pragma unroll
-          for (int i = 0; i < MF; ++i)
-            if (jj + i > 0)
-              acc[i][c * NC + jj] =
-                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][jj], A[ks & 1][i], acc[i][c * NC + jj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (++cur_kt == kt_end) {
+        cur_kt = kt_begin;
+        ++cur_seg;
       }
     }
-    if (++cur_kt == kt_end) {
-      cur_kt = kt_begin;
-      ++cur_seg;
-    }
-  }
+    if (dbg == 200) ts2 = __builtin_amdgcn_s_memrealtime();
 
-  // ---- epilogue ------------------------------------------------------------------------------------------
-  const int lm = lane & 15;
-  const int ln = (lane >> 4) * 4;
+    // ================= hand-over: every wave is done with both LDS stages =========================================
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < total;
+    int nm0 = 0, nn0 = 0, nz = 0, ntn = 0, nkb = 0, nke = 0, nnt = 0;
+    if (has_next) {
+      // first k-tile of the NEXT output tile -> stage 0, in flight while this tile's epilogue drains through stage 1
+      decode(vn, nm0, nn0, nz, ntn, nkb, nke);
+      nnt = max(nke - nkb, 0) * nseg;
+      sm0 = nm0; sn0 = nn0; skt_begin = nkb; skt_end = nke; st_seg = 0; st_kt = nkb;
+      if (nnt > 0) stage(0);
+    }
+
+    // ================= epilogue of tile v ===========================================================================
+    // fragment (i, j) of this wave: lane holds C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) .. +3].  Per j, the
+    // MF fragments are written to this wave's private staging rows ([16 MF][16 + 4 pad] floats; the pad makes the
+    // 8-lane ds_write_b128 groups conflict-free) and read back as 64-B row segments by a rolled loop.
+    {
+      char* ep = smem + STAGE + wave * EP_WAVE;
+      const int wr_off = ((lane & 15) * EP_LD + 4 * (lane >> 4)) * 4;
+      const int rd_row = lane >> 2, rd_c4 = (lane & 3) * 4;
+      const int mw = m0 + wm * MF * 16;
+      const int nw = n0 + wn * 128;
 #pragma unroll
-  for (int i = 0; i < MF; ++i) {
-    const int m = m0 + wm * MF * 16 + i * 16 + lm;
+      for (int j = 0; j < NFW; ++j) {
 #pragma unroll
-    for (int j = 0; j < NFW; ++j) {
-      if (desync == 100) {   // EXPERIMENT: main loop only (accumulators kept live, nothing stored)
-        asm volatile("" ::"v"(acc[i][j]));
-        continue;
+        for (int i = 0; i < MF; ++i) *(f32x4_t*)(ep + wr_off + i * 16 * EP_LD * 4) = acc[i][j];
+        if (dbg >= 100) continue;   // EXPERIMENT: nothing stored (main-loop-only timing)
+#pragma unroll 1
+        for (int r = 0; r < MF; ++r) {
+          const int row = r * 16 + rd_row;
+          const f32x4_t val = *(const f32x4_t*)(ep + (row * EP_LD + rd_c4) * 4);
+          epilogue4<EPI>(p, val, mw + row, nw + j * 16 + rd_c4, z, ksplit);
+        }
       }
-      egv_gemm_store4(p, acc[i][j], m, n0 + wn * 128 + j * 16 + ln, z, ksplit);
+      if (do_cs && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          const int m = mw + i * 16 + (lane & 15);
+          if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
+          else p.colsum[m] = cs[i][0];
+        }
+      }
     }
-    if (do_cs && ln == 0) {
-      if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
-      else p.colsum[m] = cs[i][0];
+    if (dbg == 200 && tid == 0) {
+      unsigned long long* tsb = (unsigned long long*)p.aux_out + (long)v * 4;
+      tsb[0] = ts0; tsb[1] = ts1; tsb[2] = ts2; tsb[3] = __builtin_amdgcn_s_memrealtime();
     }
+    if (!has_next) break;
+    v = vn; m0 = nm0; n0 = nn0; z = nz; tn = ntn; kt_begin = nkb; kt_end = nke; nt = nnt;
+    // k-tile 0 of the new tile has landed (and this wave's epilogue stores have drained: vmcnt counts them too);
+    // after the barrier stage 1 (the epilogue staging rows of every wave) may be overwritten by k-tile 1.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 }
 
-template <int MF, int NC, bool TN>
+template <int MF, bool TN, int EPI>
 int launch_big(const egv_gemm_desc& p, hipStream_t s) {
   constexpr int BM = MF * 64;
   constexpr int lds = 2 * (BM * 128 + BNB * 128);
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNB - 1) / BNB);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
-  auto k = gemm_big_kernel<MF, NC, TN>;
+  const int total = tiles * ks;
+  auto k = gemm_big_kernel<MF, TN, EPI>;
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return EGV_ERR_LAUNCH + (int)hipGetLastError();
     attr_set = true;
   }
-  static const int desync = getenv("EGV_DESYNC") ? atoi(getenv("EGV_DESYNC")) : 0;
-  EGV_LAUNCH(k, dim3(tiles, ks), dim3(512), lds, s, p, desync);
+  static const int dbg = getenv("EGV_GEMM_DBG") ? atoi(getenv("EGV_GEMM_DBG")) : 0;
+  // persistent workgroups: one per CU (144 KiB of LDS each); G = 256 keeps v % 8 == blockIdx % 8 (XCD affinity)
+  const int grid = total < 256 ? total : 256;
+  EGV_LAUNCH(k, dim3(grid), dim3(512), lds, s, p, dbg);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
+}
+
+template <int MF, bool TN>
+int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
+  if (p.ksplit > 1 || TN) return launch_big<MF, TN, EPI_RAW>(p, s);   // split-K slab / wgrad: plain fp32 output
+  if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
+    if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW>(p, s);
+    return launch_big<MF, false, EPI_LINEAR>(p, s);
+  }
+  if (p.alpha == 1.0f && p.act == EGV_ACT_GELU) return launch_big<MF, false, EPI_GELU>(p, s);
+  if (p.alpha == 1.0f && p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD>(p, s);
+  return launch_big<MF, false, EPI_GENERIC>(p, s);
 }
 
 }  // namespace
@@ -314,7 +433,9 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s) {
 bool egv_gemm_big_supports(const egv_gemm_desc& p) {
   if (p.M < 256 || p.N < BNB || p.N % 4 != 0) return false;
   if (p.lda % 8 != 0 || p.ldb % 8 != 0) return false;
-  if (p.trans) return p.M % 8 == 0 && p.N % 8 == 0;
+  if (p.trans)
+    return p.M % 8 == 0 && p.N % 8 == 0 && p.out_f32 != nullptr && p.act == EGV_ACT_NONE && !p.bias && !p.residual &&
+           !p.out_hi && p.alpha == 1.0f;
   return p.K % KT == 0;
 }
 
@@ -336,11 +457,11 @@ int egv_gemm_big_pick_mf(const egv_gemm_desc& p) {
   return best_mf;
 }
 
-// variant: 0 = auto; 4 / 5 force MF; +10 selects the 4-fragment phase (NC = 4) where it exists (diagnostics)
+// variant: 0 / 3 = auto; 4 / 5 force MF (diagnostics)
 int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant) {
-  if (p.trans) return launch_big<4, 2, true>(p, s);
+  if (p.trans) return launch_epi<4, true>(p, s);
   int mf = (variant % 10 == 4 || variant % 10 == 5) ? variant % 10 : egv_gemm_big_pick_mf(p);
   if (p.M < mf * 64) mf = 4;
-  if (mf == 5) return launch_big<5, 2, false>(p, s);
-  return (variant >= 10) ? launch_big<4, 4, false>(p, s) : launch_big<4, 2, false>(p, s);
+  if (mf == 5) return launch_epi<5, false>(p, s);
+  return launch_epi<4, false>(p, s);
 }
