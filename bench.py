@@ -57,7 +57,8 @@ def cpu_baseline(B=4, T=4, L=32):
         loss.backward()
         return time.perf_counter() - t0
 
-    dt = one(B)                  # no separate warm-up: it would double the bounded CPU budget
+    one(1)                       # warm-up at B=1 (thread pool, allocator) -- a fraction of the timed sample
+    dt = one(B)
     return {"value": round(B / dt, 4), "unit": "clip-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 fwd+bwd+EgoNCE step of the CPU oracle at B={B} (T={T}, L={L}), {dt:.1f} s, "
                       f"{os.cpu_count()} logical cpus"}
@@ -71,8 +72,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--arch", default="base_patch16_224")
-    ap.add_argument("--precision", default=os.environ.get("EGOVLP_PRECISION", "bf16x3"),
-                    help="bf16x3 (parity mode, fp32-grade) | bf16 (single pass) | mixed (fwd bf16x3, bwd bf16)")
+    ap.add_argument("--precision", default=os.environ.get("EGOVLP_PRECISION", "mixed"),
+                    help="mixed (default: forward bf16x3 = embeddings and loss inside the 1e-3 parity bar, backward "
+                         "single-pass bf16) | bf16 (single pass everywhere, fast mode) | bf16x3 (fp32-grade everywhere)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass bf16 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -93,11 +96,13 @@ def main():
     from egovlp_amd.synth import synth_batch
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
 
-    if args.precision == "mixed":
-        ops.Precision.set("bf16x3", "bf16")
-    else:
-        ops.Precision.set(args.precision)
+    def set_precision(name):
+        if name == "mixed":
+            ops.Precision.set("bf16x3", "bf16")
+        else:
+            ops.Precision.set(name)
 
+    set_precision(args.precision)
     B, T, L = args.batch, args.frames, 32
     model = build_model(args.arch, 16).cuda().train()
     net = model
@@ -115,21 +120,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        egoclip_step(net, loss_fn, opt, data, world, rank)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = egoclip_step(net, loss_fn, opt, data, world, rank)
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+    def measure(steps, warmup):
+        for _ in range(warmup):
+            egoclip_step(net, loss_fn, opt, data, world, rank)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = egoclip_step(net, loss_fn, opt, data, world, rank)
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax), float(loss)
+
+    dt, loss_val = measure(args.steps, args.warmup)
     ms = dt / args.steps * 1e3
     pairs = world * B * args.steps / dt
-    loss_val = float(loss)
 
     # ---- dominant-kernel roofline: the bf16-MFMA GEMM.  HIP events bracket every egv_gemm_nt launch on the stream
     # the kernels run on, in a separate instrumented pass of the same step (so the timed value above is untouched).
@@ -143,16 +150,17 @@ def main():
         ops.KERNEL_TIMER = None
         g = kt["egv_gemm_nt"]
         ach = g["flops"] / g["seconds"] / 1e12
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (egv_gemm_nt)", "achieved": round(ach, 1),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "launches_per_step": g["launches"] // 2,
+        roof = {"bound": "mfma", "kernel": "gemm_big_kernel / gemm_nt_kernel (every egv_gemm_nt launch of the step)",
+                "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": g["launches"] // 2,
                 "avg_launch_us": round(g["seconds"] / g["launches"] * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3),
                 "gemm_ms_per_step": round(g["seconds"] / 2 * 1e3, 3),
-                "mfma_issue_tflops": round(ach * (3 if ops.Precision.fwd_passes == 3 and ops.Precision.bwd_passes == 3 else 1), 1)
-                if args.precision != "mixed" else None,
-                "note": "achieved = algorithmic 2*M*N*K of all GEMM launches of a step / their summed HIP-event time; "
-                        "bf16x3 issues 3 MFMA passes per algorithmic product (ceiling 1/3 of peak)"}
+                "mfma_issue_tflops": round(g["issue_flops"] / g["seconds"] / 1e12, 1),
+                "note": "achieved = algorithmic 2*M*N*K of all GEMM launches of a step / their summed HIP-event time "
+                        "(events on the launch stream around each C-ABI call); bf16x3 launches issue 3 MFMA passes per "
+                        "algorithmic product (mfma_issue_tflops counts them); traffic: see profiles/ PMC summaries"}
     key = (args.arch, T)
     step_frac = None
     if key in FWD_GFLOP_PER_PAIR:
@@ -162,7 +170,7 @@ def main():
         "metric": "clip-pairs/sec (whole node), 4f/224^2 ViT-B + 32-tok text, B=32/GPU, train step (fwd+gather+EgoNCE+bwd+AdamW)",
         "value": round(pairs, 2), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
+        "dtype": "bf16", "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
         "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
                    "parallelism": f"dp{world}", "precision": "/".join(ops.Precision.name())},
@@ -171,6 +179,16 @@ def main():
     }
     if roof is not None:
         out["roofline"] = roof
+    if args.precision != "bf16" and not args.no_fast_mode:
+        # secondary line: the same step with single-pass bf16 operands everywhere (embeddings ~6e-3 from fp32:
+        # outside the parity bar, reported for reference only -- `value` above is the parity-mode number)
+        set_precision("bf16")
+        dt2, loss2 = measure(args.steps, max(args.warmup, 2))
+        out["fast_mode_bf16"] = {"value": round(world * B * args.steps / dt2, 2), "unit": "clip-pairs/s",
+                                 "ms_per_step": round(dt2 / args.steps * 1e3, 3), "loss": round(loss2, 5),
+                                 "step_mfma_frac": None if key not in FWD_GFLOP_PER_PAIR else round(
+                                     B * args.steps / dt2 * FWD_GFLOP_PER_PAIR[key] * 3e9 / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        set_precision(args.precision)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

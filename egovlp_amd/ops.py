@@ -51,20 +51,20 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def time(self, name, flops, fn):
+    def time(self, name, flops, fn, passes=1):
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         fn()
         e1.record(st)
-        self.records.setdefault(name, []).append((e0, e1, flops))
+        self.records.setdefault(name, []).append((e0, e1, flops, flops * passes))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
-            out[name] = {"launches": len(recs), "seconds": sum(a.elapsed_time(b) for a, b, _ in recs) * 1e-3,
-                         "flops": float(sum(f for _, _, f in recs))}
+            out[name] = {"launches": len(recs), "seconds": sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3,
+                         "flops": float(sum(r[2] for r in recs)), "issue_flops": float(sum(r[3] for r in recs))}
         return out
 
 
@@ -137,7 +137,7 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     d.trans, d.colsum = 0, None
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * K,
-                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"))
+                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"), passes)
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
 
@@ -174,7 +174,7 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     d.trans, d.colsum = 1, _p(cs)
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * Kd,
-                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"))
+                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"), passes)
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)")
     return cs
