@@ -52,8 +52,10 @@ PROTOTYPES = {
     "egv_patch_gather": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, i64, c_p]),
     "egv_assemble_tokens": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p]),
     "egv_assemble_tokens_bwd": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),
-    "egv_divided_attn_fwd": (i32, [c_p, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
-    "egv_divided_attn_bwd": (i32, [c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p]),
+    "egv_divided_attn_fwd": (i32, [c_p, c_p, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),
+    "egv_divided_attn_fwd_work_floats": (i64, [i32, i32, i32, i32, i32]),
+    "egv_divided_attn_bwd": (i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
+    "egv_divided_attn_bwd_work_floats": (i64, [i32, i32, i32, i32]),
     "egv_embed_fwd": (i32, [c_p, c_p, c_p, i32, i32, i32, c_p, c_p]),
     "egv_embed_bwd": (i32, [c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p]),
     "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),

@@ -111,6 +111,36 @@ __device__ __forceinline__ void att_gfrag(const float* rowp, int ks, int lane, f
   att_split8(v, hi, lo);
 }
 
+// ---- the same two loaders for operands that already ARE split-bf16 planes in HBM (the fused qkv buffer written by
+// the qkv GEMM epilogue, the attention-output gradient written by the proj dgrad epilogue): a straight 16-B copy.
+// row_off(r) returns the ELEMENT offset of row r (64 contiguous bf16) inside the hi / lo planes.  256 threads.
+template <typename RowOff>
+__device__ __forceinline__ void att_stage_planes(char* hi, char* lo, const bf16_t* ph, const bf16_t* pl, int nrows,
+                                                 int prows, RowOff row_off) {
+  for (int t = threadIdx.x; t < prows * 8; t += 256) {
+    const int row = t >> 3, chunk = t & 7;
+    u32x4_t a = {0u, 0u, 0u, 0u}, b = a;
+    if (row < nrows) {
+      const long off = row_off(row) + chunk * 8;
+      a = *(const u32x4_t*)(ph + off);
+      if (lo) b = *(const u32x4_t*)(pl + off);
+    }
+    const int o = row * ATT_ROW_BYTES + ((chunk ^ (row & 7)) << 4);
+    *(u32x4_t*)(hi + o) = a;
+    if (lo) *(u32x4_t*)(lo + o) = b;
+  }
+}
+
+// B-operand fragment straight from global planes: `off` = element offset of this lane's row (l&15 resolved by the
+// caller); columns 8*((l>>4) + 4*ks) .. +7.
+__device__ __forceinline__ void att_gfrag_planes(const bf16_t* ph, const bf16_t* pl, long off, int ks, int lane,
+                                                 bf16x8_t& hi, bf16x8_t& lo) {
+  const long o = off + ((lane >> 4) + 4 * ks) * 8;
+  hi = *(const bf16x8_t*)(ph + o);
+  lo = hi;
+  if (pl) lo = *(const bf16x8_t*)(pl + o);
+}
+
 template <int PASSES>
 __device__ __forceinline__ f32x4_t att_mma(bf16x8_t ah, bf16x8_t al, bf16x8_t bh, bf16x8_t bl, f32x4_t c) {
   if (PASSES == 3) {
@@ -127,10 +157,12 @@ __device__ __forceinline__ f32x4_t att_mma(bf16x8_t ah, bf16x8_t al, bf16x8_t bh
 enum { MODE_SPACE = 0, MODE_TEXT = 2 };
 
 struct AttGeom {
-  const float* q;
+  const float* q;    // MODE_TEXT: fp32 sources
   const float* k;
   const float* v;
-  long tok_stride;   // floats between consecutive tokens in q/k/v
+  const bf16_t* ph;  // MODE_SPACE: the fused qkv buffer [B, S, 3, H, 64] as split-bf16 planes (pl == nullptr: hi only)
+  const bf16_t* pl;
+  long tok_stride;   // elements between consecutive tokens in q/k/v (or in the planes)
   int B, T, n, H, S; // S = tokens per batch item (1+T*n or L)
   int nq, nk;
   const long long* mask;  // MODE_TEXT only

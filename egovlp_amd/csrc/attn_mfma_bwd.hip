@@ -15,22 +15,39 @@
 namespace {
 
 struct AttGrad {
-  float* dq;
+  float* dq;           // MODE_TEXT: fp32 outputs
   float* dk;
   float* dv;
-  long tok_stride;     // floats between tokens in dq/dk/dv
-  const float* d_out;  // [B, S, H*64] fp32
+  bf16_t* gh;          // MODE_SPACE: dqkv as split-bf16 planes [B, S, 3, H, 64] (gl == nullptr: hi only)
+  bf16_t* gl;
+  long tok_stride;     // elements between tokens in dq/dk/dv (or in the gradient planes)
+  const float* d_out;  // MODE_TEXT: [B, S, H*64] fp32
+  const bf16_t* doh;   // MODE_SPACE: d_out planes
+  const bf16_t* dol;
   long do_stride;
   const float* lse;    // [B, H, S]
-  float* delta;        // [B, H, S] workspace (written by dQ kernel, read by dKV kernel)
+  float* delta;        // [B, H, S] workspace (written by dQ kernel, read by dKV kernel; slot 0 = the CLS row's delta,
+                       //  precomputed by egv_attn_cls_delta in MODE_SPACE)
+  float* dcls;         // MODE_SPACE: [B, H, 3, 64] fp32 accumulators of the CLS token's raw dq / dk / dv (zeroed first)
 };
 
+__device__ __forceinline__ void store_planes4(bf16_t* hi, bf16_t* lo, long off, f32x4_t v) {
+  bf16_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+  *(u32x2_t*)(hi + off) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+  if (lo) *(u32x2_t*)(lo + off) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+}
+
 // ------------------------------------------------------------------------------------------------ dQ
+// MODE_SPACE: operands are planes; the clip's CLS query rides as query row n (see attn_mfma_fwd.hip): its L and delta
+// are the GLOBAL ones (lse[b,h,0], delta[b,h,0]); its dq partial over this frame's keys is accumulated atomically.
 template <int MODE, int NKF, int PASSES>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const AttGrad gr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKP = NKF * 16;
   constexpr int PLANE = NKP * ATT_ROW_BYTES;
+  constexpr bool SP = (MODE == MODE_SPACE);
   char* k_hi = smem;
   char* v_hi = smem + PLANE;
   char* k_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
@@ -41,9 +58,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long hoff = (long)grp.h * ATT_D;
+  const long HD = (long)g.H * ATT_D;
 
-  att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
-  att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  if (SP) {
+    att_stage_planes(k_hi, k_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + HD + hoff; });
+    att_stage_planes(v_hi, v_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + 2 * HD + hoff; });
+  } else {
+    att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
+    att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  }
   for (int j = threadIdx.x; j < NKP; j += 256) {
     float bias = (j < g.nk) ? 0.f : -1e30f;
     if (MODE == MODE_TEXT && j < g.nk && g.mask[(long)grp.b * g.S + j] == 0) bias = -1e30f;
@@ -52,19 +75,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
   __syncthreads();
 
   const int gq = lane >> 4;
-  const int ntiles = (g.nq + 15) / 16;
+  const int nq_all = SP ? g.nq + 1 : g.nq;
+  const int ntiles = (nq_all + 15) / 16;
   for (int qt = wave; qt < ntiles; qt += 4) {
     asm volatile("" ::: "memory");  // K/V fragments are loop-invariant: stop LICM from hoisting ~900 VGPRs of them
     const int qi = qt * 16 + (lane & 15);
-    const int qc = min(qi, g.nq - 1);
-    const long tok = grp.q_tok(g, qc);
-    const float* qrow = g.q + tok * g.tok_stride + hoff;
-    const float* grow = gr.d_out + tok * gr.do_stride + hoff;
+    const bool is_cls = SP && qi >= g.nq;
+    const long tok = is_cls ? grp.tok0 : grp.q_tok(g, min(qi, g.nq - 1));
     bf16x8_t qh[2], ql[2], gh[2], gl[2];
-    att_gfrag(qrow, 0, lane, 0.125f, qh[0], ql[0]);
-    att_gfrag(qrow, 1, lane, 0.125f, qh[1], ql[1]);
-    att_gfrag(grow, 0, lane, 1.0f, gh[0], gl[0]);
-    att_gfrag(grow, 1, lane, 1.0f, gh[1], gl[1]);
+    if (SP) {
+      att_gfrag_planes(g.ph, g.pl, tok * g.tok_stride + hoff, 0, lane, qh[0], ql[0]);
+      att_gfrag_planes(g.ph, g.pl, tok * g.tok_stride + hoff, 1, lane, qh[1], ql[1]);
+      att_gfrag_planes(gr.doh, gr.dol, tok * gr.do_stride + hoff, 0, lane, gh[0], gl[0]);
+      att_gfrag_planes(gr.doh, gr.dol, tok * gr.do_stride + hoff, 1, lane, gh[1], gl[1]);
+    } else {
+      const float* qrow = g.q + tok * g.tok_stride + hoff;
+      const float* grow = gr.d_out + tok * gr.do_stride + hoff;
+      att_gfrag(qrow, 0, lane, 1.0f, qh[0], ql[0]);
+      att_gfrag(qrow, 1, lane, 1.0f, qh[1], ql[1]);
+      att_gfrag(grow, 0, lane, 1.0f, gh[0], gl[0]);
+      att_gfrag(grow, 1, lane, 1.0f, gh[1], gl[1]);
+    }
     const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (tok - grp.tok0);
     const float L = gr.lse[lrow];
 
@@ -88,13 +119,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
       const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[kf][r] = __expf(s[r] + kb[r] - L);
+        p[kf][r] = __expf(s[r] * 0.125f + kb[r] - L);
+        if (SP && kf == 0 && r == 0 && is_cls && grp.f > 0 && gq == 0) p[kf][r] = 0.f;   // CLS key x CLS query: group 0 only
         delta += p[kf][r] * d[r];
       }
       dp[kf] = d;
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
+    if (is_cls) delta = gr.delta[lrow];             // the CLS row's delta spans all frame groups: precomputed
 
     f32x4_t dq[4];
 #pragma unroll
@@ -117,10 +150,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
         dq[df] = att_mma<PASSES>(kh, kl, sh, sl, dq[df]);
       }
     }
-    if (qi < g.nq) {
-      float* out = gr.dq + tok * gr.tok_stride + hoff;
+    if (SP && qi == g.nq) {
+      float* a = gr.dcls + ((long)grp.b * g.H + grp.h) * 192;
 #pragma unroll
-      for (int df = 0; df < 4; ++df) *(f32x4_t*)(out + df * 16 + 4 * gq) = dq[df] * 0.125f;
+      for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(a + df * 16 + 4 * gq + r, dq[df][r]);
+    } else if (qi < g.nq) {
+      if (SP) {
+#pragma unroll
+        for (int df = 0; df < 4; ++df)
+          store_planes4(gr.gh, gr.gl, tok * gr.tok_stride + hoff + df * 16 + 4 * gq, dq[df] * 0.125f);
+      } else {
+        float* out = gr.dq + tok * gr.tok_stride + hoff;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) *(f32x4_t*)(out + df * 16 + 4 * gq) = dq[df] * 0.125f;
+      }
       if (gq == 0) gr.delta[lrow] = delta;
     }
   }
@@ -132,6 +177,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NQP = NQF * 16;
   constexpr int PLANE = NQP * ATT_ROW_BYTES;
+  constexpr bool SP = (MODE == MODE_SPACE);
   char* q_hi = smem;
   char* o_hi = smem + PLANE;
   char* q_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
@@ -143,13 +189,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long hoff = (long)grp.h * ATT_D;
+  const long HD = (long)g.H * ATT_D;
+  const int nq_all = SP ? g.nq + 1 : g.nq;          // query row n = the clip's CLS query (MODE_SPACE)
+  auto qrow_tok = [&](int r) { return (SP && r >= g.nq) ? grp.tok0 : grp.q_tok(g, r); };
 
-  att_stage(q_hi, q_lo, g.nq, NQP, 0.125f, [&](int r) { return g.q + grp.q_tok(g, r) * g.tok_stride + hoff; });
-  att_stage(o_hi, o_lo, g.nq, NQP, 1.0f, [&](int r) { return gr.d_out + grp.q_tok(g, r) * gr.do_stride + hoff; });
+  if (SP) {
+    att_stage_planes(q_hi, q_lo, g.ph, g.pl, nq_all, NQP, [&](int r) { return qrow_tok(r) * g.tok_stride + hoff; });
+    att_stage_planes(o_hi, o_lo, gr.doh, gr.dol, nq_all, NQP, [&](int r) { return qrow_tok(r) * gr.do_stride + hoff; });
+  } else {
+    att_stage(q_hi, q_lo, g.nq, NQP, 1.0f, [&](int r) { return g.q + grp.q_tok(g, r) * g.tok_stride + hoff; });
+    att_stage(o_hi, o_lo, g.nq, NQP, 1.0f, [&](int r) { return gr.d_out + grp.q_tok(g, r) * gr.do_stride + hoff; });
+  }
   for (int i = threadIdx.x; i < NQP; i += 256) {
     float L = 1e30f, dl = 0.f;  // padded query rows: P = exp(s - 1e30) = 0
-    if (i < g.nq) {
-      const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (grp.q_tok(g, i) - grp.tok0);
+    if (i < nq_all) {
+      const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (qrow_tok(i) - grp.tok0);
       L = gr.lse[lrow];
       dl = gr.delta[lrow];
     }
@@ -164,15 +218,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
     const int kj = kf * 16 + (lane & 15);
     const int kc = min(kj, g.nk - 1);
     const long ktok = grp.k_tok(g, kc);
-    const float* krow = g.k + ktok * g.tok_stride + hoff;
-    const float* vrow = g.v + ktok * g.tok_stride + hoff;
     bf16x8_t kh[2], kl[2], vh[2], vl[2];
-    att_gfrag(krow, 0, lane, 1.0f, kh[0], kl[0]);
-    att_gfrag(krow, 1, lane, 1.0f, kh[1], kl[1]);
-    att_gfrag(vrow, 0, lane, 1.0f, vh[0], vl[0]);
-    att_gfrag(vrow, 1, lane, 1.0f, vh[1], vl[1]);
+    if (SP) {
+      att_gfrag_planes(g.ph, g.pl, ktok * g.tok_stride + HD + hoff, 0, lane, kh[0], kl[0]);
+      att_gfrag_planes(g.ph, g.pl, ktok * g.tok_stride + HD + hoff, 1, lane, kh[1], kl[1]);
+      att_gfrag_planes(g.ph, g.pl, ktok * g.tok_stride + 2 * HD + hoff, 0, lane, vh[0], vl[0]);
+      att_gfrag_planes(g.ph, g.pl, ktok * g.tok_stride + 2 * HD + hoff, 1, lane, vh[1], vl[1]);
+    } else {
+      const float* krow = g.k + ktok * g.tok_stride + hoff;
+      const float* vrow = g.v + ktok * g.tok_stride + hoff;
+      att_gfrag(krow, 0, lane, 1.0f, kh[0], kl[0]);
+      att_gfrag(krow, 1, lane, 1.0f, kh[1], kl[1]);
+      att_gfrag(vrow, 0, lane, 1.0f, vh[0], vl[0]);
+      att_gfrag(vrow, 1, lane, 1.0f, vh[1], vl[1]);
+    }
     float kb = (kj < g.nk) ? 0.f : -1e30f;
     if (MODE == MODE_TEXT && kj < g.nk && g.mask[(long)grp.b * g.S + kj] == 0) kb = -1e30f;
+    const bool excl_cls = SP && grp.f > 0 && kj == 0;   // CLS key x CLS query is counted in frame-group 0 only
 
     f32x4_t dk[4], dv[4];
 #pragma unroll
@@ -203,7 +265,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
         const f32x4_t D4 = *(const f32x4_t*)(del_s + r0 + 4 * gq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pr = __expf(s[r] + kb - L4[r]);
+          float pr = __expf(s[r] * 0.125f + kb - L4[r]);
+          if (excl_cls && r0 + 4 * gq + r == g.nq) pr = 0.f;
           pv[4 * t + r] = pr;
           dsv[4 * t + r] = pr * (d[r] - D4[r]);
         }
@@ -224,20 +287,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
       }
     }
     if (kj < g.nk) {
-      float* okp = gr.dk + ktok * gr.tok_stride + hoff;
-      float* ovp = gr.dv + ktok * gr.tok_stride + hoff;
-      const bool shared_cls = (MODE == MODE_SPACE) && (kj == 0);
+      if (SP && kj == 0) {
+        // the CLS key / value are shared by the T frame-groups of a clip: raw fp32 accumulation (finish kernel scales)
+        float* a = gr.dcls + ((long)grp.b * g.H + grp.h) * 192;
 #pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        const int d = df * 16 + 4 * gq;
-        if (shared_cls) {
+        for (int df = 0; df < 4; ++df)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            atomicAdd(okp + d + r, dk[df][r]);
-            atomicAdd(ovp + d + r, dv[df][r]);
+            atomicAdd(a + 64 + df * 16 + 4 * gq + r, dk[df][r]);
+            atomicAdd(a + 128 + df * 16 + 4 * gq + r, dv[df][r]);
           }
-        } else {
-          *(f32x4_t*)(okp + d) = dk[df];
+      } else if (SP) {
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+          const long o = ktok * gr.tok_stride + hoff + df * 16 + 4 * gq;
+          store_planes4(gr.gh, gr.gl, o + HD, dk[df] * 0.125f);
+          store_planes4(gr.gh, gr.gl, o + 2 * HD, dv[df]);
+        }
+      } else {
+        float* okp = gr.dk + ktok * gr.tok_stride + hoff;
+        float* ovp = gr.dv + ktok * gr.tok_stride + hoff;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+          const int d = df * 16 + 4 * gq;
+          *(f32x4_t*)(okp + d) = dk[df] * 0.125f;
           *(f32x4_t*)(ovp + d) = dv[df];
         }
       }
@@ -272,7 +345,8 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
 
 template <int MODE>
 int dispatch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hipStream_t s) {
-  const int m = g.nk > g.nq ? g.nk : g.nq;  // one fragment count covers both the key and the query extent
+  const int nq_all = (MODE == MODE_SPACE) ? g.nq + 1 : g.nq;
+  const int m = g.nk > nq_all ? g.nk : nq_all;  // one fragment count covers both the key and the query extent
   if (m <= 32) return launch_bwd<MODE, 2>(g, gr, ngroups, passes, s);
   if (m <= 64) return launch_bwd<MODE, 4>(g, gr, ngroups, passes, s);
   if (m <= 224) return launch_bwd<MODE, 14>(g, gr, ngroups, passes, s);
@@ -282,20 +356,28 @@ int dispatch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, h
 
 }  // namespace
 
-int egv_attn_space_bwd_impl(const float* qkv, const float* d_out, const float* lse, float* delta, int B, int T, int n,
-                            int H, int passes, float* dqkv, hipStream_t s) {
+int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* do_hi, const bf16_t* do_lo,
+                            const float* lse, float* delta, float* dcls, int B, int T, int n, int H, int passes,
+                            bf16_t* dqkv_hi, bf16_t* dqkv_lo, hipStream_t s) {
   AttGeom g;
   const long HD = (long)H * ATT_D;
-  g.q = qkv; g.k = qkv + HD; g.v = qkv + 2 * HD;
+  g.q = g.k = g.v = nullptr;
+  g.ph = qkv_hi;
+  g.pl = (passes == 3) ? qkv_lo : nullptr;
   g.tok_stride = 3 * HD;
   g.B = B; g.T = T; g.n = n; g.H = H; g.S = 1 + T * n;
   g.nq = n; g.nk = n + 1;
   g.mask = nullptr;
   AttGrad gr;
-  gr.dq = dqkv; gr.dk = dqkv + HD; gr.dv = dqkv + 2 * HD;
+  gr.dq = gr.dk = gr.dv = nullptr;
+  gr.gh = dqkv_hi;
+  gr.gl = (passes == 3) ? dqkv_lo : nullptr;
   gr.tok_stride = 3 * HD;
-  gr.d_out = d_out; gr.do_stride = HD;
-  gr.lse = lse; gr.delta = delta;
+  gr.d_out = nullptr;
+  gr.doh = do_hi;
+  gr.dol = (passes == 3) ? do_lo : nullptr;
+  gr.do_stride = HD;
+  gr.lse = lse; gr.delta = delta; gr.dcls = dcls;
   return dispatch_bwd<MODE_SPACE>(g, gr, B * T * H, passes, s);
 }
 
@@ -307,14 +389,16 @@ extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v,
   AttGeom g;
   const long HD = (long)H * ATT_D;
   g.q = q; g.k = k; g.v = v;
+  g.ph = g.pl = nullptr;
   g.tok_stride = HD;
   g.B = B; g.T = 1; g.n = L; g.H = H; g.S = L;
   g.nq = L; g.nk = L;
   g.mask = (const long long*)mask;
   AttGrad gr;
   gr.dq = dq; gr.dk = dk; gr.dv = dv;
+  gr.gh = gr.gl = nullptr;
   gr.tok_stride = HD;
-  gr.d_out = d_out; gr.do_stride = HD;
-  gr.lse = lse; gr.delta = delta_work;
+  gr.d_out = d_out; gr.doh = gr.dol = nullptr; gr.do_stride = HD;
+  gr.lse = lse; gr.delta = delta_work; gr.dcls = nullptr;
   return dispatch_bwd<MODE_TEXT>(g, gr, B * H, passes, (hipStream_t)stream);
 }

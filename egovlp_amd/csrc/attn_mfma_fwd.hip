@@ -15,13 +15,19 @@
 
 namespace {
 
+// MODE_SPACE reads q/k/v from the split-bf16 planes of the fused qkv buffer and additionally carries the clip's CLS
+// query as one more query row (index n, it rides in the padding of the last 16-query tile): its softmax over THIS
+// group's keys is written as an un-normalised partial (o[64], m, l) to cls_ws; egv_attn_cls_combine merges the T
+// partials of a (clip, head).  The CLS key is counted for the CLS query in frame-group 0 only.
+// q is NOT pre-scaled: scores are multiplied by 64^-0.5 after the MFMA (exact for the power of two).
 template <int MODE, int NKF, int PASSES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
                                                        bf16_t* __restrict__ out_lo, long out_stride,
-                                                       float* __restrict__ lse) {
+                                                       float* __restrict__ lse, float* __restrict__ cls_ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKP = NKF * 16;
   constexpr int PLANE = NKP * ATT_ROW_BYTES;
+  constexpr bool SP = (MODE == MODE_SPACE);
   char* k_hi = smem;
   char* v_hi = smem + PLANE;
   char* k_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
@@ -32,9 +38,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long hoff = (long)grp.h * ATT_D;
+  const long HD = (long)g.H * ATT_D;
 
-  att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
-  att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  if (SP) {
+    att_stage_planes(k_hi, k_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + HD + hoff; });
+    att_stage_planes(v_hi, v_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + 2 * HD + hoff; });
+  } else {
+    att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
+    att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  }
   for (int j = threadIdx.x; j < NKP; j += 256) {
     float bias = (j < g.nk) ? 0.f : -1e30f;
     if (MODE == MODE_TEXT && j < g.nk && g.mask[(long)grp.b * g.S + j] == 0) bias = -1e30f;
@@ -43,15 +55,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* 
   __syncthreads();
 
   const int gq = lane >> 4;  // lane group
-  const int ntiles = (g.nq + 15) / 16;
+  const int nq_all = SP ? g.nq + 1 : g.nq;          // + the CLS query row
+  const int ntiles = (nq_all + 15) / 16;
   for (int qt = wave; qt < ntiles; qt += 4) {
     asm volatile("" ::: "memory");  // K/V fragments are loop-invariant: stop LICM from hoisting ~900 VGPRs of them
     const int qi = qt * 16 + (lane & 15);
-    const int qc = min(qi, g.nq - 1);
-    const float* qrow = g.q + grp.q_tok(g, qc) * g.tok_stride + hoff;
+    const bool is_cls = SP && qi >= g.nq;           // rows past n all alias the CLS row; only qi == n is stored
+    const long qtok = is_cls ? grp.tok0 : grp.q_tok(g, min(qi, g.nq - 1));
     bf16x8_t qh[2], ql[2];
-    att_gfrag(qrow, 0, lane, 0.125f, qh[0], ql[0]);  // q *= 64^-0.5 (video_transformer.py:106)
-    att_gfrag(qrow, 1, lane, 0.125f, qh[1], ql[1]);
+    if (SP) {
+      att_gfrag_planes(g.ph, g.pl, qtok * g.tok_stride + hoff, 0, lane, qh[0], ql[0]);
+      att_gfrag_planes(g.ph, g.pl, qtok * g.tok_stride + hoff, 1, lane, qh[1], ql[1]);
+    } else {
+      const float* qrow = g.q + qtok * g.tok_stride + hoff;
+      att_gfrag(qrow, 0, lane, 1.0f, qh[0], ql[0]);
+      att_gfrag(qrow, 1, lane, 1.0f, qh[1], ql[1]);
+    }
 
     f32x4_t s[NKF];
 #pragma unroll
@@ -70,7 +89,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* 
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) {
       const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
-      s[kf] += kb;
+      s[kf] = s[kf] * 0.125f + kb;                  // q *= 64^-0.5 (video_transformer.py:106), applied to the scores
+      if (SP && kf == 0 && is_cls && grp.f > 0 && gq == 0) s[0][0] = -1e30f;   // CLS key x CLS query: group 0 only
       m = fmaxf(m, fmaxf(fmaxf(s[kf][0], s[kf][1]), fmaxf(s[kf][2], s[kf][3])));
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -104,9 +124,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* 
         o[df] = att_mma<PASSES>(vh, vl, ph, pl, o[df]);
       }
     }
-    if (qi < g.nq) {
+    if (SP && qi == g.nq) {
+      // CLS query x this frame's keys: un-normalised partial for egv_attn_cls_combine
+      float* w = cls_ws + (((long)grp.b * g.H + grp.h) * g.T + grp.f) * 68;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) *(f32x4_t*)(w + df * 16 + 4 * gq) = o[df];
+      if (gq == 0) {
+        w[64] = m;
+        w[65] = l;
+      }
+    } else if (qi < g.nq) {
       const float inv = 1.0f / l;
-      const long tok = grp.q_tok(g, qi);
+      const long tok = qtok;
       bf16_t* oh = out_hi + tok * out_stride + hoff;
       bf16_t* ol = out_lo ? out_lo + tok * out_stride + hoff : nullptr;
 #pragma unroll
@@ -128,17 +157,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* 
 
 template <int MODE, int NKF>
 int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol, long ostride, float* lse,
-               hipStream_t s) {
+               float* cls_ws, hipStream_t s) {
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NKF * 16 * ATT_ROW_BYTES + NKF * 16 * sizeof(float);
   if (passes == 3) {
     auto kern = attn_fwd_kernel<MODE, NKF, 3>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, ol, ostride, lse);
+    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, ol, ostride, lse, cls_ws);
   } else {
     auto kern = attn_fwd_kernel<MODE, NKF, 1>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, nullptr, ostride, lse);
+    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, nullptr, ostride, lse, cls_ws);
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -150,26 +179,26 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
 // tiny test configs), 4, 14 (ViT-B/16: 197 keys), 18 (ViT-L/14: 257 keys)
 template <int MODE>
 static int dispatch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol, long ostride, float* lse,
-                        hipStream_t s) {
-  if (g.nk <= 32) return launch_fwd<MODE, 2>(g, ngroups, passes, oh, ol, ostride, lse, s);
-  if (g.nk <= 64) return launch_fwd<MODE, 4>(g, ngroups, passes, oh, ol, ostride, lse, s);
-  if (g.nk <= 224) return launch_fwd<MODE, 14>(g, ngroups, passes, oh, ol, ostride, lse, s);
-  if (g.nk <= 288) return launch_fwd<MODE, 18>(g, ngroups, passes, oh, ol, ostride, lse, s);
+                        float* cls_ws, hipStream_t s) {
+  if (g.nk <= 32) return launch_fwd<MODE, 2>(g, ngroups, passes, oh, ol, ostride, lse, cls_ws, s);
+  if (g.nk <= 64) return launch_fwd<MODE, 4>(g, ngroups, passes, oh, ol, ostride, lse, cls_ws, s);
+  if (g.nk <= 224) return launch_fwd<MODE, 14>(g, ngroups, passes, oh, ol, ostride, lse, cls_ws, s);
+  if (g.nk <= 288) return launch_fwd<MODE, 18>(g, ngroups, passes, oh, ol, ostride, lse, cls_ws, s);
   return EGV_ERR_ARG;
 }
 
-int egv_attn_space_fwd_impl(const float* qkv, int B, int T, int n, int H, int passes, bf16_t* out_hi, bf16_t* out_lo,
-                            float* lse, hipStream_t s) {
+int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, int T, int n, int H, int passes,
+                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, hipStream_t s) {
   AttGeom g;
   const long HD = (long)H * ATT_D;
-  g.q = qkv;
-  g.k = qkv + HD;
-  g.v = qkv + 2 * HD;
+  g.q = g.k = g.v = nullptr;
+  g.ph = qkv_hi;
+  g.pl = (passes == 3) ? qkv_lo : nullptr;
   g.tok_stride = 3 * HD;
   g.B = B; g.T = T; g.n = n; g.H = H; g.S = 1 + T * n;
   g.nq = n; g.nk = n + 1;
   g.mask = nullptr;
-  return dispatch_fwd<MODE_SPACE>(g, B * T * H, passes, out_hi, out_lo, HD, lse, s);
+  return dispatch_fwd<MODE_SPACE>(g, B * T * H, passes, out_hi, out_lo, HD, lse, cls_ws, s);
 }
 
 extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v, const int64_t* mask, int32_t B,
@@ -181,10 +210,11 @@ extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v,
   AttGeom g;
   const long HD = (long)H * ATT_D;
   g.q = q; g.k = k; g.v = v;
+  g.ph = g.pl = nullptr;
   g.tok_stride = HD;
   g.B = B; g.T = 1; g.n = L; g.H = H; g.S = L;
   g.nq = L; g.nk = L;
   g.mask = (const long long*)mask;
   if (!mask) return EGV_ERR_ARG;
-  return dispatch_fwd<MODE_TEXT>(g, B * H, passes, out_hi, out_lo, HD, lse, (hipStream_t)stream);
+  return dispatch_fwd<MODE_TEXT>(g, B * H, passes, out_hi, out_lo, HD, lse, nullptr, (hipStream_t)stream);
 }

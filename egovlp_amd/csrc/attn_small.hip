@@ -1,10 +1,15 @@
-// The two "thin" attention shapes of divided space-time attention, on the vector ALU in exact fp32:
+// The "thin" attention shapes of divided space-time attention, on the vector ALU in fp32:
 //   * time attention (model/video_transformer.py:114-124, '(b n) f d'): per (b, location, head) only
-//     T queries x (CLS + T) keys (4 x 5 at T=4, 16 x 17 at T=16) -- far below an MFMA tile; the kernel is
-//     HBM-bound (it streams the whole qkv buffer once), one wave64 per group with lane = head channel d.
-//   * the CLS query row (:109-112): 1 query x all S keys per (b, head): a GEMV-shaped, HBM-bound pass
-//     over all K and V rows, 16 lanes per key (float4 each) so every row is one coalesced 256-B read.
-// Both read q/k/v straight out of the fused qkv buffer [B,S,3,H,64] and write split-bf16 planes.
+//     T queries x (CLS + T) keys (4 x 5 at T=4, 16 x 17 at T=16) -- far below an MFMA tile; HBM-bound (it streams the
+//     qkv planes once).  One wave owns one (b, location) and HPW heads: with HPW = 4 a lane holds 4 channels of one head,
+//     so every load is 8 B per lane / 512 B per wave and one 4-step shuffle tree reduces four heads' dot products at once
+//     (HPW = 1, lane = channel, is kept for head counts that are not a multiple of 4).
+//   * the CLS query row (:109-112, 1 query x all S keys per (b, head)) no longer has kernels of its own: each group of
+//     the space (MFMA) / time kernel carries the clip's CLS query as one more query against ITS keys -- forward as an
+//     un-normalised softmax partial merged by egv_attn_cls_combine, backward with the global log-sum-exp and delta, so
+//     every dK / dV row leaves the kernel complete (patch queries + CLS query) and is written ONCE, as bf16 planes.
+//     Only the CLS token's own gradients (shared by all groups of a clip) go through fp32 atomics + a finish kernel.
+// All operands and results are split-bf16 planes of the fused [B, S, 3, H, 64] buffer (lo plane optional).
 #include "common.h"
 #include "egovlp_hip.h"
 
@@ -12,335 +17,446 @@ namespace {
 
 constexpr int D = 64;
 
-__device__ __forceinline__ float sum16(float v) {  // reduce over the 16 lanes of a key group
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+template <int LPH>
+__device__ __forceinline__ float redh(float v) {   // sum over the LPH lanes that share a head
+#pragma unroll
+  for (int o = LPH / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
+template <int CPL>
+__device__ __forceinline__ void ldp(const bf16_t* __restrict__ ph, const bf16_t* __restrict__ pl, long off, float (&x)[CPL]) {
+  if (CPL == 4) {
+    const u32x2_t a = *(const u32x2_t*)(ph + off);
+    x[0] = __uint_as_float(a[0] << 16);
+    x[1] = __uint_as_float(a[0] & 0xffff0000u);
+    x[2] = __uint_as_float(a[1] << 16);
+    x[3] = __uint_as_float(a[1] & 0xffff0000u);
+    if (pl) {
+      const u32x2_t b = *(const u32x2_t*)(pl + off);
+      x[0] += __uint_as_float(b[0] << 16);
+      x[1] += __uint_as_float(b[0] & 0xffff0000u);
+      x[2] += __uint_as_float(b[1] << 16);
+      x[3] += __uint_as_float(b[1] & 0xffff0000u);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      x[c] = bf16_to_f32(ph[off + c]);
+      if (pl) x[c] += bf16_to_f32(pl[off + c]);
+    }
+  }
+}
+
+template <int CPL>
+__device__ __forceinline__ void stp(bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long off, const float (&x)[CPL]) {
+  bf16_t h[CPL], l[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) split_bf16(x[c], h[c], l[c]);
+  if (CPL == 4) {
+    *(u32x2_t*)(ph + off) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+    if (pl) *(u32x2_t*)(pl + off) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      ph[off + c] = h[c];
+      if (pl) pl[off + c] = l[c];
+    }
+  }
+}
+
+template <int CPL>
+__device__ __forceinline__ float dotc(const float (&a)[CPL], const float (&b)[CPL]) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) s += a[c] * b[c];
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------- time fwd
-template <int TMAX>
-__global__ __launch_bounds__(256) void attn_time_fwd_kernel(const float* __restrict__ qkv, int B, int T, int n, int H,
-                                                            bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
-                                                            float* __restrict__ lse) {
+template <int TMAX, int HPW>
+__global__ __launch_bounds__(256) void attn_time_fwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
+                                                            int B, int T, int n, int H, bf16_t* __restrict__ out_hi,
+                                                            bf16_t* __restrict__ out_lo, float* __restrict__ lse,
+                                                            float* __restrict__ cls_ws) {
+  constexpr int LPH = 64 / HPW, CPL = HPW;
   const int lane = threadIdx.x & 63;
+  const int HQ = H / HPW;
   const long gid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long ngroups = (long)B * n * H;
-  if (gid >= ngroups) return;
-  const int h = (int)(gid % H);
-  const long r = gid / H;
+  if (gid >= (long)B * n * HQ) return;
+  const int hq = (int)(gid % HQ);
+  const long r = gid / HQ;
   const int i = (int)(r % n);
   const int b = (int)(r / n);
+  const int head = hq * HPW + lane / LPH;
+  const int ch = (lane % LPH) * CPL;
   const long S = 1 + (long)T * n;
   const long HD = (long)H * D;
   const long ts = 3 * HD;
-  const float* base = qkv + (long)b * S * ts + (long)h * D + lane;
-  const float kc = base[HD], vc = base[2 * HD];
-  float q[TMAX], k[TMAX], v[TMAX];
+  const long base = (long)b * S * ts + (long)head * D + ch;   // token 0, q part
+  float qc[CPL], kc[CPL], vc[CPL];
+  ldp<CPL>(qh, ql, base, qc);
+  ldp<CPL>(qh, ql, base + HD, kc);
+  ldp<CPL>(qh, ql, base + 2 * HD, vc);
+  float q[TMAX][CPL], k[TMAX][CPL], v[TMAX][CPL];
 #pragma unroll
   for (int f = 0; f < TMAX; ++f) {
-    q[f] = k[f] = v[f] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) q[f][c] = k[f][c] = v[f][c] = 0.f;
     if (f < T) {
-      const float* p = base + (1 + (long)f * n + i) * ts;
-      q[f] = p[0] * 0.125f;
-      k[f] = p[HD];
-      v[f] = p[2 * HD];
+      const long p = base + (1 + (long)f * n + i) * ts;
+      ldp<CPL>(qh, ql, p, q[f]);
+      ldp<CPL>(qh, ql, p + HD, k[f]);
+      ldp<CPL>(qh, ql, p + 2 * HD, v[f]);
     }
   }
 #pragma unroll
   for (int f = 0; f < TMAX; ++f) {
     if (f < T) {
       float s[TMAX + 1];
-      s[0] = wave_sum(q[f] * kc);
+      s[0] = redh<LPH>(dotc<CPL>(q[f], kc)) * 0.125f;
       float m = s[0];
 #pragma unroll
       for (int j = 0; j < TMAX; ++j) {
         s[j + 1] = -3e38f;
         if (j < T) {
-          s[j + 1] = wave_sum(q[f] * k[j]);
+          s[j + 1] = redh<LPH>(dotc<CPL>(q[f], k[j])) * 0.125f;
           m = fmaxf(m, s[j + 1]);
         }
       }
-      float p0 = __expf(s[0] - m);
+      const float p0 = __expf(s[0] - m);
       float l = p0;
-      float o = p0 * vc;
+      float o[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) o[c] = p0 * vc[c];
 #pragma unroll
       for (int j = 0; j < TMAX; ++j) {
         if (j < T) {
           const float pj = __expf(s[j + 1] - m);
           l += pj;
-          o += pj * v[j];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) o[c] += pj * v[j][c];
         }
       }
-      o /= l;
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) o[c] *= inv;
       const long tok = (long)b * S + 1 + (long)f * n + i;
-      bf16_t hh, ll;
-      split_bf16(o, hh, ll);
-      out_hi[tok * HD + (long)h * D + lane] = hh;
-      if (out_lo) out_lo[tok * HD + (long)h * D + lane] = ll;
-      if (lane == 0 && lse) lse[((long)b * H + h) * S + 1 + (long)f * n + i] = m + __logf(l);
+      stp<CPL>(out_hi, out_lo, tok * HD + (long)head * D + ch, o);
+      if (lane % LPH == 0 && lse) lse[((long)b * H + head) * S + 1 + (long)f * n + i] = m + __logf(l);
+    }
+  }
+  // the clip's CLS query against this location's T keys (+ the CLS key, counted in location-group 0 only)
+  {
+    float s[TMAX + 1];
+    s[0] = (i == 0) ? redh<LPH>(dotc<CPL>(qc, kc)) * 0.125f : -1e30f;
+    float m = s[0];
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+      s[j + 1] = -3e38f;
+      if (j < T) {
+        s[j + 1] = redh<LPH>(dotc<CPL>(qc, k[j])) * 0.125f;
+        m = fmaxf(m, s[j + 1]);
+      }
+    }
+    const float p0 = (i == 0) ? __expf(s[0] - m) : 0.f;
+    float l = p0;
+    float o[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) o[c] = p0 * vc[c];
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+      if (j < T) {
+        const float pj = __expf(s[j + 1] - m);
+        l += pj;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) o[c] += pj * v[j][c];
+      }
+    }
+    float* w = cls_ws + (((long)b * H + head) * n + i) * 68;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) w[ch + c] = o[c];
+    if (lane % LPH == 0) {
+      w[64] = m;
+      w[65] = l;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------- time bwd
-// one workgroup = (b, h, 16 consecutive locations); each wave walks 4 locations and keeps the CLS-key
-// gradient in registers, so the CLS rows receive one atomicAdd per workgroup and channel.
-template <int TMAX>
-__global__ __launch_bounds__(256) void attn_time_bwd_kernel(const float* __restrict__ qkv,
-                                                            const float* __restrict__ d_out,
-                                                            const float* __restrict__ lse, int B, int T, int n, int H,
-                                                            float* __restrict__ dqkv) {
-  __shared__ float red[2][4][D];
+// one workgroup = (b, head group, 16 consecutive locations); each wave walks 4 locations and keeps the CLS token's raw
+// dq / dk / dv partials in registers: one LDS reduction + one atomicAdd per channel per workgroup.
+template <int TMAX, int HPW>
+__global__ __launch_bounds__(256) void attn_time_bwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
+                                                            const bf16_t* __restrict__ doh,
+                                                            const bf16_t* __restrict__ dol,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, int B, int T, int n, int H,
+                                                            bf16_t* __restrict__ gh, bf16_t* __restrict__ gl,
+                                                            float* __restrict__ dcls) {
+  constexpr int LPH = 64 / HPW, CPL = HPW;
+  __shared__ float red[3][4][64 * CPL];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int HQ = H / HPW;
   const int chunks = (n + 15) / 16;
   const int ic = blockIdx.x % chunks;
   const int bh = blockIdx.x / chunks;
-  const int h = bh % H, b = bh / H;
+  const int hq = bh % HQ, b = bh / HQ;
+  const int head = hq * HPW + lane / LPH;
+  const int ch = (lane % LPH) * CPL;
   const long S = 1 + (long)T * n;
   const long HD = (long)H * D;
   const long ts = 3 * HD;
-  const float* base = qkv + (long)b * S * ts + (long)h * D + lane;
-  float* dbase = dqkv + (long)b * S * ts + (long)h * D + lane;
-  const float kc = base[HD], vc = base[2 * HD];
-  float dkc = 0.f, dvc = 0.f;
+  const long base = (long)b * S * ts + (long)head * D + ch;
+  const long obase = (long)b * S * HD + (long)head * D + ch;
+  const long lbase = ((long)b * H + head) * S;
+  float qc[CPL], kc[CPL], vc[CPL], goc[CPL];
+  ldp<CPL>(qh, ql, base, qc);
+  ldp<CPL>(qh, ql, base + HD, kc);
+  ldp<CPL>(qh, ql, base + 2 * HD, vc);
+  ldp<CPL>(doh, dol, obase, goc);
+  const float Lc = lse[lbase], dc = delta[lbase];
+  float dqc[CPL], dkc[CPL], dvc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) dqc[c] = dkc[c] = dvc[c] = 0.f;
+
   for (int ii = 0; ii < 4; ++ii) {
     const int i = ic * 16 + wave * 4 + ii;
     if (i >= n) break;
-    float q[TMAX], k[TMAX], v[TMAX], go[TMAX], dk[TMAX], dv[TMAX];
+    float q[TMAX][CPL], k[TMAX][CPL], v[TMAX][CPL], go[TMAX][CPL], dk[TMAX][CPL], dv[TMAX][CPL];
 #pragma unroll
     for (int f = 0; f < TMAX; ++f) {
-      q[f] = k[f] = v[f] = go[f] = dk[f] = dv[f] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) q[f][c] = k[f][c] = v[f][c] = go[f][c] = dk[f][c] = dv[f][c] = 0.f;
       if (f < T) {
         const long tok = 1 + (long)f * n + i;
-        const float* p = base + tok * ts;
-        q[f] = p[0] * 0.125f;
-        k[f] = p[HD];
-        v[f] = p[2 * HD];
-        go[f] = d_out[((long)b * S + tok) * HD + (long)h * D + lane];
+        ldp<CPL>(qh, ql, base + tok * ts, q[f]);
+        ldp<CPL>(qh, ql, base + tok * ts + HD, k[f]);
+        ldp<CPL>(qh, ql, base + tok * ts + 2 * HD, v[f]);
+        ldp<CPL>(doh, dol, obase + tok * HD, go[f]);
       }
     }
 #pragma unroll
     for (int f = 0; f < TMAX; ++f) {
       if (f < T) {
-        const float L = lse[((long)b * H + h) * S + 1 + (long)f * n + i];
+        const float L = lse[lbase + 1 + (long)f * n + i];
         float p[TMAX + 1], dp[TMAX + 1];
-        p[0] = __expf(wave_sum(q[f] * kc) - L);
-        dp[0] = wave_sum(go[f] * vc);
-        float delta = p[0] * dp[0];
+        p[0] = __expf(redh<LPH>(dotc<CPL>(q[f], kc)) * 0.125f - L);
+        dp[0] = redh<LPH>(dotc<CPL>(go[f], vc));
+        float dl = p[0] * dp[0];
 #pragma unroll
         for (int j = 0; j < TMAX; ++j) {
           p[j + 1] = dp[j + 1] = 0.f;
           if (j < T) {
-            p[j + 1] = __expf(wave_sum(q[f] * k[j]) - L);
-            dp[j + 1] = wave_sum(go[f] * v[j]);
-            delta += p[j + 1] * dp[j + 1];
+            p[j + 1] = __expf(redh<LPH>(dotc<CPL>(q[f], k[j])) * 0.125f - L);
+            dp[j + 1] = redh<LPH>(dotc<CPL>(go[f], v[j]));
+            dl += p[j + 1] * dp[j + 1];
           }
         }
-        const float ds0 = p[0] * (dp[0] - delta);
-        float dq = ds0 * kc;
-        dkc += ds0 * q[f];
-        dvc += p[0] * go[f];
+        const float ds0 = p[0] * (dp[0] - dl);
+        float dq[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          dq[c] = ds0 * kc[c];
+          dkc[c] += ds0 * q[f][c];
+          dvc[c] += p[0] * go[f][c];
+        }
 #pragma unroll
         for (int j = 0; j < TMAX; ++j) {
           if (j < T) {
-            const float ds = p[j + 1] * (dp[j + 1] - delta);
-            dq += ds * k[j];
-            dk[j] += ds * q[f];
-            dv[j] += p[j + 1] * go[f];
+            const float ds = p[j + 1] * (dp[j + 1] - dl);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              dq[c] += ds * k[j][c];
+              dk[j][c] += ds * q[f][c];
+              dv[j][c] += p[j + 1] * go[f][c];
+            }
           }
         }
-        dbase[(1 + (long)f * n + i) * ts] = dq * 0.125f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dq[c] *= 0.125f;
+        stp<CPL>(gh, gl, base + (1 + (long)f * n + i) * ts, dq);
+      }
+    }
+    // the clip's CLS query against this location's keys (global log-sum-exp Lc and delta dc)
+    if (i == 0) {
+      const float p0 = __expf(redh<LPH>(dotc<CPL>(qc, kc)) * 0.125f - Lc);
+      const float ds0 = p0 * (redh<LPH>(dotc<CPL>(goc, vc)) - dc);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        dqc[c] += ds0 * kc[c];
+        dkc[c] += ds0 * qc[c];
+        dvc[c] += p0 * goc[c];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+      if (j < T) {
+        const float pj = __expf(redh<LPH>(dotc<CPL>(qc, k[j])) * 0.125f - Lc);
+        const float ds = pj * (redh<LPH>(dotc<CPL>(goc, v[j])) - dc);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          dqc[c] += ds * k[j][c];
+          dk[j][c] += ds * qc[c];
+          dv[j][c] += pj * goc[c];
+        }
       }
     }
 #pragma unroll
     for (int f = 0; f < TMAX; ++f) {
       if (f < T) {
-        float* p = dbase + (1 + (long)f * n + i) * ts;
-        p[HD] = dk[f];
-        p[2 * HD] = dv[f];
+        const long p = base + (1 + (long)f * n + i) * ts;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dk[f][c] *= 0.125f;
+        stp<CPL>(gh, gl, p + HD, dk[f]);
+        stp<CPL>(gh, gl, p + 2 * HD, dv[f]);
       }
     }
   }
-  red[0][wave][lane] = dkc;
-  red[1][wave][lane] = dvc;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    red[0][wave][lane * CPL + c] = dqc[c];
+    red[1][wave][lane * CPL + c] = dkc[c];
+    red[2][wave][lane * CPL + c] = dvc[c];
+  }
   __syncthreads();
   if (wave == 0) {
-    atomicAdd(dbase + HD, red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
-    atomicAdd(dbase + 2 * HD, red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------- CLS fwd
-// one workgroup per (b, h): 16 key-groups (4 per wave) x 16 lanes (float4 of the 64-d row each)
-__global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const float* __restrict__ qkv, int B, int S, int H,
-                                                           bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
-                                                           float* __restrict__ lse) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* sc = (float*)smem_raw;        // [S] scores -> probabilities
-  float* red = sc + ((S + 3) & ~3);    // [16][64] partial outputs, then scalars
-  const int tid = threadIdx.x;
-  const int kg = tid >> 4;             // key group 0..15
-  const int l16 = tid & 15;
-  const int h = blockIdx.x % H, b = blockIdx.x / H;
-  const long HD = (long)H * D;
-  const long ts = 3 * HD;
-  const float* base = qkv + (long)b * S * ts + (long)h * D + l16 * 4;
-  f32x4_t q = *(const f32x4_t*)base;
-  q *= 0.125f;
-  float mloc = -3e38f;
-  for (int j = kg; j < S; j += 16) {
-    const f32x4_t kv = *(const f32x4_t*)(base + (long)j * ts + HD);
-    const float s = sum16(q[0] * kv[0] + q[1] * kv[1] + q[2] * kv[2] + q[3] * kv[3]);
-    if (l16 == 0) sc[j] = s;
-    mloc = fmaxf(mloc, s);
-  }
-  // block max
-  mloc = wave_max(mloc);
-  __shared__ float wred[8];
-  if ((tid & 63) == 0) wred[tid >> 6] = mloc;
-  __syncthreads();
-  const float m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-  float lloc = 0.f;
-  for (int j = tid; j < S; j += 256) {
-    const float p = __expf(sc[j] - m);
-    sc[j] = p;
-    lloc += p;
-  }
-  lloc = wave_sum(lloc);
-  if ((tid & 63) == 0) wred[4 + (tid >> 6)] = lloc;
-  __syncthreads();
-  const float l = wred[4] + wred[5] + wred[6] + wred[7];
-  f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-  for (int j = kg; j < S; j += 16) {
-    const f32x4_t vv = *(const f32x4_t*)(base + (long)j * ts + 2 * HD);
-    o += sc[j] * vv;
-  }
-  *(f32x4_t*)(red + kg * 64 + l16 * 4) = o;
-  __syncthreads();
-  if (tid < 64) {
-    float acc = 0.f;
+    float* a = dcls + ((long)b * H + head) * 192 + ch;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc += red[g * 64 + tid];
-    acc /= l;
-    bf16_t hh, ll;
-    split_bf16(acc, hh, ll);
-    const long o_off = (long)b * S * HD + (long)h * D + tid;  // token 0
-    out_hi[o_off] = hh;
-    if (out_lo) out_lo[o_off] = ll;
-    if (tid == 0 && lse) lse[((long)b * H + h) * S] = m + __logf(l);
-  }
-}
-
-// ------------------------------------------------------------------------------------------- CLS bwd
-// dq_cls is stored; dk_j / dv_j are ADDED (plain read-modify-write: every (b,h,j) element has exactly one
-// owner here and the patch kernels that wrote / atomically accumulated the same rows ran earlier on the
-// same stream).
-__global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const float* __restrict__ qkv,
-                                                           const float* __restrict__ d_out,
-                                                           const float* __restrict__ lse, int B, int S, int H,
-                                                           float* __restrict__ dqkv) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* pj = (float*)smem_raw;            // [S]
-  float* dpj = pj + ((S + 3) & ~3);        // [S]
-  float* red = dpj + ((S + 3) & ~3);       // [16][64]
-  __shared__ float wred[4];
-  const int tid = threadIdx.x;
-  const int kg = tid >> 4, l16 = tid & 15;
-  const int h = blockIdx.x % H, b = blockIdx.x / H;
-  const long HD = (long)H * D;
-  const long ts = 3 * HD;
-  const float* base = qkv + (long)b * S * ts + (long)h * D + l16 * 4;
-  float* dbase = dqkv + (long)b * S * ts + (long)h * D + l16 * 4;
-  f32x4_t q = *(const f32x4_t*)base;
-  q *= 0.125f;
-  const f32x4_t go = *(const f32x4_t*)(d_out + (long)b * S * HD + (long)h * D + l16 * 4);
-  const float L = lse[((long)b * H + h) * S];
-  float dloc = 0.f;
-  for (int j = kg; j < S; j += 16) {
-    const f32x4_t kv = *(const f32x4_t*)(base + (long)j * ts + HD);
-    const f32x4_t vv = *(const f32x4_t*)(base + (long)j * ts + 2 * HD);
-    const float s = sum16(q[0] * kv[0] + q[1] * kv[1] + q[2] * kv[2] + q[3] * kv[3]);
-    const float dp = sum16(go[0] * vv[0] + go[1] * vv[1] + go[2] * vv[2] + go[3] * vv[3]);
-    const float p = __expf(s - L);
-    if (l16 == 0) {
-      pj[j] = p;
-      dpj[j] = dp;
-      dloc += p * dp;
+    for (int c = 0; c < CPL; ++c) {
+      const int x = lane * CPL + c;
+      atomicAdd(a + c, red[0][0][x] + red[0][1][x] + red[0][2][x] + red[0][3][x]);
+      atomicAdd(a + 64 + c, red[1][0][x] + red[1][1][x] + red[1][2][x] + red[1][3][x]);
+      atomicAdd(a + 128 + c, red[2][0][x] + red[2][1][x] + red[2][2][x] + red[2][3][x]);
     }
   }
-  dloc = wave_sum(dloc);
-  if ((tid & 63) == 0) wred[tid >> 6] = dloc;
-  __syncthreads();
-  const float delta = wred[0] + wred[1] + wred[2] + wred[3];
-  f32x4_t dq = {0.f, 0.f, 0.f, 0.f};
-  for (int j = kg; j < S; j += 16) {
-    const float p = pj[j];
-    const float ds = p * (dpj[j] - delta);
-    const f32x4_t kv = *(const f32x4_t*)(base + (long)j * ts + HD);
-    dq += ds * kv;
-    float* dk = dbase + (long)j * ts + HD;
-    float* dv = dbase + (long)j * ts + 2 * HD;
-    *(f32x4_t*)dk = *(const f32x4_t*)dk + ds * q;
-    *(f32x4_t*)dv = *(const f32x4_t*)dv + p * go;
+}
+
+// ------------------------------------------------------------------------------------------- CLS row helpers
+// forward: merge the G softmax partials (o[64], m, l) of one (clip, head) -> output planes of token 0 + its lse.
+__global__ __launch_bounds__(64) void attn_cls_combine_kernel(const float* __restrict__ ws, int G, int S, int H,
+                                                              bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                              float* __restrict__ lse) {
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x % H, b = blockIdx.x / H;
+  const float* w = ws + (long)blockIdx.x * G * 68;
+  float m = -3e38f;
+  for (int g = 0; g < G; ++g) m = fmaxf(m, w[(long)g * 68 + 64]);
+  float l = 0.f, o = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float e = __expf(w[(long)g * 68 + 64] - m);
+    l += w[(long)g * 68 + 65] * e;
+    o += w[(long)g * 68 + lane] * e;
   }
-  *(f32x4_t*)(red + kg * 64 + l16 * 4) = dq;
-  __syncthreads();
-  if (tid < 64) {
-    float acc = 0.f;
+  o /= l;
+  bf16_t hh, ll;
+  split_bf16(o, hh, ll);
+  const long off = (long)b * S * H * D + (long)h * D + lane;
+  out_hi[off] = hh;
+  if (out_lo) out_lo[off] = ll;
+  if (lane == 0) lse[((long)b * H + h) * S] = m + __logf(l);
+}
+
+// backward prologue: delta of the CLS query row = sum_d dO[d] * O[d] (== sum_j P_j dP_j over ALL keys)
+__global__ __launch_bounds__(64) void attn_cls_delta_kernel(const bf16_t* __restrict__ oh, const bf16_t* __restrict__ ol,
+                                                            const bf16_t* __restrict__ doh,
+                                                            const bf16_t* __restrict__ dol, int S, int H,
+                                                            float* __restrict__ delta) {
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x % H, b = blockIdx.x / H;
+  const long off = (long)b * S * H * D + (long)h * D + lane;
+  float o = bf16_to_f32(oh[off]), g = bf16_to_f32(doh[off]);
+  if (ol) o += bf16_to_f32(ol[off]);
+  if (dol) g += bf16_to_f32(dol[off]);
+  const float d = wave_sum(o * g);
+  if (lane == 0) delta[((long)b * H + h) * S] = d;
+}
+
+// backward epilogue: the CLS token's accumulated raw dq / dk / dv -> gradient planes of token 0 (q and k carry 64^-0.5)
+__global__ __launch_bounds__(64) void attn_cls_finish_kernel(const float* __restrict__ dcls, int S, int H,
+                                                             bf16_t* __restrict__ gh, bf16_t* __restrict__ gl) {
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x % H, b = blockIdx.x / H;
+  const float* a = dcls + (long)blockIdx.x * 192;
+  const long HD = (long)H * D;
+  const long off = (long)b * S * 3 * HD + (long)h * D + lane;
+  const float v[3] = {a[lane] * 0.125f, a[64 + lane] * 0.125f, a[128 + lane]};
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc += red[g * 64 + tid];
-    dqkv[(long)b * S * ts + (long)h * D + tid] = acc * 0.125f;
+  for (int part = 0; part < 3; ++part) {
+    bf16_t hh, ll;
+    split_bf16(v[part], hh, ll);
+    gh[off + part * HD] = hh;
+    if (gl) gl[off + part * HD] = ll;
   }
+}
+
+template <int TMAX>
+int launch_time_fwd(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
+                    float* ws, hipStream_t s) {
+  if (H % 4 == 0 && TMAX <= 4) {   // 4 heads per wave while the per-lane q/k/v arrays still fit the register file
+    const long ngroups = (long)B * n * (H / 4);
+    EGV_LAUNCH((attn_time_fwd_kernel<TMAX, 4>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
+               oh, ol, lse, ws);
+  } else {
+    const long ngroups = (long)B * n * H;
+    EGV_LAUNCH((attn_time_fwd_kernel<TMAX, 1>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
+               oh, ol, lse, ws);
+  }
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+template <int TMAX>
+int launch_time_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
+                    const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s) {
+  const int chunks = (n + 15) / 16;
+  if (H % 4 == 0 && TMAX <= 4) {
+    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
+               lse, delta, B, T, n, H, gh, gl, dcls);
+  } else {
+    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 1>), dim3((unsigned)(B * H * chunks)), dim3(256), 0, s, qh, ql, doh, dol, lse,
+               delta, B, T, n, H, gh, gl, dcls);
+  }
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
 }
 
 }  // namespace
 
-int egv_attn_time_fwd_impl(const float* qkv, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
+int egv_attn_time_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol,
+                           float* lse, float* ws, hipStream_t s) {
+  if (T <= 4) return launch_time_fwd<4>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
+  if (T <= 8) return launch_time_fwd<8>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
+  if (T <= 16) return launch_time_fwd<16>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
+  return EGV_ERR_ARG;
+}
+
+int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
+                           const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls,
                            hipStream_t s) {
-  const long ngroups = (long)B * n * H;
-  const dim3 grid((unsigned)((ngroups + 3) / 4)), block(256);
-  if (T <= 4)
-    EGV_LAUNCH(attn_time_fwd_kernel<4>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
-  else if (T <= 8)
-    EGV_LAUNCH(attn_time_fwd_kernel<8>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
-  else if (T <= 16)
-    EGV_LAUNCH(attn_time_fwd_kernel<16>, grid, block, 0, s, qkv, B, T, n, H, oh, ol, lse);
-  else
-    return EGV_ERR_ARG;
+  if (T <= 4) return launch_time_bwd<4>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
+  if (T <= 8) return launch_time_bwd<8>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
+  if (T <= 16) return launch_time_bwd<16>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
+  return EGV_ERR_ARG;
+}
+
+int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse,
+                              hipStream_t s) {
+  EGV_LAUNCH(attn_cls_combine_kernel, dim3(B * H), dim3(64), 0, s, ws, G, S, H, oh, ol, lse);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
 
-int egv_attn_time_bwd_impl(const float* qkv, const float* d_out, const float* lse, int B, int T, int n, int H,
-                           float* dqkv, hipStream_t s) {
-  const dim3 grid((unsigned)(B * H * ((n + 15) / 16))), block(256);
-  if (T <= 4)
-    EGV_LAUNCH(attn_time_bwd_kernel<4>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
-  else if (T <= 8)
-    EGV_LAUNCH(attn_time_bwd_kernel<8>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
-  else if (T <= 16)
-    EGV_LAUNCH(attn_time_bwd_kernel<16>, grid, block, 0, s, qkv, d_out, lse, B, T, n, H, dqkv);
-  else
-    return EGV_ERR_ARG;
+int egv_attn_cls_delta_impl(const bf16_t* oh, const bf16_t* ol, const bf16_t* doh, const bf16_t* dol, int B, int S, int H,
+                            float* delta, hipStream_t s) {
+  EGV_LAUNCH(attn_cls_delta_kernel, dim3(B * H), dim3(64), 0, s, oh, ol, doh, dol, S, H, delta);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
 
-int egv_attn_cls_fwd_impl(const float* qkv, int B, int S, int H, bf16_t* oh, bf16_t* ol, float* lse, hipStream_t s) {
-  const size_t lds = (size_t)(((S + 3) & ~3) + 16 * 64) * sizeof(float);
-  EGV_LAUNCH(attn_cls_fwd_kernel, dim3(B * H), dim3(256), lds, s, qkv, B, S, H, oh, ol, lse);
-  EGV_CHECK_LAUNCH();
-  return EGV_OK;
-}
-
-int egv_attn_cls_bwd_impl(const float* qkv, const float* d_out, const float* lse, int B, int S, int H, float* dqkv,
-                          hipStream_t s) {
-  const size_t lds = (size_t)(2 * ((S + 3) & ~3) + 16 * 64) * sizeof(float);
-  EGV_LAUNCH(attn_cls_bwd_kernel, dim3(B * H), dim3(256), lds, s, qkv, d_out, lse, B, S, H, dqkv);
+int egv_attn_cls_finish_impl(const float* dcls, int B, int S, int H, bf16_t* gh, bf16_t* gl, hipStream_t s) {
+  EGV_LAUNCH(attn_cls_finish_kernel, dim3(B * H), dim3(64), 0, s, dcls, S, H, gh, gl);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

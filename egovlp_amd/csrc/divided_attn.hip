@@ -1,56 +1,75 @@
-// C-ABI entry points of divided space-time attention (VarAttention core, model/video_transformer.py:104-133):
-// patch queries by the space (MFMA) or time (VALU) kernel + the CLS query row by the CLS kernel.
+// C-ABI entry points of divided space-time attention (VarAttention core, model/video_transformer.py:104-133).
+// Patch queries run in the space (MFMA) or time (VALU) kernel; the clip's CLS query row (:109-112) rides along in every
+// group of those kernels (see attn_small.hip) and is finished by tiny combine / delta / finish kernels.
 #include "common.h"
 #include "egovlp_hip.h"
 
-int egv_attn_space_fwd_impl(const float* qkv, int B, int T, int n, int H, int passes, bf16_t* out_hi, bf16_t* out_lo,
-                            float* lse, hipStream_t s);
-int egv_attn_space_bwd_impl(const float* qkv, const float* d_out, const float* lse, float* delta, int B, int T, int n,
-                            int H, int passes, float* dqkv, hipStream_t s);
-int egv_attn_time_fwd_impl(const float* qkv, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
+int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, int T, int n, int H, int passes,
+                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, hipStream_t s);
+int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* do_hi, const bf16_t* do_lo,
+                            const float* lse, float* delta, float* dcls, int B, int T, int n, int H, int passes,
+                            bf16_t* dqkv_hi, bf16_t* dqkv_lo, hipStream_t s);
+int egv_attn_time_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol,
+                           float* lse, float* ws, hipStream_t s);
+int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
+                           const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls,
                            hipStream_t s);
-int egv_attn_time_bwd_impl(const float* qkv, const float* d_out, const float* lse, int B, int T, int n, int H,
-                           float* dqkv, hipStream_t s);
-int egv_attn_cls_fwd_impl(const float* qkv, int B, int S, int H, bf16_t* oh, bf16_t* ol, float* lse, hipStream_t s);
-int egv_attn_cls_bwd_impl(const float* qkv, const float* d_out, const float* lse, int B, int S, int H, float* dqkv,
-                          hipStream_t s);
+int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse,
+                              hipStream_t s);
+int egv_attn_cls_delta_impl(const bf16_t* oh, const bf16_t* ol, const bf16_t* doh, const bf16_t* dol, int B, int S, int H,
+                            float* delta, hipStream_t s);
+int egv_attn_cls_finish_impl(const float* dcls, int B, int S, int H, bf16_t* gh, bf16_t* gl, hipStream_t s);
 
-extern "C" int egv_divided_attn_fwd(const float* qkv, int32_t B, int32_t T, int32_t n, int32_t H, int32_t mode,
-                                    int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream) {
-  if (!qkv || !out_hi || !lse || B <= 0 || T <= 0 || n <= 0 || H <= 0) return EGV_ERR_ARG;
-  if (passes != 1 && passes != 3) return EGV_ERR_ARG;
-  if (passes == 3 && !out_lo) return EGV_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  int rc;
-  if (mode == 0)
-    rc = egv_attn_space_fwd_impl(qkv, B, T, n, H, passes, out_hi, out_lo, lse, s);
-  else if (mode == 1)
-    rc = egv_attn_time_fwd_impl(qkv, B, T, n, H, out_hi, out_lo, lse, s);
-  else
-    return EGV_ERR_ARG;
-  if (rc) return rc;
-  return egv_attn_cls_fwd_impl(qkv, B, 1 + T * n, H, out_hi, out_lo, lse, s);
+extern "C" int64_t egv_divided_attn_fwd_work_floats(int32_t B, int32_t T, int32_t n, int32_t H, int32_t mode) {
+  return (int64_t)B * H * (mode == 0 ? T : n) * 68;
 }
 
-extern "C" int egv_divided_attn_bwd(const float* qkv, const float* d_out, const float* lse, int32_t B, int32_t T,
-                                    int32_t n, int32_t H, int32_t mode, int32_t passes, float* dqkv, float* work,
-                                    void* stream) {
-  if (!qkv || !d_out || !lse || !dqkv || B <= 0 || T <= 0 || n <= 0 || H <= 0) return EGV_ERR_ARG;
+extern "C" int64_t egv_divided_attn_bwd_work_floats(int32_t B, int32_t T, int32_t n, int32_t H) {
+  return (int64_t)B * H * (1 + (int64_t)T * n) + (int64_t)B * H * 192;
+}
+
+extern "C" int egv_divided_attn_fwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, int32_t B, int32_t T, int32_t n,
+                                    int32_t H, int32_t mode, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo,
+                                    float* lse, float* work, void* stream) {
+  if (!qkv_hi || !out_hi || !lse || !work || B <= 0 || T <= 0 || n <= 0 || H <= 0) return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
-  if (mode == 0 && !work) return EGV_ERR_ARG;
+  if (passes == 3 && (!out_lo || !qkv_lo)) return EGV_ERR_ARG;
+  if (passes == 1) { qkv_lo = nullptr; out_lo = nullptr; }
   hipStream_t s = (hipStream_t)stream;
-  const long S = 1 + (long)T * n;
-  const long row = 3L * H * 64;
-  // the CLS token's k/v rows are accumulated atomically by the patch kernels: zero token 0 of every clip
-  if (hipMemset2DAsync(dqkv, S * row * sizeof(float), 0, row * sizeof(float), B, s) != hipSuccess)
-    return EGV_ERR_LAUNCH;
   int rc;
   if (mode == 0)
-    rc = egv_attn_space_bwd_impl(qkv, d_out, lse, work, B, T, n, H, passes, dqkv, s);
+    rc = egv_attn_space_fwd_impl(qkv_hi, qkv_lo, B, T, n, H, passes, out_hi, out_lo, lse, work, s);
   else if (mode == 1)
-    rc = egv_attn_time_bwd_impl(qkv, d_out, lse, B, T, n, H, dqkv, s);
+    rc = egv_attn_time_fwd_impl(qkv_hi, qkv_lo, B, T, n, H, out_hi, out_lo, lse, work, s);
   else
     return EGV_ERR_ARG;
   if (rc) return rc;
-  return egv_attn_cls_bwd_impl(qkv, d_out, lse, B, (int)S, H, dqkv, s);
+  return egv_attn_cls_combine_impl(work, B, mode == 0 ? T : n, 1 + T * n, H, out_hi, out_lo, lse, s);
+}
+
+extern "C" int egv_divided_attn_bwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, const egv_bf16* out_hi,
+                                    const egv_bf16* out_lo, const egv_bf16* dout_hi, const egv_bf16* dout_lo,
+                                    const float* lse, int32_t B, int32_t T, int32_t n, int32_t H, int32_t mode,
+                                    int32_t passes, egv_bf16* dqkv_hi, egv_bf16* dqkv_lo, float* work, void* stream) {
+  if (!qkv_hi || !out_hi || !dout_hi || !lse || !dqkv_hi || !work || B <= 0 || T <= 0 || n <= 0 || H <= 0)
+    return EGV_ERR_ARG;
+  if (passes != 1 && passes != 3) return EGV_ERR_ARG;
+  if (passes == 3 && (!qkv_lo || !out_lo || !dout_lo || !dqkv_lo)) return EGV_ERR_ARG;
+  if (passes == 1) { qkv_lo = nullptr; out_lo = nullptr; dout_lo = nullptr; dqkv_lo = nullptr; }
+  hipStream_t s = (hipStream_t)stream;
+  const int S = 1 + T * n;
+  float* delta = work;                          // [B, H, S]
+  float* dcls = work + (long)B * H * S;         // [B, H, 3, 64] raw fp32 accumulators of the CLS token
+  if (hipMemsetAsync(dcls, 0, sizeof(float) * (size_t)B * H * 192, s) != hipSuccess) return EGV_ERR_LAUNCH;
+  int rc = egv_attn_cls_delta_impl(out_hi, out_lo, dout_hi, dout_lo, B, S, H, delta, s);
+  if (rc) return rc;
+  if (mode == 0)
+    rc = egv_attn_space_bwd_impl(qkv_hi, qkv_lo, dout_hi, dout_lo, lse, delta, dcls, B, T, n, H, passes, dqkv_hi,
+                                 dqkv_lo, s);
+  else if (mode == 1)
+    rc = egv_attn_time_bwd_impl(qkv_hi, qkv_lo, dout_hi, dout_lo, lse, delta, B, T, n, H, dqkv_hi, dqkv_lo, dcls, s);
+  else
+    return EGV_ERR_ARG;
+  if (rc) return rc;
+  return egv_attn_cls_finish_impl(dcls, B, S, H, dqkv_hi, dqkv_lo, s);
 }

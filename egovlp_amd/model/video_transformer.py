@@ -22,7 +22,7 @@ from ..ops import ACT_GELU, ACT_GELU_BWD, Planes, Precision
 from ..weights import WeightCache
 
 
-def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True):
+def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False):
     """Backward of y = x W^T + b.  `dy` is fp32 [M,N] (split to bf16 planes here, one pass, no transpose) or
     already-split row-major Planes.  The SAME row-major planes feed both gradients: dgrad contracts over N
     (dy . W, weights cached transposed) and wgrad contracts over the M token rows with the TN kernel
@@ -36,7 +36,10 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True):
     dW = torch.empty((N, K), dtype=torch.float32, device=dev)
     db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True)
     dx = None
-    if need_dx:
+    if need_dx and dx_planes:      # dx feeds a kernel that consumes planes (attention backward): no fp32 copy at all
+        dx = ops.empty_planes(M, K, Pb, dev)
+        ops.gemm_nt(dy, wt, passes=Pb, out_planes=dx, K=N)
+    elif need_dx:
         dx = torch.empty((M, K), dtype=torch.float32, device=dev)
         ops.gemm_nt(dy, wt, passes=Pb, out_f32=dx, K=N)
     return dx, dW, db
@@ -82,15 +85,15 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
 
         # ---- temporal attention branch (:166-167)
         n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P)
-        qkv_t = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(n3, W(tqkv_w), passes=P, bias=tqkv_b, out_f32=qkv_t)
+        qkv_t = ops.empty_planes(M, 3 * D, P, dev)       # qkv never exists in fp32: the attention kernels read planes
+        ops.gemm_nt(n3, W(tqkv_w), passes=P, bias=tqkv_b, out_planes=qkv_t)
         a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, P)
         tr = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(a_t, W(tproj_w), passes=P, bias=tproj_b, residual=x2, out_f32=tr)
         # ---- spatial attention branch (:168-171)
         n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P)
-        qkv_s = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(n1, W(sqkv_w), passes=P, bias=sqkv_b, out_f32=qkv_s)
+        qkv_s = ops.empty_planes(M, 3 * D, P, dev)
+        ops.gemm_nt(n1, W(sqkv_w), passes=P, bias=sqkv_b, out_planes=qkv_s)
         a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, P)
         sr = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(a_s, W(sproj_w), passes=P, bias=sproj_b, residual=x2, out_f32=sr)
@@ -105,16 +108,16 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
 
         if train:
             ctx.geom, ctx.wc, ctx.P = geom, wc, P
-            ctx.planes = (n3, a_t, n1, a_s, n2, h)
-            ctx.save_for_backward(x2, mean3, rstd3, qkv_t, lse_t, tr, mean1, rstd1, qkv_s, lse_s, sr, mean2, rstd2, z,
+            ctx.planes = (n3, a_t, n1, a_s, n2, h, qkv_t, qkv_s)
+            ctx.save_for_backward(x2, mean3, rstd3, lse_t, tr, mean1, rstd1, lse_s, sr, mean2, rstd2, z,
                                   n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w)
         return out.view(B, S, D)
 
     @staticmethod
     def backward(ctx, g_out):
-        (x2, mean3, rstd3, qkv_t, lse_t, tr, mean1, rstd1, qkv_s, lse_s, sr, mean2, rstd2, z,
+        (x2, mean3, rstd3, lse_t, tr, mean1, rstd1, lse_s, sr, mean2, rstd2, z,
          n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w) = ctx.saved_tensors
-        n3, a_t, n1, a_s, n2, h = ctx.planes
+        n3, a_t, n1, a_s, n2, h, qkv_t, qkv_s = ctx.planes
         B, T, n, H, eps = ctx.geom
         wc = ctx.wc
         Pb = Precision.bwd_passes
@@ -137,13 +140,13 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         # d_sr = G + LN2'(d_n2)
         d_sr, d_n2w, d_n2b, d_sr_pl = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G, planes_passes=Pb)
         # ---- spatial attention backward
-        d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb)
-        d_qkv_s = ops.divided_attn_bwd(qkv_s, d_as, lse_s, B, T, n, H, 0, Pb)
+        d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb, dx_planes=True)
+        d_qkv_s = ops.divided_attn_bwd(qkv_s, a_s, d_as, lse_s, B, T, n, H, 0, Pb)
         d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb)
         d_tr, d_n1w, d_n1b, d_tr_pl = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1, planes_passes=Pb)
         # ---- temporal attention backward
-        d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb)
-        d_qkv_t = ops.divided_attn_bwd(qkv_t, d_at, lse_t, B, T, n, H, 1, Pb)
+        d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb, dx_planes=True)
+        d_qkv_t = ops.divided_attn_bwd(qkv_t, a_t, d_at, lse_t, B, T, n, H, 1, Pb)
         d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb)
         # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
         d_x, d_n3w, d_n3b, d_x_pl = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr,

@@ -297,21 +297,26 @@ def assemble_tokens_bwd(dx, B, T, n, D, T_model):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def divided_attn_fwd(qkv, B, T, n, H, mode, passes):
-    """qkv fp32 [B*S, 3*H*64] -> (Planes [B*S, H*64], lse [B,H,S])."""
+def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes):
+    """qkv planes [B*S, 3*H*64] (the qkv GEMM's out_planes) -> (Planes [B*S, H*64], lse [B,H,S])."""
     S = 1 + T * n
-    out = empty_planes(B * S, H * 64, passes, qkv.device)
-    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
-    check(_lib.lib().egv_divided_attn_fwd(_p(qkv), B, T, n, H, mode, passes, _p(out.hi), _p(out.lo), _p(lse),
-                                          _stream()), "egv_divided_attn_fwd")
+    dev = qkv.hi.device
+    out = empty_planes(B * S, H * 64, passes, dev)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    work = torch.empty(_lib.lib().egv_divided_attn_fwd_work_floats(B, T, n, H, mode), dtype=torch.float32, device=dev)
+    check(_lib.lib().egv_divided_attn_fwd(_p(qkv.hi), _p(qkv.lo), B, T, n, H, mode, passes, _p(out.hi), _p(out.lo),
+                                          _p(lse), _p(work), _stream()), "egv_divided_attn_fwd")
     return out, lse
 
 
-def divided_attn_bwd(qkv, d_out, lse, B, T, n, H, mode, passes):
+def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, mode, passes) -> Planes:
+    """-> dqkv planes [B*S, 3*H*64], ready to be the dY operand of the qkv dgrad / wgrad GEMMs."""
     S = 1 + T * n
-    dqkv = torch.empty_like(qkv)
-    work = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
-    check(_lib.lib().egv_divided_attn_bwd(_p(qkv), _p(d_out), _p(lse), B, T, n, H, mode, passes, _p(dqkv), _p(work),
+    dev = qkv.hi.device
+    dqkv = empty_planes(B * S, 3 * H * 64, passes, dev)
+    work = torch.empty(_lib.lib().egv_divided_attn_bwd_work_floats(B, T, n, H), dtype=torch.float32, device=dev)
+    check(_lib.lib().egv_divided_attn_bwd(_p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(d_out.hi), _p(d_out.lo),
+                                          _p(lse), B, T, n, H, mode, passes, _p(dqkv.hi), _p(dqkv.lo), _p(work),
                                           _stream()), "egv_divided_attn_bwd")
     return dqkv
 

@@ -107,17 +107,27 @@ int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, int32_t n, in
                             float* d_pe, float* d_cls, float* d_pos, float* d_temporal, void* stream);
 
 /* ---- divided space-time attention ------------------------------------------------------------------
- * VarAttention core (model/video_transformer.py:104-133) on the fused qkv buffer [B, S, 3, H, 64] fp32
- * (S = 1 + T*n, token order 1 + f*n + i).  q is scaled by 64^-0.5 inside.  mode 0 = space
- * (group = (b,f,h): n queries x (CLS + n) keys), mode 1 = time (group = (b,i,h): T queries x (CLS + T)
- * keys).  The CLS query row (attends to all S keys, :112) is computed by the same call.  Output: split
- * planes [B, S, H*64]; lse [B, H, S] (log-sum-exp of each query row, saved for backward).           */
-int egv_divided_attn_fwd(const float* qkv, int32_t B, int32_t T, int32_t n, int32_t H, int32_t mode,
-                         int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream);
-/* dqkv [B,S,3,H,64] fp32 is fully written (CLS rows zeroed inside, then accumulated).  d_out [B,S,H*64] fp32. */
-int egv_divided_attn_bwd(const float* qkv, const float* d_out, const float* lse, int32_t B, int32_t T,
-                         int32_t n, int32_t H, int32_t mode, int32_t passes, float* dqkv,
-                         float* work /* B*H*S floats (mode 0) */, void* stream);
+ * VarAttention core (model/video_transformer.py:104-133) on the fused qkv buffer [B, S, 3, H, 64] given as split-bf16
+ * planes (exactly what the qkv GEMM epilogue writes; qkv_lo is ignored / may be NULL when passes == 1).
+ * S = 1 + T*n, token order 1 + f*n + i.  q is scaled by 64^-0.5 inside.  mode 0 = space (group = (b,f,h): n queries x
+ * (CLS + n) keys, bf16 MFMA, scores never leave LDS / registers), mode 1 = time (group = (b,i,h): T queries x (CLS + T)
+ * keys, VALU fp32).  The CLS query row (attends to all S keys, :112) rides in every group as an extra query; its
+ * partials are merged by a small combine kernel.  Output: split planes [B, S, H*64]; lse [B, H, S] (log-sum-exp of each
+ * query row, saved for backward).  `work`: egv_divided_attn_fwd_work_floats(...) floats.                            */
+int egv_divided_attn_fwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, int32_t B, int32_t T, int32_t n, int32_t H,
+                         int32_t mode, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, float* work,
+                         void* stream);
+int64_t egv_divided_attn_fwd_work_floats(int32_t B, int32_t T, int32_t n, int32_t H, int32_t mode);
+/* Backward: out_* = the forward output planes, dout_* = gradient w.r.t. them (planes, e.g. from the proj dgrad
+ * epilogue).  dqkv [B,S,3,H,64] is written ONCE as split planes -- every dK / dV row already contains the CLS query's
+ * contribution -- i.e. directly in the operand format of the qkv dgrad / wgrad GEMMs.  Only the CLS token's own
+ * gradients are accumulated in fp32 (atomics) and converted by a finish kernel.
+ * `work`: egv_divided_attn_bwd_work_floats(...) floats.                                                              */
+int egv_divided_attn_bwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, const egv_bf16* out_hi, const egv_bf16* out_lo,
+                         const egv_bf16* dout_hi, const egv_bf16* dout_lo, const float* lse, int32_t B, int32_t T,
+                         int32_t n, int32_t H, int32_t mode, int32_t passes, egv_bf16* dqkv_hi, egv_bf16* dqkv_lo,
+                         float* work, void* stream);
+int64_t egv_divided_attn_bwd_work_floats(int32_t B, int32_t T, int32_t n, int32_t H);
 
 /* ---- DistilBERT pieces ----------------------------------------------------------------------------
  * Embeddings (modeling_distilbert.py:82-118): e[b,l,:] = word[ids[b,l]] + pos[l] (fp32 sum; LN is a

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/c8; mkdir -p $O
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 ) > $O/pytest.log 2>&1
+bash tools/gpu_prof.sh c8 bf16
