@@ -10,6 +10,8 @@
 //     every dK / dV row leaves the kernel complete (patch queries + CLS query) and is written ONCE, as bf16 planes.
 //     Only the CLS token's own gradients (shared by all groups of a clip) go through fp32 atomics + a finish kernel.
 // All operands and results are split-bf16 planes of the fused [B, S, 3, H, 64] buffer (lo plane optional).
+#include <cstdlib>
+
 #include "common.h"
 #include "egovlp_hip.h"
 
@@ -17,10 +19,22 @@ namespace {
 
 constexpr int D = 64;
 
+// sum over the 16 lanes of a DPP row, result in every lane: quad_perm xor 1, xor 2, then row rotations by 4 and 8.
+// Full-rate VALU (DPP) instead of four ds_bpermute round trips through the LDS crossbar -- the time-attention backward
+// does ~250 of these reductions per location and was shuffle-bound (296 us per call with __shfl_xor).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return v;
+}
+
 template <int LPH>
 __device__ __forceinline__ float redh(float v) {   // sum over the LPH lanes that share a head
-#pragma unroll
-  for (int o = LPH / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = row16_sum(v);
+  if (LPH >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPH == 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -39,6 +53,15 @@ __device__ __forceinline__ void ldp(const bf16_t* __restrict__ ph, const bf16_t*
       x[2] += __uint_as_float(b[1] << 16);
       x[3] += __uint_as_float(b[1] & 0xffff0000u);
     }
+  } else if (CPL == 2) {
+    const uint32_t a = *(const uint32_t*)(ph + off);
+    x[0] = __uint_as_float(a << 16);
+    x[1] = __uint_as_float(a & 0xffff0000u);
+    if (pl) {
+      const uint32_t b = *(const uint32_t*)(pl + off);
+      x[0] += __uint_as_float(b << 16);
+      x[1] += __uint_as_float(b & 0xffff0000u);
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -56,6 +79,9 @@ __device__ __forceinline__ void stp(bf16_t* __restrict__ ph, bf16_t* __restrict_
   if (CPL == 4) {
     *(u32x2_t*)(ph + off) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
     if (pl) *(u32x2_t*)(pl + off) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+  } else if (CPL == 2) {
+    *(uint32_t*)(ph + off) = pack2(h[0], h[1]);
+    if (pl) *(uint32_t*)(pl + off) = pack2(l[0], l[1]);
   } else {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -184,16 +210,20 @@ __global__ __launch_bounds__(256) void attn_time_fwd_kernel(const bf16_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------- time bwd
-// one workgroup = (b, head group, 16 consecutive locations); each wave walks 4 locations and keeps the CLS token's raw
-// dq / dk / dv partials in registers: one LDS reduction + one atomicAdd per channel per workgroup.
+// one workgroup = (b, head group, 16 consecutive locations); each wave walks 4 locations.  Per location the T keys /
+// values and their gradient accumulators live in registers and ONE rolled loop walks the T patch queries plus, as
+// iteration T, the clip's CLS query (global log-sum-exp / delta, its dq partial accumulated instead of stored) -- the
+// first version unrolled everything, needed > 256 VGPRs (1 wave per SIMD) and ran at 229 us per call.
+// The CLS token's raw dq / dk / dv partials stay in registers across locations: one LDS reduction + one atomicAdd per
+// channel per workgroup.
 template <int TMAX, int HPW>
-__global__ __launch_bounds__(256) void attn_time_bwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
-                                                            const bf16_t* __restrict__ doh,
-                                                            const bf16_t* __restrict__ dol,
-                                                            const float* __restrict__ lse,
-                                                            const float* __restrict__ delta, int B, int T, int n, int H,
-                                                            bf16_t* __restrict__ gh, bf16_t* __restrict__ gl,
-                                                            float* __restrict__ dcls) {
+__global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void attn_time_bwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
+                                                               const bf16_t* __restrict__ doh,
+                                                               const bf16_t* __restrict__ dol,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, int B, int T, int n,
+                                                               int H, bf16_t* __restrict__ gh, bf16_t* __restrict__ gl,
+                                                               float* __restrict__ dcls) {
   constexpr int LPH = 64 / HPW, CPL = HPW;
   __shared__ float red[3][4][64 * CPL];
   const int lane = threadIdx.x & 63;
@@ -208,109 +238,101 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(const bf16_t* __rest
   const long S = 1 + (long)T * n;
   const long HD = (long)H * D;
   const long ts = 3 * HD;
-  const long base = (long)b * S * ts + (long)head * D + ch;
-  const long obase = (long)b * S * HD + (long)head * D + ch;
-  const long lbase = ((long)b * H + head) * S;
+  // per-clip bases (wave-uniform) + 32-bit per-lane element offsets
+  const bf16_t* qb = qh + (long)b * S * ts;
+  const bf16_t* qbl = ql ? ql + (long)b * S * ts : nullptr;
+  bf16_t* gb = gh + (long)b * S * ts;
+  bf16_t* gbl = gl ? gl + (long)b * S * ts : nullptr;
+  const bf16_t* ob = doh + (long)b * S * HD;
+  const bf16_t* obl = dol ? dol + (long)b * S * HD : nullptr;
+  const unsigned hc = (unsigned)(head * D + ch);
+  const float* lb = lse + ((long)b * H + head) * S;
   float qc[CPL], kc[CPL], vc[CPL], goc[CPL];
-  ldp<CPL>(qh, ql, base, qc);
-  ldp<CPL>(qh, ql, base + HD, kc);
-  ldp<CPL>(qh, ql, base + 2 * HD, vc);
-  ldp<CPL>(doh, dol, obase, goc);
-  const float Lc = lse[lbase], dc = delta[lbase];
+  ldp<CPL>(qb, qbl, hc, qc);
+  ldp<CPL>(qb, qbl, hc + HD, kc);
+  ldp<CPL>(qb, qbl, hc + 2 * HD, vc);
+  ldp<CPL>(ob, obl, hc, goc);
+  const float Lc = lb[0], dc = delta[((long)b * H + head) * S];
   float dqc[CPL], dkc[CPL], dvc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) dqc[c] = dkc[c] = dvc[c] = 0.f;
 
+#pragma unroll 1
   for (int ii = 0; ii < 4; ++ii) {
     const int i = ic * 16 + wave * 4 + ii;
     if (i >= n) break;
-    float q[TMAX][CPL], k[TMAX][CPL], v[TMAX][CPL], go[TMAX][CPL], dk[TMAX][CPL], dv[TMAX][CPL];
+    float k[TMAX][CPL], v[TMAX][CPL], dk[TMAX][CPL], dv[TMAX][CPL];
 #pragma unroll
-    for (int f = 0; f < TMAX; ++f) {
+    for (int j = 0; j < TMAX; ++j) {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) q[f][c] = k[f][c] = v[f][c] = go[f][c] = dk[f][c] = dv[f][c] = 0.f;
-      if (f < T) {
-        const long tok = 1 + (long)f * n + i;
-        ldp<CPL>(qh, ql, base + tok * ts, q[f]);
-        ldp<CPL>(qh, ql, base + tok * ts + HD, k[f]);
-        ldp<CPL>(qh, ql, base + tok * ts + 2 * HD, v[f]);
-        ldp<CPL>(doh, dol, obase + tok * HD, go[f]);
+      for (int c = 0; c < CPL; ++c) k[j][c] = v[j][c] = dk[j][c] = dv[j][c] = 0.f;
+      if (j < T) {
+        const unsigned to = (unsigned)((1 + j * n + i) * ts) + hc;
+        ldp<CPL>(qb, qbl, to + HD, k[j]);
+        ldp<CPL>(qb, qbl, to + 2 * HD, v[j]);
       }
     }
+#pragma unroll 1
+    for (int f = 0; f <= T; ++f) {
+      const bool is_cls = (f == T);
+      const int tok = is_cls ? 0 : 1 + f * n + i;
+      float qf[CPL], gof[CPL];
+      ldp<CPL>(qb, qbl, (unsigned)(tok * ts) + hc, qf);
+      ldp<CPL>(ob, obl, (unsigned)(tok * HD) + hc, gof);
+      const float L = lb[tok];
+      // CLS key: every patch query sees it; the CLS query only in location-group 0
+      float p0 = __expf(redh<LPH>(dotc<CPL>(qf, kc)) * 0.125f - L);
+      if (is_cls && i != 0) p0 = 0.f;
+      const float dp0 = redh<LPH>(dotc<CPL>(gof, vc));
+      float p[TMAX], dp[TMAX];
+      float dl = p0 * dp0;
 #pragma unroll
-    for (int f = 0; f < TMAX; ++f) {
-      if (f < T) {
-        const float L = lse[lbase + 1 + (long)f * n + i];
-        float p[TMAX + 1], dp[TMAX + 1];
-        p[0] = __expf(redh<LPH>(dotc<CPL>(q[f], kc)) * 0.125f - L);
-        dp[0] = redh<LPH>(dotc<CPL>(go[f], vc));
-        float dl = p[0] * dp[0];
-#pragma unroll
-        for (int j = 0; j < TMAX; ++j) {
-          p[j + 1] = dp[j + 1] = 0.f;
-          if (j < T) {
-            p[j + 1] = __expf(redh<LPH>(dotc<CPL>(q[f], k[j])) * 0.125f - L);
-            dp[j + 1] = redh<LPH>(dotc<CPL>(go[f], v[j]));
-            dl += p[j + 1] * dp[j + 1];
-          }
+      for (int j = 0; j < TMAX; ++j) {
+        p[j] = dp[j] = 0.f;
+        if (j < T) {
+          p[j] = __expf(redh<LPH>(dotc<CPL>(qf, k[j])) * 0.125f - L);
+          dp[j] = redh<LPH>(dotc<CPL>(gof, v[j]));
+          dl += p[j] * dp[j];
         }
-        const float ds0 = p[0] * (dp[0] - dl);
-        float dq[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          dq[c] = ds0 * kc[c];
-          dkc[c] += ds0 * q[f][c];
-          dvc[c] += p[0] * go[f][c];
-        }
-#pragma unroll
-        for (int j = 0; j < TMAX; ++j) {
-          if (j < T) {
-            const float ds = p[j + 1] * (dp[j + 1] - dl);
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-              dq[c] += ds * k[j][c];
-              dk[j][c] += ds * q[f][c];
-              dv[j][c] += p[j + 1] * go[f][c];
-            }
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) dq[c] *= 0.125f;
-        stp<CPL>(gh, gl, base + (1 + (long)f * n + i) * ts, dq);
       }
-    }
-    // the clip's CLS query against this location's keys (global log-sum-exp Lc and delta dc)
-    if (i == 0) {
-      const float p0 = __expf(redh<LPH>(dotc<CPL>(qc, kc)) * 0.125f - Lc);
-      const float ds0 = p0 * (redh<LPH>(dotc<CPL>(goc, vc)) - dc);
+      if (is_cls) dl = dc;                  // the CLS row's delta spans all locations: precomputed
+      const float ds0 = p0 * (dp0 - dl);
+      float dq[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        dqc[c] += ds0 * kc[c];
-        dkc[c] += ds0 * qc[c];
-        dvc[c] += p0 * goc[c];
+        dq[c] = ds0 * kc[c];
+        dkc[c] += ds0 * qf[c];
+        dvc[c] += p0 * gof[c];
+      }
+#pragma unroll
+      for (int j = 0; j < TMAX; ++j) {
+        if (j < T) {
+          const float ds = p[j] * (dp[j] - dl);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            dq[c] += ds * k[j][c];
+            dk[j][c] += ds * qf[c];
+            dv[j][c] += p[j] * gof[c];
+          }
+        }
+      }
+      if (is_cls) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dqc[c] += dq[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) dq[c] *= 0.125f;
+        stp<CPL>(gb, gbl, (unsigned)(tok * ts) + hc, dq);
       }
     }
 #pragma unroll
     for (int j = 0; j < TMAX; ++j) {
       if (j < T) {
-        const float pj = __expf(redh<LPH>(dotc<CPL>(qc, k[j])) * 0.125f - Lc);
-        const float ds = pj * (redh<LPH>(dotc<CPL>(goc, v[j])) - dc);
+        const unsigned to = (unsigned)((1 + j * n + i) * ts) + hc;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          dqc[c] += ds * k[j][c];
-          dk[j][c] += ds * qc[c];
-          dv[j][c] += pj * goc[c];
-        }
-      }
-    }
-#pragma unroll
-    for (int f = 0; f < TMAX; ++f) {
-      if (f < T) {
-        const long p = base + (1 + (long)f * n + i) * ts;
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) dk[f][c] *= 0.125f;
-        stp<CPL>(gh, gl, p + HD, dk[f]);
-        stp<CPL>(gh, gl, p + 2 * HD, dv[f]);
+        for (int c = 0; c < CPL; ++c) dk[j][c] *= 0.125f;
+        stp<CPL>(gb, gbl, to + HD, dk[j]);
+        stp<CPL>(gb, gbl, to + 2 * HD, dv[j]);
       }
     }
   }
@@ -335,27 +357,52 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(const bf16_t* __rest
 
 // ------------------------------------------------------------------------------------------- CLS row helpers
 // forward: merge the G softmax partials (o[64], m, l) of one (clip, head) -> output planes of token 0 + its lse.
-__global__ __launch_bounds__(64) void attn_cls_combine_kernel(const float* __restrict__ ws, int G, int S, int H,
+// 256 threads: thread = (sub = t >> 4, 4 channels); the 16 subs walk the groups interleaved with an online merge, then
+// one LDS round merges the subs.
+__global__ __launch_bounds__(256) void attn_cls_combine_kernel(const float* __restrict__ ws, int G, int S, int H,
                                                               bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
                                                               float* __restrict__ lse) {
-  const int lane = threadIdx.x;
+  __shared__ float sm[16], sl[16], so[16][64];
+  const int t = threadIdx.x;
+  const int sub = t >> 4, c4 = (t & 15) * 4;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
   const float* w = ws + (long)blockIdx.x * G * 68;
-  float m = -3e38f;
-  for (int g = 0; g < G; ++g) m = fmaxf(m, w[(long)g * 68 + 64]);
-  float l = 0.f, o = 0.f;
-  for (int g = 0; g < G; ++g) {
-    const float e = __expf(w[(long)g * 68 + 64] - m);
-    l += w[(long)g * 68 + 65] * e;
-    o += w[(long)g * 68 + lane] * e;
+  float m = -3e38f, l = 0.f;
+  f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+  for (int g = sub; g < G; g += 16) {
+    const float mg = w[(long)g * 68 + 64], lg = w[(long)g * 68 + 65];
+    const f32x4_t og = *(const f32x4_t*)(w + (long)g * 68 + c4);
+    const float mn = fmaxf(m, mg);
+    const float ea = __expf(m - mn), eb = __expf(mg - mn);
+    l = l * ea + lg * eb;
+    o = o * ea + og * eb;
+    m = mn;
   }
-  o /= l;
-  bf16_t hh, ll;
-  split_bf16(o, hh, ll);
-  const long off = (long)b * S * H * D + (long)h * D + lane;
-  out_hi[off] = hh;
-  if (out_lo) out_lo[off] = ll;
-  if (lane == 0) lse[((long)b * H + h) * S] = m + __logf(l);
+  if ((t & 15) == 0) {
+    sm[sub] = m;
+    sl[sub] = l;
+  }
+  *(f32x4_t*)&so[sub][c4] = o;
+  __syncthreads();
+  if (t < 64) {
+    float mm = -3e38f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mm = fmaxf(mm, sm[i]);
+    float ll = 0.f, oo = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e = __expf(sm[i] - mm);   // subs that saw no group: m = -3e38 -> e = 0
+      ll += sl[i] * e;
+      oo += so[i][t] * e;
+    }
+    oo /= ll;
+    bf16_t hh, lo2;
+    split_bf16(oo, hh, lo2);
+    const long off = (long)b * S * H * D + (long)h * D + t;
+    out_hi[off] = hh;
+    if (out_lo) out_lo[off] = lo2;
+    if (t == 0) lse[((long)b * H + h) * S] = mm + __logf(ll);
+  }
 }
 
 // backward prologue: delta of the CLS query row = sum_d dO[d] * O[d] (== sum_j P_j dP_j over ALL keys)
@@ -411,8 +458,12 @@ template <int TMAX>
 int launch_time_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
                     const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s) {
   const int chunks = (n + 15) / 16;
-  if (H % 4 == 0 && TMAX <= 4) {
+  static const int want4 = getenv("EGV_TIME_HPW") ? atoi(getenv("EGV_TIME_HPW")) == 4 : 0;   // A/B diagnostics
+  if (H % 4 == 0 && TMAX <= 4 && want4) {
     EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
+               lse, delta, B, T, n, H, gh, gl, dcls);
+  } else if (H % 2 == 0 && TMAX <= 8) {
+    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 2>), dim3((unsigned)(B * (H / 2) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
                lse, delta, B, T, n, H, gh, gl, dcls);
   } else {
     EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 1>), dim3((unsigned)(B * H * chunks)), dim3(256), 0, s, qh, ql, doh, dol, lse,
@@ -443,7 +494,7 @@ int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh
 
 int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse,
                               hipStream_t s) {
-  EGV_LAUNCH(attn_cls_combine_kernel, dim3(B * H), dim3(64), 0, s, ws, G, S, H, oh, ol, lse);
+  EGV_LAUNCH(attn_cls_combine_kernel, dim3(B * H), dim3(256), 0, s, ws, G, S, H, oh, ol, lse);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
