@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("out_hi", c_p), ("out_lo", c_p), ("ldoh", i64),
         ("ksplit", i32), ("accumulate", i32),
         ("partial", c_p),
-        ("trans", i32),
+        ("trans", i32), ("aux_bf16", i32),
         ("colsum", c_p),
     ]
 

@@ -79,6 +79,19 @@ __device__ __forceinline__ bf16x8_t lds_tr2(const char* p) {
   return __builtin_bit_cast(bf16x8_t, z);
 }
 
+// The same transpose read as inline asm.  hipcc (ROCm 7.2) cannot prove that a ds_read_tr BUILTIN does not alias the
+// LDS-DMA writes in flight and puts `s_waitcnt vmcnt(0)` in front of every batch of them (seen in the .s of the TN
+// kernel: the wait landed right behind the DMA issue of k-tile t+2, serialising every prefetch; 2.15 us per k-tile against
+// 1.45 for the NT kernel whose plain LDS loads carry alias info).  An asm read is invisible to that pass; its completion
+// is waited for by hand (lgkmcnt(0) at the end of the phase that issued it, before the halves are combined -- the asm
+// outputs never live across a basic-block boundary, see cdna_hip_programming.md 5.7).
+template <int OFF>
+__device__ __forceinline__ u32x2_t tr_asm(unsigned addr) {
+  u32x2_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return r;
+}
+
 // One 4-column piece of one output row: alpha, + bias, activation, + residual, stores (include/egovlp_hip.h order).
 template <int EPI>
 __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int m, int n, int z, int ksplit) {
@@ -90,11 +103,24 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
   if (EPI == EPI_GENERIC && p.alpha != 1.0f) v *= p.alpha;
   if (EPI != EPI_GELU_BWD && p.bias) v += *(const f32x4_t*)(p.bias + n);
   if (EPI == EPI_GELU || (EPI == EPI_GENERIC && p.act == EGV_ACT_GELU)) {
-    if (p.aux_out) *(f32x4_t*)(p.aux_out + (long)m * p.ldaux + n) = v;
+    if (p.aux_out) {
+      if (p.aux_bf16)
+        *(u32x2_t*)((bf16_t*)p.aux_out + (long)m * p.ldaux + n) =
+            (u32x2_t){pack2(f32_to_bf16(v[0]), f32_to_bf16(v[1])), pack2(f32_to_bf16(v[2]), f32_to_bf16(v[3]))};
+      else
+        *(f32x4_t*)(p.aux_out + (long)m * p.ldaux + n) = v;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
   } else if (EPI == EPI_GELU_BWD || (EPI == EPI_GENERIC && p.act == EGV_ACT_GELU_BWD)) {
-    const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
+    f32x4_t zv;
+    if (p.aux_bf16) {
+      const u32x2_t zb = *(const u32x2_t*)((const bf16_t*)p.aux_in + (long)m * p.ldaux + n);
+      zv = (f32x4_t){__uint_as_float(zb[0] << 16), __uint_as_float(zb[0] & 0xffff0000u), __uint_as_float(zb[1] << 16),
+                     __uint_as_float(zb[1] & 0xffff0000u)};
+    } else {
+      zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(zv[e]);
   } else if (EPI == EPI_GENERIC && p.act == EGV_ACT_RELU_BWD) {
@@ -184,20 +210,68 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     a_rd1 = b_rd1 = 0;
   }
 
-  bf16x8_t A[2][MF], Bq[2][NC];
-  auto load_a = [&](int sb, int ks, bf16x8_t (&dst)[MF]) {
+  // TN keeps ONE fragment set: the pending halves of the asm reads are its second buffer (commit happens after the
+  // phase's MFMAs), which keeps the kernel under 256 VGPRs without spills -- a spilled pending half would be read early.
+  bf16x8_t A[TN ? 1 : 2][MF], Bq[TN ? 1 : 2][NC];
+  // NT: plain LDS loads straight into the destination fragments (issue = load, commit = nothing).
+  // TN: asm transpose reads into pending halves (issue), combined into the fragment after the hand-placed wait (commit).
+  u32x2_t pa[TN ? MF : 1][2], pb[TN ? NC : 1][2];
+  const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  auto issue_a = [&](int sb, int ks, bf16x8_t (&dst)[MF]) {
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
-      if (!TN) dst[f] = lds_b128(smem + sb + (ks ? a_rd1 : a_rd0) + f * 2048);
-      else dst[f] = lds_tr2(smem + sb + a_rd0 + ks * (32 * 512) + (((wm * 4 + f) ^ tn_r7) << 5));
+      if (!TN) {
+        dst[f] = lds_b128(smem + sb + (ks ? a_rd1 : a_rd0) + f * 2048);
+      } else {
+        const unsigned ad = lds0 + sb + a_rd0 + (((wm * 4 + f) ^ tn_r7) << 5);
+        if (ks == 0) {
+          pa[TN ? f : 0][0] = tr_asm<0>(ad);
+          pa[TN ? f : 0][1] = tr_asm<16 * 512>(ad);
+        } else {
+          pa[TN ? f : 0][0] = tr_asm<32 * 512>(ad);
+          pa[TN ? f : 0][1] = tr_asm<48 * 512>(ad);
+        }
+      }
     }
   };
-  auto load_b = [&](int sb, int ks, int c, bf16x8_t (&dst)[NC]) {
+  auto issue_b = [&](int sb, int ks, int c, bf16x8_t (&dst)[NC]) {
 #pragma unroll
     for (int jj = 0; jj < NC; ++jj) {
       const int j = c * NC + jj;
-      if (!TN) dst[jj] = lds_b128(smem + sb + (ks ? b_rd1 : b_rd0) + j * 2048);
-      else dst[jj] = lds_tr2(smem + sb + b_rd0 + ks * (32 * 512) + (((wn * 8 + j) ^ tn_r7) << 5));
+      if (!TN) {
+        dst[jj] = lds_b128(smem + sb + (ks ? b_rd1 : b_rd0) + j * 2048);
+      } else {
+        const unsigned ad = lds0 + sb + b_rd0 + (((wn * 8 + j) ^ tn_r7) << 5);
+        if (ks == 0) {
+          pb[TN ? jj : 0][0] = tr_asm<0>(ad);
+          pb[TN ? jj : 0][1] = tr_asm<16 * 512>(ad);
+        } else {
+          pb[TN ? jj : 0][0] = tr_asm<32 * 512>(ad);
+          pb[TN ? jj : 0][1] = tr_asm<48 * 512>(ad);
+        }
+      }
+    }
+  };
+  auto commit_a = [&](bf16x8_t (&dst)[MF]) {
+    if (TN) {
+#pragma unroll
+      for (int f = 0; f < MF; ++f)
+        dst[f] = __builtin_bit_cast(bf16x8_t, (u32x4_t){pa[TN ? f : 0][0][0], pa[TN ? f : 0][0][1], pa[TN ? f : 0][1][0],
+                                                        pa[TN ? f : 0][1][1]});
+    }
+  };
+  auto commit_b = [&](bf16x8_t (&dst)[NC]) {
+    if (TN) {
+#pragma unroll
+      for (int jj = 0; jj < NC; ++jj)
+        dst[jj] = __builtin_bit_cast(bf16x8_t, (u32x4_t){pb[TN ? jj : 0][0][0], pb[TN ? jj : 0][0][1],
+                                                         pb[TN ? jj : 0][1][0], pb[TN ? jj : 0][1][1]});
+    }
+  };
+  auto tn_wait = [&]() {
+    if (TN) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -277,8 +351,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-      load_b(0, 0, 0, Bq[0]);
-      load_a(0, 0, A[0]);
+      issue_b(0, 0, 0, Bq[0]);
+      issue_a(0, 0, A[0]);
+      tn_wait();
+      commit_b(Bq[0]);
+      commit_a(A[0]);
     }
     if (dbg == 200) ts1 = __builtin_amdgcn_s_memrealtime();
 
@@ -298,9 +375,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           if (c == 0 && cs_on) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
-              cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[ks & 1][i], cs[i], 0, 0, 0);
+              cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[TN ? 0 : (ks & 1)][i], cs[i], 0, 0, 0);
           }
-          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][0], A[ks & 1][0], acc[0][c * NC], 0, 0, 0);
+          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph & 1)][0], A[TN ? 0 : (ks & 1)][0],
+                                                                   acc[0][c * NC], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (last) {
             if (t + 1 < nt) {
@@ -308,14 +386,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
               asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
               __builtin_amdgcn_s_barrier();
               if (t + 2 < nt) stage(t & 1);
-              load_b(STAGE - sb, 0, 0, Bq[0]);
-              load_a(STAGE - sb, 0, A[0]);
+              issue_b(STAGE - sb, 0, 0, Bq[0]);
+              issue_a(STAGE - sb, 0, A[0]);
             }
           } else {
             const int ks2 = (c + 1 < NCH) ? ks : ks + 1;
             const int c2 = (c + 1 < NCH) ? c + 1 : 0;
-            load_b(sb, ks2, c2, Bq[(ph + 1) & 1]);
-            if (c2 == 0) load_a(sb, ks2, A[ks2 & 1]);
+            issue_b(sb, ks2, c2, Bq[TN ? 0 : ((ph + 1) & 1)]);
+            if (c2 == 0) issue_a(sb, ks2, A[TN ? 0 : (ks2 & 1)]);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -323,9 +401,22 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
             for (int i = 0; i < MF; ++i)
               if (jj + i > 0)
-                acc[i][c * NC + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[ph & 1][jj], A[ks & 1][i],
+                acc[i][c * NC + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph & 1)][jj], A[TN ? 0 : (ks & 1)][i],
                                                                               acc[i][c * NC + jj], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+          if (TN) {   // the asm reads issued above have had this phase's MFMAs to land: wait, then assemble the fragments
+            if (last) {
+              if (t + 1 < nt) {
+                tn_wait();
+                commit_b(Bq[0]);
+                commit_a(A[0]);
+              }
+            } else {
+              tn_wait();
+              commit_b(Bq[0]);
+              if (c + 1 >= NCH) commit_a(A[0]);
+            }
+          }
         }
       }
       if (++cur_kt == kt_end) {

@@ -242,6 +242,7 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   if (p.colsum && !p.trans) return EGV_ERR_ARG;
   const int variant = gemm_variant(p);
   if (variant < 0) return EGV_ERR_ARG;
+  if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // bf16 aux: gemm_big GELU epilogues only
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);

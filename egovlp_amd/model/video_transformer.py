@@ -101,7 +101,10 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P)
         Hd = fc1_w.shape[0]
         h = ops.empty_planes(M, Hd, P, dev)
-        z = torch.empty((M, Hd), dtype=torch.float32, device=dev) if train else None
+        # pre-activation saved for GELU' in backward: bf16 when backward runs single-pass bf16 anyway (half the bytes of
+        # fc1's epilogue write and of fc2-dgrad's epilogue read); fp32 in the all-bf16x3 parity mode
+        z_dtype = torch.bfloat16 if (Precision.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D)) else torch.float32
+        z = torch.empty((M, Hd), dtype=z_dtype, device=dev) if train else None
         ops.gemm_nt(n2, W(fc1_w), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h)
         out = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(h, W(fc2_w), passes=P, bias=fc2_b, residual=sr, out_f32=out)

@@ -127,6 +127,7 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     d.residual, d.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     aux = aux_in if aux_in is not None else aux_out
     d.aux_in, d.aux_out, d.ldaux = _p(aux_in), _p(aux_out), (aux.stride(0) if aux is not None else 0)
+    d.aux_bf16 = int(aux is not None and aux.dtype == torch.bfloat16)
     d.out_f32, d.ldo = _p(out_f32), (out_f32.stride(0) if out_f32 is not None else 0)
     if out_planes is not None:
         d.out_hi, d.out_lo, d.ldoh = _p(out_planes.hi), _p(out_planes.lo), out_planes.ld
@@ -135,11 +136,18 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
         partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device)
     d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
     d.trans, d.colsum = 0, None
+    if d.aux_bf16 and not uses_big_gemm(M, N, K):
+        raise ValueError("bf16 aux buffers are only supported by the big-tile GEMM kernel (see uses_big_gemm)")
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * K,
                           lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"), passes)
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
+
+
+def uses_big_gemm(M, N, K):
+    """Mirror of the kernel choice in csrc/gemm_nt.hip (gemm_variant) for NT problems without split-K."""
+    return M >= 256 and N >= 256 and K % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
 
 
 def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=None):
@@ -171,7 +179,7 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
     partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
     d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
-    d.trans, d.colsum = 1, _p(cs)
+    d.trans, d.colsum, d.aux_bf16 = 1, _p(cs), 0
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * Kd,
                           lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"), passes)

@@ -55,7 +55,10 @@ typedef struct egv_gemm_desc {
   egv_bf16* out_hi; egv_bf16* out_lo; int64_t ldoh;
   int32_t ksplit, accumulate;
   float* partial;
-  int32_t trans;    /* 0: A[M,K], B[N,K] (contraction index contiguous).  1 ("TN", wgrad): A is stored [K, lda] with
+  int32_t trans;    /* (see below) */
+  int32_t aux_bf16; /* != 0: aux_in / aux_out are bf16 [M, ldaux] instead of fp32 (the GELU pre-activation saved by fc1 for
+                       fc2's dgrad: half the bytes when backward runs single-pass bf16 anyway).  Big-tile kernel only.
+                       trans = 0: A[M,K], B[N,K] (contraction index contiguous).  1 ("TN", wgrad): A is stored [K, lda] with
                        its M rows as COLUMNS and B is stored [K, ldb] with N columns, C[m,n] = sum_k A[k,m] B[k,n] --
                        no transposed copy of either operand is ever made (CDNA4 transpose-read from LDS).  Requires
                        M >= 256, N >= 256, both multiples of 8; K is arbitrary (rows past K are zero-filled).        */

@@ -151,6 +151,27 @@ def test_gemm_big_tiles(ops, passes, M, N, K):
     assert rel(pl.float(), ref) < TOL[passes] * 2 + 1e-5
 
 
+def test_gemm_big_gelu_epilogues_bf16_aux(ops):
+    """fc1 / fc2-dgrad flavour of gemm_big: fast-erf GELU (+ pre-activation saved as bf16) and GELU' from the bf16 copy."""
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 8200, 1024, 128
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias = torch.randn(N, generator=g)
+    A, Bm = planes_from(ops, a, 1), planes_from(ops, b, 1)
+    ref = (A.float().double().cpu() @ Bm.float().double().cpu().t()) + bias      # exact product of the bf16 operands
+    for dt, tol in ((torch.float32, 2e-6), (torch.bfloat16, 3e-3)):
+        z = torch.empty(M, N, dtype=dt, device="cuda")
+        h = ops.empty_planes(M, N, 3, "cuda")
+        ops.gemm_nt(A, Bm, passes=1, bias=bias.cuda(), act=ops.ACT_GELU, aux_out=z, out_planes=h)
+        assert rel(z.float(), ref) < tol
+        assert rel(h.float(), F.gelu(ref)) < 5e-6                                  # A&S 7.1.26 erf: |err| <= 4e-7
+        out = torch.empty(M, N, device="cuda")
+        ops.gemm_nt(A, Bm, passes=1, act=ops.ACT_GELU_BWD, aux_in=z, out_f32=out)
+        zd = z.float().double().cpu().requires_grad_(True)
+        F.gelu(zd).sum().backward()
+        assert rel(out, (ref - bias) * zd.grad) < 5e-6
+
+
 @pytest.mark.parametrize("passes", [3, 1])
 @pytest.mark.parametrize("Mtok,N,K,ksplit", [(6280, 768, 256, None), (1000, 256, 768, 1), (130, 512, 256, 2), (25120, 256, 256, 28)])
 def test_gemm_tn_wgrad(ops, passes, Mtok, N, K, ksplit):

@@ -1,30 +1,51 @@
-"""Per-block timeline of gemm_big (diagnostic): EGV_GEMM_DBG=200 python tools/gemm_trace.py M N K"""
-import os, sys, torch
+"""Per-output-tile timeline of gemm_big (diagnostic): python tools/gemm_trace.py M N K [tn [ksplit]]
+Each persistent workgroup stamps s_memrealtime (100 MHz) at tile start / first MFMA / end of main loop / end of epilogue
+(EGV_GEMM_DBG=200: results are not stored)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
 os.environ["EGV_GEMM_DBG"] = "200"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from egovlp_amd import ops
+from egovlp_amd import _lib, ops  # noqa: E402
+
 m, n, k = [int(x) for x in sys.argv[1:4]]
-a = ops.split_f32(torch.rand(m, k, device="cuda") * 2 - 1, 1)[0]
-b = ops.split_f32(torch.rand(n, k, device="cuda") * 2 - 1, 1)[0]
+tn = len(sys.argv) > 4 and sys.argv[4] == "tn"
+ksplit = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+if tn:
+    a = ops.split_f32(torch.rand(k, m, device="cuda") * 2 - 1, 1)[0]
+    b = ops.split_f32(torch.rand(k, n, device="cuda") * 2 - 1, 1)[0]
+else:
+    a = ops.split_f32(torch.rand(m, k, device="cuda") * 2 - 1, 1)[0]
+    b = ops.split_f32(torch.rand(n, k, device="cuda") * 2 - 1, 1)[0]
 out = torch.empty(m, n, device="cuda")
-nb = 4096
-ts = torch.zeros(nb * 4, dtype=torch.int64, device="cuda")
+partial = torch.empty(ksplit * (m * n + m), device="cuda") if ksplit > 1 else None
+ts = torch.zeros(8192 * 4, dtype=torch.int64, device="cuda")
+d = _lib.GemmDesc()
+d.a_hi, d.lda, d.b_hi, d.ldb = a.hi.data_ptr(), a.ld, b.hi.data_ptr(), b.ld
+d.M, d.N, d.K, d.passes, d.alpha, d.act = m, n, k, 1, 1.0, 0
+d.out_f32, d.ldo = out.data_ptr(), n
+d.ksplit, d.partial = ksplit, (partial.data_ptr() if partial is not None else None)
+d.trans = int(tn)
+d.aux_out = ts.data_ptr()
 for it in range(3):
     ts.zero_()
     torch.cuda.synchronize()
-    ops.gemm_nt(a, b, passes=1, out_f32=out, aux_out=ts.view(torch.float32))
+    _lib.check(_lib.lib().egv_gemm_nt(C.byref(d), torch.cuda.current_stream().cuda_stream), "egv_gemm_nt")
     torch.cuda.synchronize()
 t = ts.view(-1, 4).cpu()
 t = t[t[:, 0] > 0].double() / 100.0   # us
 t0 = t[:, 0].min()
 t = t - t0
-order = torch.argsort(t[:, 0])
-t = t[order]
+t = t[torch.argsort(t[:, 0])]
 nblk = t.shape[0]
-print(f"M={m} N={n} K={k}: {nblk} blocks, kernel span {t[:,3].max():.1f} us")
-print("start times (us): p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f" % tuple(t[:, 0].quantile(torch.tensor([0, .25, .5, .75, 1.0], dtype=torch.float64)).tolist()))
+print(f"M={m} N={n} K={k} tn={tn} ksplit={ksplit}: {nblk} tiles, kernel span {t[:,3].max():.1f} us")
+q = torch.tensor([0, .25, .5, .75, 1.0], dtype=torch.float64)
+print("tile start (us): p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f" % tuple(t[:, 0].quantile(q).tolist()))
 print("prologue  (us): mean %.2f max %.2f" % ((t[:, 1] - t[:, 0]).mean(), (t[:, 1] - t[:, 0]).max()))
 print("main loop (us): mean %.2f min %.2f max %.2f" % ((t[:, 2] - t[:, 1]).mean(), (t[:, 2] - t[:, 1]).min(), (t[:, 2] - t[:, 1]).max()))
 print("epilogue  (us): mean %.2f max %.2f" % ((t[:, 3] - t[:, 2]).mean(), (t[:, 3] - t[:, 2]).max()))
-for i in list(range(0, min(nblk, 12))) + list(range(max(0, nblk - 6), nblk)):
-    print("  blk#%4d start %7.2f  pro %6.2f  loop %7.2f  epi %6.2f  end %7.2f" % (i, t[i, 0], t[i, 1] - t[i, 0], t[i, 2] - t[i, 1], t[i, 3] - t[i, 2], t[i, 3]))
+for i in list(range(0, min(nblk, 6))) + list(range(max(0, nblk - 4), nblk)):
+    print("  tile#%4d start %7.2f  pro %6.2f  loop %7.2f  epi %6.2f  end %7.2f" % (i, t[i, 0], t[i, 1] - t[i, 0], t[i, 2] - t[i, 1], t[i, 3] - t[i, 2], t[i, 3]))
