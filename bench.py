@@ -39,7 +39,7 @@ def build_model(arch, model_frames):
     return m
 
 
-def cpu_baseline(B=4, T=4, L=32):
+def cpu_baseline(B=16, T=4, L=32):
     """The oracle (fp32 PyTorch-on-CPU restatement of the reference, pinned to reference outputs) timed on the
     host cores of this box: one fwd+bwd+loss of the same workload at a bounded batch."""
     from egovlp_amd.model.schema import state_dict_schema

@@ -98,34 +98,49 @@ __global__ __launch_bounds__(256) void relu_split_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// patch gather (im2col for a PxP / stride P conv): one thread moves 4 consecutive pixels of one patch row.
-// Source rows are W*4 B contiguous, so a wave reads 64*16 B = 1 KiB of one image row segment: coalesced.
+// patch gather (im2col for a PxP / stride P conv): one thread moves G consecutive pixels of one patch row (G = 4 when
+// P % 4 == 0 -- ViT-B/16 -- else 2 -- ViT-L/14).  Source rows are W*4 B contiguous, so a wave reads one image row
+// segment: coalesced.  Columns K .. lda-1 of the output planes (K padded to the GEMM's k-tile) are left untouched:
+// the caller zero-fills them once.
+template <int G>
 __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ video, int BT, int C, int H, int W,
                                                            int P, bf16_t* __restrict__ ahi, bf16_t* __restrict__ alo,
                                                            long lda) {
-  // thread -> (image bt, channel c, image row y, 4-pixel group xg)
-  const int W4 = W / 4;
-  const long total = (long)BT * C * H * W4;
+  // thread -> (image bt, channel c, image row y, G-pixel group xg)
+  const int WG = W / G;
+  const long total = (long)BT * C * H * WG;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int xg = (int)(i % W4);
-  long t = i / W4;
+  const int xg = (int)(i % WG);
+  long t = i / WG;
   const int y = (int)(t % H);
   t /= H;
   const int c = (int)(t % C);
   const int bt = (int)(t / C);
-  const f32x4_t v = *(const f32x4_t*)(video + (((long)bt * C + c) * H + y) * W + xg * 4);
+  const float* src = video + (((long)bt * C + c) * H + y) * W + xg * G;
+  float v[G];
+  if (G == 4) {
+    const f32x4_t q = *(const f32x4_t*)src;
+    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+  } else {
+    v[0] = src[0]; v[1] = src[1];
+  }
   const int gw = W / P, gh = H / P;
   const int py = y / P, iy = y % P;
-  const int x = xg * 4;
+  const int x = xg * G;
   const int px = x / P, ix = x % P;
   const long row = ((long)bt * gh + py) * gw + px;
   const int col = (c * P + iy) * P + ix;
-  bf16_t h[4], l[4];
+  bf16_t h[G], l[G];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
-  *(u32x2_t*)(ahi + row * lda + col) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
-  if (alo) *(u32x2_t*)(alo + row * lda + col) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+  for (int e = 0; e < G; ++e) split_bf16(v[e], h[e], l[e]);
+  if (G == 4) {
+    *(u32x2_t*)(ahi + row * lda + col) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+    if (alo) *(u32x2_t*)(alo + row * lda + col) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+  } else {
+    *(uint32_t*)(ahi + row * lda + col) = pack2(h[0], h[1]);
+    if (alo) *(uint32_t*)(alo + row * lda + col) = pack2(l[0], l[1]);
+  }
 }
 
 // x[b, s, :] for s = 0: cls + pos[0]; s = 1 + f*n + i: pe[(b*T+f)*n + i] + pos[1+i] + temporal[f]
@@ -283,10 +298,16 @@ extern "C" int egv_relu_split(const float* x, int64_t ldx, int32_t rows, int32_t
 
 extern "C" int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
                                 egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream) {
-  if (!video || !a_hi || P % 4 != 0 || W % P != 0 || H % P != 0) return EGV_ERR_ARG;
-  const long total = (long)BT * C * H * (W / 4);
-  EGV_LAUNCH(patch_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C,
-                     H, W, P, a_hi, a_lo, lda);
+  if (!video || !a_hi || P % 2 != 0 || W % P != 0 || H % P != 0 || lda % 2 != 0) return EGV_ERR_ARG;
+  if (P % 4 == 0) {
+    const long total = (long)BT * C * H * (W / 4);
+    EGV_LAUNCH(patch_gather_kernel<4>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C, H, W, P,
+               a_hi, a_lo, lda);
+  } else {
+    const long total = (long)BT * C * H * (W / 2);
+    EGV_LAUNCH(patch_gather_kernel<2>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C, H, W, P,
+               a_hi, a_lo, lda);
+  }
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

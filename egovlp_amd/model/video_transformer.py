@@ -172,8 +172,13 @@ class _PatchTokensFn(torch.autograd.Function):
         Pp = Precision.fwd_passes
         _GRAD_PLANES.clear()
         a = ops.patch_gather(video.contiguous(), P_, Pp)
+        K = proj_w[0].numel()
+        if a.cols == K:
+            w_pl = wc.get(proj_w, need_t=False)[0]
+        else:   # ViT-L/14: K = 588 is zero-padded to the 64-deep k-tile on both operands
+            w_pl = ops.split_f32(torch.nn.functional.pad(proj_w.detach().reshape(D, K), (0, a.cols - K)), Pp)[0]
         pe = torch.empty((a.rows, D), dtype=torch.float32, device=video.device)
-        ops.gemm_nt(a, wc.get(proj_w, need_t=False)[0], passes=Pp, bias=proj_b, out_f32=pe)
+        ops.gemm_nt(a, w_pl, passes=Pp, bias=proj_b, out_f32=pe)
         x = ops.assemble_tokens(pe, cls_token, pos_embed, temporal_embed, B, T, n, D)
         ctx.geom, ctx.a, ctx.Pp = geom, a, Pp
         ctx.wshape = proj_w.shape
@@ -186,6 +191,9 @@ class _PatchTokensFn(torch.autograd.Function):
         _GRAD_PLANES.clear()      # block 0's input-gradient planes have no consumer
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
         _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False)
+        K = ctx.wshape[1] * ctx.wshape[2] * ctx.wshape[3]
+        if d_w.shape[1] != K:
+            d_w = d_w[:, :K].contiguous()      # drop the zero-padded k columns
         return None, None, None, d_w.view(ctx.wshape), d_b, d_cls, d_pos, d_tmp
 
 

@@ -277,10 +277,13 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
 
 # ------------------------------------------------------------------------------------------ video tokens
 def patch_gather(video5d, P, passes) -> Planes:
+    """im2col planes [B*T*patches, K = C*P*P]; K is padded with zero columns to a multiple of 64 (the GEMM k-tile;
+    588 -> 640 for ViT-L/14), `cols` of the returned planes is the PADDED width."""
     B, T, Cc, H, W = video5d.shape
     rows = B * T * (H // P) * (W // P)
     K = Cc * P * P
-    pl = empty_planes(rows, K, passes, video5d.device)
+    Kp = (K + 63) // 64 * 64
+    pl = empty_planes(rows, Kp, passes, video5d.device, zero=(Kp != K))
     check(_lib.lib().egv_patch_gather(_p(video5d), B * T, Cc, H, W, P, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
           "egv_patch_gather")
     return pl

@@ -163,3 +163,39 @@ def test_train_step_matches_oracle(full):
         print("  update %-55s rel %.2e" % (name, r))
         assert r < 2e-2, name      # Adam's m/sqrt(v) is sign-like at step 1: tiny grads flip easily
     m.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("name,kw,T,B", [
+    ("config4_T16", dict(img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, num_frames=16), 16, 1),
+    ("config5_vitl14", dict(img_size=224, patch_size=14, embed_dim=1024, depth=24, num_heads=16, num_frames=4), 4, 1),
+])
+def test_other_baseline_configs_video_encoder_matches_oracle(name, kw, T, B):
+    """BASELINE configs 4 (16 frames: temporal attention 16 x 17, S = 3137) and 5 (ViT-L/14: D = 1024, 24 blocks, 257 keys):
+    video encoder forward + a few parameter gradients vs the fp32 CPU oracle at a small batch, parity mode."""
+    from egovlp_amd.model.video_transformer import SpaceTimeTransformer
+    from egovlp_amd.ops import Precision
+    Precision.set("bf16x3")
+    net = SpaceTimeTransformer(num_classes=0, time_init="rand", **kw)
+    sd = synth_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=5)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().train()
+    g = torch.Generator().manual_seed(77)
+    video = torch.randn(B, T, 3, kw["img_size"], kw["img_size"], generator=g)
+    feats = net(video.cuda())
+    feats.square().sum().backward()
+    cfg = O.VideoCfg(img_size=kw["img_size"], patch_size=kw["patch_size"], embed_dim=kw["embed_dim"], depth=kw["depth"],
+                     num_heads=kw["num_heads"], num_frames=kw["num_frames"])
+    sdo = {"video_model." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.video_encoder(video, sdo, cfg)
+    ref.square().sum().backward()
+    r = rel(feats, ref)
+    print("%s: feats rel %.2e" % (name, r))
+    assert r < PARITY
+    last = kw["depth"] - 1
+    for pname in ("blocks.0.timeattn.qkv.weight", "blocks.%d.mlp.fc2.weight" % last, "patch_embed.proj.weight",
+                  "temporal_embed", "blocks.%d.attn.proj.bias" % (last // 2)):
+        got = dict(net.named_parameters())[pname].grad
+        want = sdo["video_model." + pname].grad
+        rg = rel(got, want)
+        print("  grad %-36s rel %.2e" % (pname, rg))
+        assert rg < 3 * PARITY, (pname, rg)

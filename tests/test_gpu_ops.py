@@ -60,6 +60,11 @@ def test_patch_gather_and_assemble(ops):
     a = ops.patch_gather(video.cuda(), P, 3)
     ref = F.unfold(video.view(B * T, C, H, W), kernel_size=P, stride=P).transpose(1, 2).reshape(-1, C * P * P)
     assert rel(a.float(), ref) < 1e-5
+    # ViT-L/14 geometry: P % 4 != 0 (2-pixel groups) and K = 588 zero-padded to the 64-deep k-tile
+    v14 = torch.randn(2, 2, 3, 28, 42, generator=g)
+    a14 = ops.patch_gather(v14.cuda(), 14, 3)
+    r14 = F.unfold(v14.view(4, 3, 28, 42), kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588)
+    assert a14.cols == 640 and rel(a14.float()[:, :588], r14) < 1e-5 and float(a14.float()[:, 588:].abs().max()) == 0.0
     n = (H // P) * (W // P)
     pe = torch.randn(B * T * n, D, generator=g)
     cls, pos, tmp = torch.randn(1, 1, D, generator=g), torch.randn(1, n + 1, D, generator=g), torch.randn(1, 5, D, generator=g)
