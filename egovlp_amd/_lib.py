@@ -48,7 +48,7 @@ PROTOTYPES = {
     "egv_transpose_planes": (i32, [c_p, c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p]),
     "egv_layernorm_fwd": (i32, [c_p, c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
     "egv_layernorm_bwd_parts": (i32, [i32]),
-    "egv_layernorm_bwd": (i32, [c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "egv_layernorm_bwd": (i32, [c_p, c_p, c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_patch_gather": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, i64, c_p]),
     "egv_assemble_tokens": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p]),
     "egv_assemble_tokens_bwd": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),
@@ -58,8 +58,8 @@ PROTOTYPES = {
     "egv_divided_attn_bwd_work_floats": (i64, [i32, i32, i32, i32]),
     "egv_embed_fwd": (i32, [c_p, c_p, c_p, i32, i32, i32, c_p, c_p]),
     "egv_embed_bwd": (i32, [c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p]),
-    "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
-    "egv_text_attn_bwd": (i32, [c_p, c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),
+    "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, i64, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
+    "egv_text_attn_bwd": (i32, [c_p, c_p, c_p, i64, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p, c_p, i64, c_p, c_p]),
     "egv_egonce_fwd_bwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, f32, f32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_egonce_work_floats": (i64, [i32, i32]),
     "egv_sim_matrix_fwd": (i32, [c_p, c_p, i32, i32, i32, f32, c_p, c_p, c_p, c_p, c_p]),

@@ -381,23 +381,24 @@ int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf
   return dispatch_bwd<MODE_SPACE>(g, gr, B * T * H, passes, s);
 }
 
-extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v, const int64_t* mask,
+extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
                                  const float* d_out, const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
-                                 float* dq, float* dk, float* dv, float* delta_work, void* stream) {
+                                 float* dq, float* dk, float* dv, int64_t lddqkv, float* delta_work, void* stream) {
   if (!q || !k || !v || !mask || !d_out || !lse || !dq || !dk || !dv || !delta_work) return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   AttGeom g;
   const long HD = (long)H * ATT_D;
   g.q = q; g.k = k; g.v = v;
   g.ph = g.pl = nullptr;
-  g.tok_stride = HD;
+  g.tok_stride = ldqkv;
   g.B = B; g.T = 1; g.n = L; g.H = H; g.S = L;
   g.nq = L; g.nk = L;
   g.mask = (const long long*)mask;
+  if (ldqkv < HD || lddqkv < HD || ldqkv % 4 != 0 || lddqkv % 4 != 0) return EGV_ERR_ARG;
   AttGrad gr;
   gr.dq = dq; gr.dk = dk; gr.dv = dv;
   gr.gh = gr.gl = nullptr;
-  gr.tok_stride = HD;
+  gr.tok_stride = lddqkv;
   gr.d_out = d_out; gr.doh = gr.dol = nullptr; gr.do_stride = HD;
   gr.lse = lse; gr.delta = delta_work; gr.dcls = nullptr;
   return dispatch_bwd<MODE_TEXT>(g, gr, B * H, passes, (hipStream_t)stream);

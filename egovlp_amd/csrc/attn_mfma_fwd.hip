@@ -201,9 +201,9 @@ int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, i
   return dispatch_fwd<MODE_SPACE>(g, B * T * H, passes, out_hi, out_lo, HD, lse, cls_ws, s);
 }
 
-extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v, const int64_t* mask, int32_t B,
-                                 int32_t L, int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse,
-                                 void* stream) {
+extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
+                                 int32_t B, int32_t L, int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo,
+                                 float* lse, void* stream) {
   if (!q || !k || !v || !out_hi || B <= 0 || L <= 0 || H <= 0) return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   if (passes == 3 && !out_lo) return EGV_ERR_ARG;
@@ -211,10 +211,10 @@ extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v,
   const long HD = (long)H * ATT_D;
   g.q = q; g.k = k; g.v = v;
   g.ph = g.pl = nullptr;
-  g.tok_stride = HD;
+  g.tok_stride = ldqkv;
   g.B = B; g.T = 1; g.n = L; g.H = H; g.S = L;
   g.nq = L; g.nk = L;
   g.mask = (const long long*)mask;
-  if (!mask) return EGV_ERR_ARG;
+  if (!mask || ldqkv < HD || ldqkv % 4 != 0) return EGV_ERR_ARG;
   return dispatch_fwd<MODE_TEXT>(g, B * H, passes, out_hi, out_lo, HD, lse, nullptr, (hipStream_t)stream);
 }

@@ -74,11 +74,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 // backward: each wave walks rows wave_id, wave_id + nwaves, ...; per-lane partial dgamma/dbeta stay in
 // registers; one LDS reduction per block at the end -> work[block][2][cols]; a second kernel sums blocks.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
-    const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+    const float* __restrict__ dy, const bf16_t* __restrict__ dyh, const bf16_t* __restrict__ dyl, long lddy,
+    const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int cols, const float* __restrict__ add1,
     const float* __restrict__ add2, float* __restrict__ dx, long lddx, bf16_t* __restrict__ dxh,
-    bf16_t* __restrict__ dxl, float* __restrict__ work) {
-  __shared__ float red[2][4][MAXV * 256];  // [dgamma/dbeta][wave][col]  32 KiB
+    bf16_t* __restrict__ dxl, float* __restrict__ work, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[2][4][MAXV * 256];
+  if (blockIdx.x == 0) {   // the reduce kernel (next launch on the stream) accumulates into these with atomics
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      if (dgamma) dgamma[c] = 0.f;
+      if (dbeta) dbeta[c] = 0.f;
+    }
+  }  // [dgamma/dbeta][wave][col]  32 KiB
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nv = cols / 4;
@@ -102,7 +109,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       gy[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       xh[i] = gy[i];
       if (c4 < nv) {
-        const f32x4_t d = *(const f32x4_t*)(dy + (long)row * lddy + c4 * 4);
+        f32x4_t d;
+        if (dyh) {   // dy as split-bf16 planes (written by the dgrad GEMM epilogue): half the bytes of fp32
+          const u32x2_t a = *(const u32x2_t*)(dyh + (long)row * lddy + c4 * 4);
+          d = (f32x4_t){__uint_as_float(a[0] << 16), __uint_as_float(a[0] & 0xffff0000u), __uint_as_float(a[1] << 16),
+                        __uint_as_float(a[1] & 0xffff0000u)};
+          if (dyl) {
+            const u32x2_t b = *(const u32x2_t*)(dyl + (long)row * lddy + c4 * 4);
+            d += (f32x4_t){__uint_as_float(b[0] << 16), __uint_as_float(b[0] & 0xffff0000u), __uint_as_float(b[1] << 16),
+                           __uint_as_float(b[1] & 0xffff0000u)};
+          }
+        } else {
+          d = *(const f32x4_t*)(dy + (long)row * lddy + c4 * 4);
+        }
         const f32x4_t xv = *(const f32x4_t*)(x + (long)row * ldx + c4 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -201,19 +220,18 @@ extern "C" int egv_layernorm_bwd_parts(int32_t rows) {
   return b < 512 ? b : 512;
 }
 
-extern "C" int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+extern "C" int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
+                                 const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, int32_t rows, int32_t cols, const float* add1,
                                  const float* add2, float* dx, int64_t lddx, egv_bf16* dx_hi, egv_bf16* dx_lo,
                                  float* dgamma, float* dbeta, float* work, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !work) return EGV_ERR_ARG;
+  if ((!dy && !dy_hi) || !x || !gamma || !mean || !rstd || !dx || !work) return EGV_ERR_ARG;
   if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
   const int parts = egv_layernorm_bwd_parts(rows);
   hipStream_t s = (hipStream_t)stream;
-  EGV_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, lddy, x, ldx, gamma, mean, rstd, rows,
-                     cols, add1, add2, dx, lddx, dx_hi, dx_lo, work);
+  EGV_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, dy_hi, dy_lo, lddy, x, ldx, gamma, mean, rstd, rows,
+             cols, add1, add2, dx, lddx, dx_hi, dx_lo, work, dgamma, dbeta);
   EGV_CHECK_LAUNCH();
-  if (dgamma && hipMemsetAsync(dgamma, 0, sizeof(float) * cols, s) != hipSuccess) return EGV_ERR_LAUNCH;
-  if (dbeta && hipMemsetAsync(dbeta, 0, sizeof(float) * cols, s) != hipSuccess) return EGV_ERR_LAUNCH;
   EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 63) / 64, (parts + 63) / 64), dim3(256), 0, s, work, parts,
              cols, dgamma, dbeta);
   EGV_CHECK_LAUNCH();

@@ -77,12 +77,11 @@ class _TextLayerFn(torch.autograd.Function):
             return wc.get(p, need_t=False)[0]
 
         x_pl, _, _ = ops.split_f32(x2, P)
-        q = torch.empty((M, D), dtype=torch.float32, device=dev)
-        k = torch.empty_like(q)
-        v = torch.empty_like(q)
-        ops.gemm_nt(x_pl, W(q_w), passes=P, bias=q_b, out_f32=q)
-        ops.gemm_nt(x_pl, W(k_w), passes=P, bias=k_b, out_f32=k)
-        ops.gemm_nt(x_pl, W(v_w), passes=P, bias=v_b, out_f32=v)
+        # q_lin / k_lin / v_lin as ONE [M, 768] x [2304, 768]^T GEMM (M = B*L = 1024 is latency-bound: three launches -> one)
+        qkv = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
+        ops.gemm_nt(x_pl, wc.get_cat((q_w, k_w, v_w), need_t=False)[0], passes=P, bias=torch.cat((q_b, k_b, v_b)),
+                    out_f32=qkv)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         c_pl, lse = ops.text_attn_fwd(q, k, v, mask, B, L, H, P)
         s1 = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(c_pl, W(o_w), passes=P, bias=o_b, residual=x2, out_f32=s1)
@@ -97,13 +96,13 @@ class _TextLayerFn(torch.autograd.Function):
         if train:
             ctx.geom, ctx.wc, ctx.P = geom, wc, P
             ctx.planes = (x_pl, c_pl, sa_pl, h)
-            ctx.save_for_backward(mask, q, k, v, lse, s1, mean1, rstd1, z, s2, mean2, rstd2,
+            ctx.save_for_backward(mask, qkv, lse, s1, mean1, rstd1, z, s2, mean2, rstd2,
                                   q_w, k_w, v_w, o_w, ln1_w, f1_w, f2_w, ln2_w)
         return out.view(B, L, D)
 
     @staticmethod
     def backward(ctx, g_out):
-        (mask, q, k, v, lse, s1, mean1, rstd1, z, s2, mean2, rstd2,
+        (mask, qkv, lse, s1, mean1, rstd1, z, s2, mean2, rstd2,
          q_w, k_w, v_w, o_w, ln1_w, f1_w, f2_w, ln2_w) = ctx.saved_tensors
         x_pl, c_pl, sa_pl, h = ctx.planes
         B, L, H, eps = ctx.geom
@@ -130,17 +129,15 @@ class _TextLayerFn(torch.autograd.Function):
         d_s1, d_ln1w, d_ln1b = ops.layernorm_bwd(d_sa, s1, ln1_w, mean1, rstd1)
         # attention output projection
         d_ctx, d_ow, d_ob = _lin_bwd(d_s1, c_pl, Wt(o_w), Pb)
-        dq, dk, dv = ops.text_attn_bwd(q, k, v, mask, d_ctx, lse, B, L, H, Pb)
-        # q/k/v projections; dx = d_s1 + dq.Wq + dk.Wk + dv.Wv chained through the residual epilogue
-        acc = d_s1
-        grads = []
-        for dy, w in ((dq, q_w), (dk, k_w), (dv, v_w)):
-            dy_pl = ops.split_f32(dy, Pb)[0]
-            _, dw, db = _lin_bwd(dy_pl, x_pl, None, Pb, need_dx=False)
-            nxt = torch.empty((M, D), dtype=torch.float32, device=G.device)
-            ops.gemm_nt(dy_pl, Wt(w), passes=Pb, residual=acc, out_f32=nxt, K=D)
-            acc = nxt
-            grads += [dw, db]
+        D3 = 3 * D
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        _, _, _, dqkv = ops.text_attn_bwd(q, k, v, mask, d_ctx, lse, B, L, H, Pb, fused_out=True)
+        # fused q/k/v projection backward: one wgrad (dW [2304, 768] + bias grads) and one dgrad chained onto d_s1
+        dqkv_pl = ops.split_f32(dqkv, Pb)[0]
+        _, dW3, db3 = _lin_bwd(dqkv_pl, x_pl, None, Pb, need_dx=False)
+        acc = torch.empty((M, D), dtype=torch.float32, device=G.device)
+        ops.gemm_nt(dqkv_pl, wc.get_cat((q_w, k_w, v_w), need_t=True)[1], passes=Pb, residual=d_s1, out_f32=acc, K=D3)
+        grads = [dW3[:D], db3[:D], dW3[D:2 * D], db3[D:2 * D], dW3[2 * D:], db3[2 * D:]]
         return (acc.view(B, L, D), None, None, None, *grads, d_ow, d_ob, d_ln1w, d_ln1b,
                 d_f1w, d_f1b, d_f2w, d_f2b, d_ln2w, d_ln2b)
 

@@ -253,11 +253,13 @@ def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, 
 
 def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=None, ldx=None, dx=None, lddx=None,
                   planes_passes=0):
-    """-> (dx [rows, cols] (= add1 + add2 + LN-backward), dgamma, dbeta[, Planes of dx when planes_passes in (1, 3)])."""
-    cols = dy2d.shape[-1]
-    rows = dy2d.shape[0] if rows is None else rows
+    """-> (dx [rows, cols] (= add1 + add2 + LN-backward), dgamma, dbeta[, Planes of dx when planes_passes in (1, 3)]).
+    dy2d: fp32 [rows, cols] or Planes (hi[, lo])."""
+    dy_pl = dy2d if isinstance(dy2d, Planes) else None
+    cols = dy_pl.cols if dy_pl is not None else dy2d.shape[-1]
+    rows = (dy_pl.rows if dy_pl is not None else dy2d.shape[0]) if rows is None else rows
     ldx = x2d.stride(0) if ldx is None else ldx
-    dev = dy2d.device
+    dev = x2d.device
     if dx is None:
         dx = torch.empty((rows, cols), dtype=torch.float32, device=dev)
         lddx = cols
@@ -266,7 +268,11 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
     parts = _lib.lib().egv_layernorm_bwd_parts(rows)
     work = torch.empty(2 * cols * parts, dtype=torch.float32, device=dev)
     pl = empty_planes(rows, cols, planes_passes, dev) if planes_passes else None
-    check(_lib.lib().egv_layernorm_bwd(_p(dy2d), dy2d.stride(0), _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
+    if dy_pl is not None:
+        dy_args = (None, _p(dy_pl.hi), _p(dy_pl.lo), dy_pl.ld)
+    else:
+        dy_args = (_p(dy2d), None, None, dy2d.stride(0))
+    check(_lib.lib().egv_layernorm_bwd(*dy_args, _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
                                        cols, _p(add1), _p(add2), _p(dx), lddx, _p(pl.hi) if pl else None,
                                        _p(pl.lo) if pl else None, _p(dg), _p(db), _p(work), _stream()),
           "egv_layernorm_bwd")
@@ -333,19 +339,28 @@ def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, m
 
 
 def text_attn_fwd(q, k, v, mask, B, L, H, passes):
+    """q, k, v: fp32 [B*L, H*64] tensors, or column-block views of one fused [B*L, 3*H*64] projection output."""
     out = empty_planes(B * L, H * 64, passes, q.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
-    check(_lib.lib().egv_text_attn_fwd(_p(q), _p(k), _p(v), _p(mask), B, L, H, passes, _p(out.hi), _p(out.lo),
-                                       _p(lse), _stream()), "egv_text_attn_fwd")
+    assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
+    check(_lib.lib().egv_text_attn_fwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), B, L, H, passes, _p(out.hi),
+                                       _p(out.lo), _p(lse), _stream()), "egv_text_attn_fwd")
     return out, lse
 
 
-def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes):
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False):
+    """-> (dq, dk, dv); with fused_out they are the column blocks of ONE [B*L, 3*H*64] tensor (returned 4th)."""
+    HD = H * 64
+    if fused_out:
+        dqkv = torch.empty((B * L, 3 * HD), dtype=torch.float32, device=q.device)
+        dq, dk, dv = dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:]
+    else:
+        dqkv = None
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     work = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
-    check(_lib.lib().egv_text_attn_bwd(_p(q), _p(k), _p(v), _p(mask), _p(d_out), _p(lse), B, L, H, passes, _p(dq),
-                                       _p(dk), _p(dv), _p(work), _stream()), "egv_text_attn_bwd")
-    return dq, dk, dv
+    check(_lib.lib().egv_text_attn_bwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), _p(d_out), _p(lse), B, L, H, passes,
+                                       _p(dq), _p(dk), _p(dv), dq.stride(0), _p(work), _stream()), "egv_text_attn_bwd")
+    return (dq, dk, dv, dqkv) if fused_out else (dq, dk, dv)
 
 
 def embed_fwd(ids, word, pos, D):

@@ -36,5 +36,18 @@ class WeightCache:
             self._c[key] = ent
         return ent[1], ent[2]
 
+    def get_cat(self, params, need_t: bool):
+        """Planes of the row-wise concatenation of several [N_i, K] weights (DistilBERT's q/k/v projections run as ONE
+        [3*768, 768] GEMM) -> (Planes [sum N_i, K], Planes [K, sum N_i] | None)."""
+        key = tuple(id(p) for p in params)
+        ver = tuple((p._version, EPOCH, p.data_ptr()) for p in params)
+        ent = self._c.get(key)
+        if ent is None or ent[0] != ver or (need_t and ent[2] is None):
+            w2 = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], dim=0)
+            pl, tp, _ = ops.split_f32(w2, 3, want_rowmajor=True, want_transposed=need_t or (ent is not None and ent[2] is not None))
+            ent = (ver, pl, tp)
+            self._c[key] = ent
+        return ent[1], ent[2]
+
     def clear(self):
         self._c.clear()

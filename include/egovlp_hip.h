@@ -88,10 +88,13 @@ int egv_layernorm_fwd(const float* x, const float* x_add, int64_t ldx, const flo
                       egv_bf16* y_hi, egv_bf16* y_lo, float* y_f32, int64_t ldy,
                       float* mean, float* rstd, void* stream);
 /* dx[r,:] = (add1 + add2)[r,:] + LN'(dy; x, gamma, mean, rstd)[r,:];  dgamma/dbeta [cols] overwritten.
+ * dy is given EITHER as fp32 (dy) OR as split-bf16 planes (dy_hi[, dy_lo]; dy == NULL) -- the dgrad GEMM that produces
+ * it can write planes directly; lddy is the leading dimension of whichever is used.
  * dx_hi/dx_lo (optional, contiguous [rows, cols]): the same dx as split-bf16 planes, i.e. already in the operand
  * format of the dgrad / wgrad GEMMs that consume it.  `work`: 2 * cols * egv_layernorm_bwd_parts(rows) floats.     */
 int egv_layernorm_bwd_parts(int32_t rows);
-int egv_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
+                      const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, int32_t rows, int32_t cols,
                       const float* add1, const float* add2, float* dx, int64_t lddx,
                       egv_bf16* dx_hi, egv_bf16* dx_lo, float* dgamma, float* dbeta, float* work, void* stream);
@@ -143,11 +146,15 @@ int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, int32_t L, in
 /* Masked multi-head attention (modeling_distilbert.py:122-203) on separate q,k,v [B, L, H*64] fp32;
  * mask [B, L] int64 (0 = padded key -> -inf).  Output split planes [B, L, H*64]; probs are recomputed
  * in backward from lse [B,H,L].                                                                     */
-int egv_text_attn_fwd(const float* q, const float* k, const float* v, const int64_t* mask, int32_t B, int32_t L,
-                      int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream);
-int egv_text_attn_bwd(const float* q, const float* k, const float* v, const int64_t* mask, const float* d_out,
-                      const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
-                      float* dq, float* dk, float* dv, float* delta_work /* B*H*L floats */, void* stream);
+int egv_text_attn_fwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask, int32_t B,
+                      int32_t L, int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse,
+                      void* stream);
+/* q, k, v (and dq, dk, dv) rows are ldqkv (lddqkv) floats apart: H*64 for separate tensors, 3*H*64 when they are the
+ * three column blocks of one fused [B*L, 3*H*64] projection output (one GEMM instead of three).                      */
+int egv_text_attn_bwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
+                      const float* d_out, const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
+                      float* dq, float* dk, float* dv, int64_t lddqkv, float* delta_work /* B*H*L floats */,
+                      void* stream);
 
 /* ---- contrastive head ---------------------------------------------------------------------------------
  * sim_matrix x3 + EgoNCE/NormSoftmaxLoss forward AND backward in one launch

@@ -212,6 +212,10 @@ def test_layernorm_fwd_bwd(ops, cols):
     assert rel(dx, xd.grad + add) < 1e-5
     assert rel(dxp.float(), xd.grad + add) < 1e-5 and torch.equal(dxp.hi.float(), dx.to(torch.bfloat16).float())
     assert rel(dg, wd.grad) < 1e-5 and rel(db, bd.grad) < 1e-5
+    # dy handed over as planes (what the dgrad GEMM epilogue writes)
+    dx2, dg2, db2 = ops.layernorm_bwd(planes_from(ops, dy, 3), x.cuda(), w.cuda(), mean, rstd, add1=add.cuda())
+    assert rel(dx2, xd.grad + add) < 2e-5 and rel(dg2, wd.grad) < 2e-5 and rel(db2, bd.grad) < 2e-5
+    assert rel(dg, wd.grad) < 1e-5 and rel(db, bd.grad) < 1e-5
 
 
 def test_layernorm_strided_cls_rows(ops):
