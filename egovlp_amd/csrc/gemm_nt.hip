@@ -210,11 +210,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int egv_gemm_nt_v2_launch(const egv_gemm_desc& p, hipStream_t s);          // gemm_nt_v2.hip
 int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant);  // gemm_big.hip
 bool egv_gemm_big_supports(const egv_gemm_desc& p);
-int egv_gemm_big_pick_mf(const egv_gemm_desc& p);
-int egv_gemm_x3_launch(const egv_gemm_desc& p, hipStream_t s, int mf);        // gemm_x3.hip
-bool egv_gemm_x3_supports(const egv_gemm_desc& p);
-int egv_gemm_duo_launch(const egv_gemm_desc& p, hipStream_t s);               // gemm_duo.hip
-bool egv_gemm_duo_supports(const egv_gemm_desc& p);
 
 // kernel choice: gemm_big (320/256 x 256 tile, k-tile 64) for the token-major GEMMs and every TN (wgrad) problem;
 // v1 (128x128, 2-stage) when M is too small to fill big tiles (DistilBERT, projections); v2 (256x128, BK = 32) only
@@ -228,7 +223,6 @@ static int gemm_variant(const egv_gemm_desc& p) {
   const bool big_ok = egv_gemm_big_supports(p);
   if (p.trans) return big_ok ? 3 : -1;
   if (forced == 1 || forced == 2) return forced;
-  if (forced == 6) return egv_gemm_duo_supports(p) ? 6 : (big_ok ? 3 : 1);
   if (forced >= 3 && big_ok) return forced;
   // big tiles only when there are enough of them to occupy the chip (DistilBERT's M = 1024 GEMMs make 12)
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
@@ -253,14 +247,8 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (variant == 6) {
-    const int rc = egv_gemm_duo_launch(p, s);
-    if (rc) return rc;
-  } else if (variant >= 3) {
-    // bf16x3 NT problems go to the fused three-product kernel (EGV_X3_FUSED=0: k-segment path of gemm_big, A/B only)
-    static const int x3_fused = getenv("EGV_X3_FUSED") ? atoi(getenv("EGV_X3_FUSED")) : 1;
-    const int rc = (x3_fused && egv_gemm_x3_supports(p)) ? egv_gemm_x3_launch(p, s, egv_gemm_big_pick_mf(p))
-                                                         : egv_gemm_big_launch(p, s, variant);
+  if (variant >= 3) {
+    const int rc = egv_gemm_big_launch(p, s, variant);
     if (rc) return rc;
   } else if (variant == 2) {
     const int rc = egv_gemm_nt_v2_launch(p, s);
