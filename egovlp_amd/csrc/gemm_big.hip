@@ -179,17 +179,25 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   int tn_col = 0;   // TN: this lane's source column (elements) before the per-piece unit XOR
   if (!TN) {
     const int chunk = (lane & 7) ^ (lane >> 3);                 // LDS position (lane&7) holds source chunk pos^(row&7)
-    a_voff = (long)(wave * MF * 8 + (lane >> 3)) * p.lda + chunk * 8;
-    b_voff = (long)(wave * 4 * 8 + (lane >> 3)) * p.ldb + chunk * 8;
+    a_voff = (long)(lane >> 3) * p.lda + chunk * 8;      // + (piece row base) * lda per piece
+    b_voff = (long)(lane >> 3) * p.ldb + chunk * 8;
   } else {
     // piece I = wave*4 + q covers k-rows 2I, 2I+1 of the tile; this lane: row 2I + (lane>>5), LDS chunk lane&31.
     // source 32-B unit = (LDS unit) ^ (row & 7) = ((lane&31)>>1) ^ ((2q + (lane>>5)) & 7); the q part is XOR-ed in per piece.
     const int r = lane >> 5;
     const int u = ((lane & 31) >> 1) ^ r;
     tn_col = ((u << 1) | (lane & 1)) * 8;
-    a_voff = (long)(wave * 8 + r) * p.lda;
-    b_voff = (long)(wave * 8 + r) * p.ldb;
+    a_voff = (long)r * p.lda;                             // + (piece row base) * lda per piece
+    b_voff = (long)r * p.ldb;
   }
+  // Which waves issue the LDS-DMA: only waves 0-3 (one per SIMD), two 1/8 shares of the tile each, so that after the
+  // k-tile barrier the OTHER wave of every SIMD goes straight back to its MFMAs instead of all eight queueing ~9 DMA
+  // issues (~60 cycles each) with the matrix pipes idle: main loop 91 -> 81.5 us on fc2-forward (tools/gemm_trace.py).
+  // EGV_GEMM_DBG bit 16 restores "every wave stages its own share" (A/B diagnostics).
+  const int ld_mode = (dbg & 0x10000) ? 0 : 2;
+  const bool loader = ld_mode == 0 || wave < 4;
+  const int nshare = ld_mode == 0 ? 1 : 2;
+  const int vw0 = ld_mode == 0 ? wave : 2 * (wave & 3);
 
   // ---- fragment read offsets (bytes within a stage) ---------------------------------------------------------
   int a_rd0, a_rd1, b_rd0, b_rd1;   // NT: k-step 0 / 1 bases;  TN: a_rd0 / b_rd0 only (k-step is an immediate)
@@ -295,26 +303,33 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 
   auto stage = [&](int buf) {   // one k-tile of tile (sm0, sn0) -> LDS stage `buf`
     char* lds = smem + buf * STAGE;
-    if (!TN) {
-      const bf16_t* ab = seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * KT;
-      const bf16_t* bb = seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * KT;
+    if (loader) {
+      for (int sh = 0; sh < nshare; ++sh) {
+        const int vw = vw0 + sh;                 // the "virtual wave" whose share of the tile is staged
+        if (!TN) {
+          const bf16_t* ab = seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * KT;
+          const bf16_t* bb = seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * KT;
 #pragma unroll
-      for (int q = 0; q < GA; ++q) glds16(ab + a_voff + (long)q * 8 * p.lda, lds + (wave * GA + q) * 1024);
+          for (int q = 0; q < GA; ++q)
+            glds16(ab + a_voff + (long)(vw * GA + q) * 8 * p.lda, lds + (vw * GA + q) * 1024);
 #pragma unroll
-      for (int q = 0; q < GB; ++q) glds16(bb + b_voff + (long)q * 8 * p.ldb, lds + A_BYTES + (wave * GB + q) * 1024);
-    } else {
-      const bf16_t* ab = seg_a(st_seg) + (long)st_kt * KT * p.lda + sm0;
-      const bf16_t* bb = seg_b(st_seg) + (long)st_kt * KT * p.ldb + sn0;
-      const int krow = st_kt * KT + wave * 8 + (lane >> 5);     // + 2q
+          for (int q = 0; q < GB; ++q)
+            glds16(bb + b_voff + (long)(vw * GB + q) * 8 * p.ldb, lds + A_BYTES + (vw * GB + q) * 1024);
+        } else {
+          const bf16_t* ab = seg_a(st_seg) + (long)st_kt * KT * p.lda + sm0;
+          const bf16_t* bb = seg_b(st_seg) + (long)st_kt * KT * p.ldb + sn0;
+          const int krow = st_kt * KT + vw * 8 + (lane >> 5);     // + 2q
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool ok = krow + 2 * q < p.K;
-        const int col = tn_col ^ (((2 * q) & 7) << 4);   // 32-B unit (16 elements) index ^= (2q) & 7
-        const bf16_t* sa = ab + a_voff + (long)(2 * q) * p.lda + col;
-        const bf16_t* sb = bb + b_voff + (long)(2 * q) * p.ldb + col;
-        const void* za = (const char*)g_zero_page + lane * 16;
-        glds16(ok ? (const void*)sa : za, lds + (wave * 4 + q) * 1024);
-        glds16(ok ? (const void*)sb : za, lds + A_BYTES + (wave * 4 + q) * 1024);
+          for (int q = 0; q < 4; ++q) {
+            const bool ok = krow + 2 * q < p.K;
+            const int col = tn_col ^ (((2 * q) & 7) << 4);   // 32-B unit (16 elements) index ^= (2q) & 7
+            const bf16_t* sa = ab + a_voff + (long)(vw * 8 + 2 * q) * p.lda + col;
+            const bf16_t* sb = bb + b_voff + (long)(vw * 8 + 2 * q) * p.ldb + col;
+            const void* za = (const char*)g_zero_page + lane * 16;
+            glds16(ok ? (const void*)sa : za, lds + (vw * 4 + q) * 1024);
+            glds16(ok ? (const void*)sb : za, lds + A_BYTES + (vw * 4 + q) * 1024);
+          }
+        }
       }
     }
     if (++st_kt == skt_end) {
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   if (nt > 0) stage(0);
 
   for (;;) {
-    if (dbg == 200) ts0 = __builtin_amdgcn_s_memrealtime();
+    if ((dbg & 0xfff) == 200) ts0 = __builtin_amdgcn_s_memrealtime();
     // ================= main loop of tile v: k-tile 0 is in flight or landed in stage 0 ==========================
     f32x4_t acc[MF][NFW];
 #pragma unroll
@@ -346,7 +361,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     if (nt > 0) {
       if (nt > 1) {
         stage(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
+        if (ld_mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       commit_b(Bq[0]);
       commit_a(A[0]);
     }
-    if (dbg == 200) ts1 = __builtin_amdgcn_s_memrealtime();
+    if ((dbg & 0xfff) == 200) ts1 = __builtin_amdgcn_s_memrealtime();
 
     int cur_seg = 0, cur_kt = kt_begin;
     for (int t = 0; t < nt; ++t) {
@@ -384,8 +400,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             if (t + 1 < nt) {
               // tile t+1 (this wave's DMA pieces) landed; all of this wave's reads of stage t&1 have returned
               asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-              __builtin_amdgcn_s_barrier();
-              if (t + 2 < nt) stage(t & 1);
+              if (!(dbg & 0x1000)) __builtin_amdgcn_s_barrier();          // DIAGNOSTIC bits (timing only, results invalid):
+              if (t + 2 < nt && !(dbg & 0x2000)) stage(t & 1);            // 0x1000 no k-tile barrier, 0x2000 no DMA in the loop
               issue_b(STAGE - sb, 0, 0, Bq[0]);
               issue_a(STAGE - sb, 0, A[0]);
             }
@@ -424,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         ++cur_seg;
       }
     }
-    if (dbg == 200) ts2 = __builtin_amdgcn_s_memrealtime();
+    if ((dbg & 0xfff) == 200) ts2 = __builtin_amdgcn_s_memrealtime();
 
     // ================= hand-over: every wave is done with both LDS stages =========================================
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       for (int j = 0; j < NFW; ++j) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) *(f32x4_t*)(ep + wr_off + i * 16 * EP_LD * 4) = acc[i][j];
-        if (dbg >= 100) continue;   // EXPERIMENT: nothing stored (main-loop-only timing)
+        if ((dbg & 0xfff) >= 100) continue;   // EXPERIMENT: nothing stored (main-loop-only timing)
 #pragma unroll 1
         for (int r = 0; r < MF; ++r) {
           const int row = r * 16 + rd_row;
@@ -471,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         }
       }
     }
-    if (dbg == 200 && tid == 0) {
+    if ((dbg & 0xfff) == 200 && tid == 0) {
       unsigned long long* tsb = (unsigned long long*)p.aux_out + (long)v * 4;
       tsb[0] = ts0; tsb[1] = ts1; tsb[2] = ts2; tsb[3] = __builtin_amdgcn_s_memrealtime();
     }

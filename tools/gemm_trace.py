@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-os.environ["EGV_GEMM_DBG"] = "200"
+os.environ["EGV_GEMM_DBG"] = str(200 + int(os.environ.get("TRACE_DIAG", "0"), 0))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egovlp_amd import _lib, ops  # noqa: E402
 
