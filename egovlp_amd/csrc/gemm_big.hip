@@ -160,6 +160,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   const int wm = wave >> 1, wn = wave & 1;
   // DIAGNOSTIC (EGV_GEMM_DBG=200, tools/gemm_trace.py): per-tile 100 MHz timestamps into p.aux_out
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  // DIAGNOSTIC (`make stamps` build, -DEGV_GEMM_STAMPS, + EGV_GEMM_DBG bit 0x4000): workgroup 0 stamps s_memtime around the
+  // k-tile hand-over of its first output tile, per wave, into 16 KiB of LDS behind the two stages ([wave][k-tile < 64]
+  // [4 stamps]); dumped after the tile.  Compiled out of the product library.
+#ifdef EGV_GEMM_STAMPS
+  const bool stamp_on = (dbg & 0x4000) && blockIdx.x == 0;
+#else
+  constexpr bool stamp_on = false;
+#endif
+  unsigned long long* stamp_lds = (unsigned long long*)(smem + 2 * STAGE) + wave * 256;
+  auto stamp = [&](int t, int i) {
+    if (stamp_on && t < 64 && lane == 0) stamp_lds[t * 4 + i] = __builtin_amdgcn_s_memtime();
+  };
 
   const int tiles_n = (p.N + BNB - 1) / BNB;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -194,10 +206,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   // k-tile barrier the OTHER wave of every SIMD goes straight back to its MFMAs instead of all eight queueing ~9 DMA
   // issues (~60 cycles each) with the matrix pipes idle: main loop 91 -> 81.5 us on fc2-forward (tools/gemm_trace.py).
   // EGV_GEMM_DBG bit 16 restores "every wave stages its own share" (A/B diagnostics).
-  const int ld_mode = (dbg & 0x10000) ? 0 : 2;
-  const bool loader = ld_mode == 0 || wave < 4;
-  const int nshare = ld_mode == 0 ? 1 : 2;
-  const int vw0 = ld_mode == 0 ? wave : 2 * (wave & 3);
+  constexpr int DMA_PH = TN ? 0 : 4;     // NT: the DMA of k-tile t+1 is issued over the first 4 phases of k-tile t (see main loop)
+  constexpr bool SPREAD_A = !TN;         // NT: the A fragments of k-step 1 are fetched over phases 0-2 of k-step 0
+  const bool loader = wave < 4;
+  const int vw0 = 2 * (wave & 3);
 
   // ---- fragment read offsets (bytes within a stage) ---------------------------------------------------------
   int a_rd0, a_rd1, b_rd0, b_rd1;   // NT: k-step 0 / 1 bases;  TN: a_rd0 / b_rd0 only (k-step is an immediate)
@@ -225,9 +237,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   // TN: asm transpose reads into pending halves (issue), combined into the fragment after the hand-placed wait (commit).
   u32x2_t pa[TN ? MF : 1][2], pb[TN ? NC : 1][2];
   const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
-  auto issue_a = [&](int sb, int ks, bf16x8_t (&dst)[MF]) {
+  auto issue_a = [&](int sb, int ks, bf16x8_t (&dst)[MF], int f0 = 0, int f1 = MF) {
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
+      if (f < f0 || f >= f1) continue;
       if (!TN) {
         dst[f] = lds_b128(smem + sb + (ks ? a_rd1 : a_rd0) + f * 2048);
       } else {
@@ -301,41 +314,50 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     oke = min(nkt_total, okb + kt_per);
   };
 
-  auto stage = [&](int buf) {   // one k-tile of tile (sm0, sn0) -> LDS stage `buf`
-    char* lds = smem + buf * STAGE;
-    if (loader) {
-      for (int sh = 0; sh < nshare; ++sh) {
-        const int vw = vw0 + sh;                 // the "virtual wave" whose share of the tile is staged
-        if (!TN) {
-          const bf16_t* ab = seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * KT;
-          const bf16_t* bb = seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * KT;
-#pragma unroll
-          for (int q = 0; q < GA; ++q)
-            glds16(ab + a_voff + (long)(vw * GA + q) * 8 * p.lda, lds + (vw * GA + q) * 1024);
-#pragma unroll
-          for (int q = 0; q < GB; ++q)
-            glds16(bb + b_voff + (long)(vw * GB + q) * 8 * p.ldb, lds + A_BYTES + (vw * GB + q) * 1024);
-        } else {
-          const bf16_t* ab = seg_a(st_seg) + (long)st_kt * KT * p.lda + sm0;
-          const bf16_t* bb = seg_b(st_seg) + (long)st_kt * KT * p.ldb + sn0;
-          const int krow = st_kt * KT + vw * 8 + (lane >> 5);     // + 2q
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool ok = krow + 2 * q < p.K;
-            const int col = tn_col ^ (((2 * q) & 7) << 4);   // 32-B unit (16 elements) index ^= (2q) & 7
-            const bf16_t* sa = ab + a_voff + (long)(vw * 8 + 2 * q) * p.lda + col;
-            const bf16_t* sb = bb + b_voff + (long)(vw * 8 + 2 * q) * p.ldb + col;
-            const void* za = (const char*)g_zero_page + lane * 16;
-            glds16(ok ? (const void*)sa : za, lds + (vw * 4 + q) * 1024);
-            glds16(ok ? (const void*)sb : za, lds + A_BYTES + (vw * 4 + q) * 1024);
-          }
-        }
+  // One DMA piece (1 KiB = 64 lanes x 16 B) of the k-tile being staged.  A loader wave owns NP pieces per k-tile: the A
+  // pieces of its two 1/8 shares first (activations stream from HBM), then the B pieces (weights, L2-resident).
+  constexpr int NP = 2 * (GA + GB);
+  auto piece = [&](char* lds, int i) {
+    if (!TN) {
+      if (i < 2 * GA) {
+        const int vw = vw0 + i / GA, q = i % GA;
+        const bf16_t* ab = seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * KT;
+        glds16(ab + a_voff + (long)(vw * GA + q) * 8 * p.lda, lds + (vw * GA + q) * 1024);
+      } else {
+        const int j = i - 2 * GA;
+        const int vw = vw0 + j / GB, q = j % GB;
+        const bf16_t* bb = seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * KT;
+        glds16(bb + b_voff + (long)(vw * GB + q) * 8 * p.ldb, lds + A_BYTES + (vw * GB + q) * 1024);
+      }
+    } else {
+      const bool isb = i >= 8;
+      const int j = i & 7;
+      const int vw = vw0 + (j >> 2), q = j & 3;
+      const int krow = st_kt * KT + vw * 8 + (lane >> 5) + 2 * q;
+      const int col = tn_col ^ (((2 * q) & 7) << 4);   // 32-B unit (16 elements) index ^= (2q) & 7
+      const void* za = (const char*)g_zero_page + lane * 16;
+      if (!isb) {
+        const bf16_t* sa = seg_a(st_seg) + (long)st_kt * KT * p.lda + sm0 + a_voff + (long)(vw * 8 + 2 * q) * p.lda + col;
+        glds16(krow < p.K ? (const void*)sa : za, lds + (vw * 4 + q) * 1024);
+      } else {
+        const bf16_t* sb = seg_b(st_seg) + (long)st_kt * KT * p.ldb + sn0 + b_voff + (long)(vw * 8 + 2 * q) * p.ldb + col;
+        glds16(krow < p.K ? (const void*)sb : za, lds + A_BYTES + (vw * 4 + q) * 1024);
       }
     }
+  };
+  auto stage_advance = [&]() {
     if (++st_kt == skt_end) {
       st_kt = skt_begin;
       ++st_seg;
     }
+  };
+  auto stage = [&](int buf) {   // one k-tile of tile (sm0, sn0) -> LDS stage `buf`
+    char* lds = smem + buf * STAGE;
+    if (loader) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) piece(lds, i);
+    }
+    stage_advance();
   };
 
   int v = blockIdx.x;
@@ -360,9 +382,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 
     if (nt > 0) {
       if (nt > 1) {
-        stage(1);
-        if (ld_mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DMA_PH) stage(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -399,17 +420,36 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           if (last) {
             if (t + 1 < nt) {
               // tile t+1 (this wave's DMA pieces) landed; all of this wave's reads of stage t&1 have returned
+              stamp(t, 0);
               asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+              stamp(t, 1);
               if (!(dbg & 0x1000)) __builtin_amdgcn_s_barrier();          // DIAGNOSTIC bits (timing only, results invalid):
-              if (t + 2 < nt && !(dbg & 0x2000)) stage(t & 1);            // 0x1000 no k-tile barrier, 0x2000 no DMA in the loop
+              stamp(t, 2);
+              if (DMA_PH) stage_advance();
+              else if (t + 2 < nt && !(dbg & 0x2000)) stage(t & 1);       // 0x1000 no k-tile barrier, 0x2000 no DMA in the loop
+              stamp(t, 3);
               issue_b(STAGE - sb, 0, 0, Bq[0]);
               issue_a(STAGE - sb, 0, A[0]);
             }
           } else {
+            if (DMA_PH && ph < DMA_PH && loader && t + 1 < nt) {
+              // k-tile t+1 -> the other stage (free since the barrier that ended k-tile t-1), a few pieces per phase: a
+              // burst of NP DMA instructions blocks the issuing wave for ~1300 cycles on the 64 B/clk L1->LDS path
+              // (s_memtime stamps, profiles/r01_d_handover_stamps.txt) while its SIMD partner runs alone
+              char* lds = smem + (STAGE - sb);
+              constexpr int PP = (NP + DMA_PH - 1) / (DMA_PH ? DMA_PH : 1);
+#pragma unroll
+              for (int i = 0; i < NP; ++i)
+                if (i >= ph * PP && i < (ph + 1) * PP) piece(lds, i);
+            }
             const int ks2 = (c + 1 < NCH) ? ks : ks + 1;
             const int c2 = (c + 1 < NCH) ? c + 1 : 0;
             issue_b(sb, ks2, c2, Bq[TN ? 0 : ((ph + 1) & 1)]);
-            if (c2 == 0) issue_a(sb, ks2, A[TN ? 0 : (ks2 & 1)]);
+            if (SPREAD_A && ks == 0) {
+              if (c < 3) issue_a(sb, 1, A[TN ? 0 : 1], 2 * c, 2 * c + 2);
+            } else if (c2 == 0) {
+              issue_a(sb, ks2, A[TN ? 0 : (ks2 & 1)]);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -441,6 +481,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       }
     }
     if ((dbg & 0xfff) == 200) ts2 = __builtin_amdgcn_s_memrealtime();
+    if (stamp_on && v == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      unsigned long long* dst = (unsigned long long*)p.aux_out + 16384 + wave * 256;
+      for (int i = lane; i < 256; i += 64) dst[i] = stamp_lds[i];
+    }
 
     // ================= hand-over: every wave is done with both LDS stages =========================================
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -504,20 +549,22 @@ template <int MF, bool TN, int EPI>
 int launch_big(const egv_gemm_desc& p, hipStream_t s) {
   constexpr int BM = MF * 64;
   constexpr int lds = 2 * (BM * 128 + BNB * 128);
+  int lds_launch = lds;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNB - 1) / BNB);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   const int total = tiles * ks;
   auto k = gemm_big_kernel<MF, TN, EPI>;
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
       return EGV_ERR_LAUNCH + (int)hipGetLastError();
     attr_set = true;
   }
   static const int dbg = getenv("EGV_GEMM_DBG") ? atoi(getenv("EGV_GEMM_DBG")) : 0;
+  if ((dbg & 0x4000) && lds + 16384 <= 163840) lds_launch += 16384;   // stamp area of the hand-over diagnostic
   // persistent workgroups: one per CU (144 KiB of LDS each); G = 256 keeps v % 8 == blockIdx % 8 (XCD affinity)
   const int grid = total < 256 ? total : 256;
-  EGV_LAUNCH(k, dim3(grid), dim3(512), lds, s, p, dbg);
+  EGV_LAUNCH(k, dim3(grid), dim3(512), lds_launch, s, p, dbg);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

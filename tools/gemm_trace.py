@@ -49,3 +49,22 @@ print("main loop (us): mean %.2f min %.2f max %.2f" % ((t[:, 2] - t[:, 1]).mean(
 print("epilogue  (us): mean %.2f max %.2f" % ((t[:, 3] - t[:, 2]).mean(), (t[:, 3] - t[:, 2]).max()))
 for i in list(range(0, min(nblk, 6))) + list(range(max(0, nblk - 4), nblk)):
     print("  tile#%4d start %7.2f  pro %6.2f  loop %7.2f  epi %6.2f  end %7.2f" % (i, t[i, 0], t[i, 1] - t[i, 0], t[i, 2] - t[i, 1], t[i, 3] - t[i, 2], t[i, 3]))
+
+if int(os.environ.get("TRACE_DIAG", "0"), 0) & 0x4000:
+    # hand-over stamps of workgroup 0's first tile: [wave][k-tile][arrive, waited, barrier passed, DMA issued] (s_memtime)
+    st = ts[16384:16384 + 8 * 256].view(8, 64, 4).cpu().double()
+    nkt = min(64, (m if tn else k) // 64 // max(ksplit, 1)) - 1
+    base = st[:, 0, 0].min()
+    print("hand-over stamps, workgroup 0, tile 0 (s_memtime ticks relative to first arrival at k-tile 0):")
+    print("  kt | arrive: min max (who last) | wait vm/lgkm: max | barrier exit: min max | dma issue: max(loaders) | period")
+    prev = None
+    for t in range(nkt):
+        a, w, b, d = st[:, t, 0] - base, st[:, t, 1] - base, st[:, t, 2] - base, st[:, t, 3] - base
+        per = "" if prev is None else "%6.0f" % (b.min() - prev)
+        prev = b.min()
+        if t < 12 or t >= nkt - 3:
+            print("  %2d | %7.0f %7.0f (w%d) | %5.0f | %7.0f %7.0f | %5.0f | %s" % (
+                t, a.min(), a.max(), int(a.argmax()), (w - a).max(), b.min(), b.max(), (d - b).max(), per))
+    for wv in range(8):
+        print("   wave %d arrive-rel-to-first per k-tile 4..11:" % wv, " ".join("%5.0f" % (st[wv, t, 0] - st[:, t, 0].min()) for t in range(4, 12)),
+              "| exit->next arrive:", " ".join("%5.0f" % (st[wv, t + 1, 0] - st[wv, t, 2]) for t in range(4, 12)))
