@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 
   // TN keeps ONE fragment set: the pending halves of the asm reads are its second buffer (commit happens after the
   // phase's MFMAs), which keeps the kernel under 256 VGPRs without spills -- a spilled pending half would be read early.
-  bf16x8_t A[TN ? 1 : 2][MF], Bq[TN ? 1 : 2][NC];
+  bf16x8_t A[TN ? 1 : 2][MF], Bq[TN ? 1 : 3][NC];
   // NT: plain LDS loads straight into the destination fragments (issue = load, commit = nothing).
   // TN: asm transpose reads into pending halves (issue), combined into the fragment after the hand-placed wait (commit).
   u32x2_t pa[TN ? MF : 1][2], pb[TN ? NC : 1][2];
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             for (int i = 0; i < MF; ++i)
               cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[TN ? 0 : (ks & 1)][i], cs[i], 0, 0, 0);
           }
-          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph & 1)][0], A[TN ? 0 : (ks & 1)][0],
+          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph % 3)][0], A[TN ? 0 : (ks & 1)][0],
                                                                    acc[0][c * NC], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (last) {
@@ -444,7 +444,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             }
             const int ks2 = (c + 1 < NCH) ? ks : ks + 1;
             const int c2 = (c + 1 < NCH) ? c + 1 : 0;
-            issue_b(sb, ks2, c2, Bq[TN ? 0 : ((ph + 1) & 1)]);
+            if (TN) {
+              issue_b(sb, ks2, c2, Bq[0]);
+            } else {
+              // NT: B fragments are fetched TWO phases ahead into a ring of three register sets (phase q uses set q % 3):
+              // one phase of MFMAs (~160 cycles) does not cover an LDS read under load (~200), two do.  The hand-over
+              // phase can only fetch phase 0 of the next k-tile (after the barrier), so phase 0 fetches phases 1 and 2.
+              if (ph == 0) issue_b(sb, 1 / NCH, 1 % NCH, Bq[TN ? 0 : 1]);
+              if (ph + 2 < 2 * NCH) issue_b(sb, (ph + 2) / NCH, (ph + 2) % NCH, Bq[TN ? 0 : ((ph + 2) % 3)]);
+            }
             if (SPREAD_A && ks == 0) {
               if (c < 3) issue_a(sb, 1, A[TN ? 0 : 1], 2 * c, 2 * c + 2);
             } else if (c2 == 0) {
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
             for (int i = 0; i < MF; ++i)
               if (jj + i > 0)
-                acc[i][c * NC + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph & 1)][jj], A[TN ? 0 : (ks & 1)][i],
+                acc[i][c * NC + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph % 3)][jj], A[TN ? 0 : (ks & 1)][i],
                                                                               acc[i][c * NC + jj], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (TN) {   // the asm reads issued above have had this phase's MFMAs to land: wait, then assemble the fragments
