@@ -41,6 +41,7 @@
 // The last tile row/column is shifted inwards (m0 = M - BM) instead of being predicated: the overlapping rows are
 // computed twice with bit-identical results, so the duplicate stores are benign and no lane ever needs a clamp.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "egovlp_hip.h"
@@ -90,6 +91,30 @@ __device__ __forceinline__ u32x2_t tr_asm(unsigned addr) {
   u32x2_t r;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
   return r;
+}
+
+// Plain 16-byte LDS read as inline asm (NT main loop): invisible to hipcc's s_waitcnt insertion, which only ever emits
+// lgkmcnt(0) in this kernel and so turns any fetch-ahead deeper than one phase back into "wait for everything"; the
+// counted waits are placed by hand (lgkm_wait<N>) and the destination is tied to the wait (tie) so that no consumer can
+// be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ bf16x8_t ld128_asm(unsigned addr) {
+  u32x4_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void tie(bf16x8_t& x) { asm volatile("" : "+v"(x)); }
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
 }
 
 // One 4-column piece of one output row: alpha, + bias, activation, + residual, stores (include/egovlp_hip.h order).
@@ -188,11 +213,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 
   // ---- DMA (global -> LDS) source offsets, in elements, relative to the tile origin of the current k-tile -----
   long a_voff, b_voff;
+  unsigned nt_avo = 0, nt_bvo = 0, avo = 0, bvo = 0;
   int tn_col = 0;   // TN: this lane's source column (elements) before the per-piece unit XOR
   if (!TN) {
     const int chunk = (lane & 7) ^ (lane >> 3);                 // LDS position (lane&7) holds source chunk pos^(row&7)
-    a_voff = (long)(lane >> 3) * p.lda + chunk * 8;      // + (piece row base) * lda per piece
-    b_voff = (long)(lane >> 3) * p.ldb + chunk * 8;
+    a_voff = b_voff = 0;
+    // byte offset of this lane's 16 B within the (BM or 256) x 64 k-tile, first piece of this wave's two shares; the
+    // pieces follow at 8 rows each.  32 bits are enough (320 rows x lda x 2 B), so the DMA addresses are a scalar base
+    // (tile origin of the k-tile) + one VGPR: no 64-bit per-lane pointers, no per-piece scalar pairs.
+    nt_avo = (unsigned)(((lane >> 3) + 2 * (wave & 3) * GA * 8) * p.lda * 2 + chunk * 16);
+    nt_bvo = (unsigned)(((lane >> 3) + 2 * (wave & 3) * GB * 8) * p.ldb * 2 + chunk * 16);
   } else {
     // piece I = wave*4 + q covers k-rows 2I, 2I+1 of the tile; this lane: row 2I + (lane>>5), LDS chunk lane&31.
     // source 32-B unit = (LDS unit) ^ (row & 7) = ((lane&31)>>1) ^ ((2q + (lane>>5)) & 7); the q part is XOR-ed in per piece.
@@ -237,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   // TN: asm transpose reads into pending halves (issue), combined into the fragment after the hand-placed wait (commit).
   u32x2_t pa[TN ? MF : 1][2], pb[TN ? NC : 1][2];
   const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  const unsigned fa = lds0 + a_rd0, fb = lds0 + b_rd0;   // NT asm fragment reads (the stages are 128-B aligned: k-step 1 = ^ 64)
   auto issue_a = [&](int sb, int ks, bf16x8_t (&dst)[MF], int f0 = 0, int f1 = MF) {
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
@@ -317,18 +348,24 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   // One DMA piece (1 KiB = 64 lanes x 16 B) of the k-tile being staged.  A loader wave owns NP pieces per k-tile: the A
   // pieces of its two 1/8 shares first (activations stream from HBM), then the B pieces (weights, L2-resident).
   constexpr int NP = 2 * (GA + GB);
-  auto piece = [&](char* lds, int i) {
+  unsigned run = 0;
+  auto piece = [&](char* lds, int i, int i0) {   // pieces are issued in ascending runs [i0, ...)
     if (!TN) {
+      // scalar base of the k-tile + this lane's 32-bit offset; `run` is opaque after every piece so that the offsets are
+      // produced one at a time (computed all at once they spill next to the live accumulators)
       if (i < 2 * GA) {
-        const int vw = vw0 + i / GA, q = i % GA;
-        const bf16_t* ab = seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * KT;
-        glds16(ab + a_voff + (long)(vw * GA + q) * 8 * p.lda, lds + (vw * GA + q) * 1024);
+        const char* ab = (const char*)(seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * KT);
+        if (i == i0) run = avo + (unsigned)(i * 16 * p.lda);
+        glds16(ab + (size_t)run, lds + (vw0 * GA + i) * 1024);
+        run += (unsigned)(16 * p.lda);
       } else {
         const int j = i - 2 * GA;
-        const int vw = vw0 + j / GB, q = j % GB;
-        const bf16_t* bb = seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * KT;
-        glds16(bb + b_voff + (long)(vw * GB + q) * 8 * p.ldb, lds + A_BYTES + (vw * GB + q) * 1024);
+        const char* bb = (const char*)(seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * KT);
+        if (i == i0 || j == 0) run = bvo + (unsigned)(j * 16 * p.ldb);
+        glds16(bb + (size_t)run, lds + A_BYTES + (vw0 * GB + j) * 1024);
+        run += (unsigned)(16 * p.ldb);
       }
+      asm volatile("" : "+v"(run));
     } else {
       const bool isb = i >= 8;
       const int j = i & 7;
@@ -353,9 +390,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   };
   auto stage = [&](int buf) {   // one k-tile of tile (sm0, sn0) -> LDS stage `buf`
     char* lds = smem + buf * STAGE;
+    avo = nt_avo; bvo = nt_bvo;
     if (loader) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) piece(lds, i);
+      for (int i = 0; i < NP; ++i) piece(lds, i, 0);
     }
     stage_advance();
   };
@@ -380,6 +418,95 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
     for (int i = 0; i < MF; ++i) cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (!TN) {
+      // ---- NT main loop ------------------------------------------------------------------------------------------------
+      // Phase q = (k-step q/4, B column pair q%4) multiplies MF x 2 fragments: A set q/4, B set q%3.  Fetch plan per
+      // k-tile (reads complete in issue order, so every wait is a count of the reads issued after the ones needed):
+      //   hand-over (phase 7 of the previous k-tile, after the barrier): B(0), A(k-step 0)
+      //   phase 0: B(1) B(2) A1[0,1]   phase 1: B(3) A1[2,3]   phase 2: B(4) A1[4]   phase 3: B(5)   phase 4: B(6)
+      //   phase 5: B(7)                phase 6: -               (B two phases ahead, A(k-step 1) four)
+      // The DMA of k-tile t+1 (into the stage freed by the barrier that ended t-1) is issued by waves 0-3 over phases
+      // 0-3, a few pieces each: a burst of all NP blocks the issuing wave ~1300 cycles on the 64 B/clk L1->LDS path.
+      auto k_tile = [&](const int t) {
+        const bool HN = t + 1 < nt;            // wave-uniform: scalar branches around the DMA issue and the hand-over
+        const int sb = (t & 1) * STAGE;
+        // fa / fb: this lane's A / B fragment address in stage 0, k-step 0 (kernel lifetime); + sb, ^ 64 for k-step 1
+        const unsigned ra0 = fa + sb, rb0 = fb + sb;
+        char* dma_lds = smem + (STAGE - sb);
+        // opaque per iteration: keeps the NP per-piece offsets (avo + i * 16 lda) from being hoisted into NP live registers
+        avo = nt_avo; bvo = nt_bvo;
+        asm volatile("" : "+v"(avo), "+v"(bvo));
+        constexpr int nA2 = MF > 4 ? 1 : 0;
+        static_for<0, 2 * NCH>([&](auto PHc) {
+          constexpr int PH = decltype(PHc)::value, ks = PH / NCH, c = PH % NCH;
+          auto rd_b = [&](auto Qc) {   // B fragments of phase Q -> register set Q % 3
+            constexpr int Q = decltype(Qc)::value, qs = Q / NCH, qc = Q % NCH;
+            const unsigned rb = qs ? rb0 ^ 64u : rb0;
+            Bq[Q % 3][0] = ld128_asm<(qc * NC) * 2048>(rb);
+            Bq[Q % 3][1] = ld128_asm<(qc * NC + 1) * 2048>(rb);
+          };
+          auto rd_a1 = [&](auto Fc) {
+            constexpr int F = decltype(Fc)::value;
+            if constexpr (F < MF) A[1][F] = ld128_asm<F * 2048>(ra0 ^ 64u);
+          };
+          if constexpr (PH == 0) {
+            rd_b(std::integral_constant<int, 1>{});
+            rd_b(std::integral_constant<int, 2>{});
+            rd_a1(std::integral_constant<int, 0>{});
+            rd_a1(std::integral_constant<int, 1>{});
+          } else if constexpr (PH <= 5) {
+            rd_b(std::integral_constant<int, PH + 2>{});
+            if constexpr (PH == 1) {
+              rd_a1(std::integral_constant<int, 2>{});
+              rd_a1(std::integral_constant<int, 3>{});
+            } else if constexpr (PH == 2) {
+              rd_a1(std::integral_constant<int, 4>{});
+            }
+          }
+          if (PH < 4 && loader && HN) {
+            constexpr int PP = (NP + 3) / 4;
+            static_for<PH * PP, (PH + 1) * PP < NP ? (PH + 1) * PP : NP>([&](auto Ic) { piece(dma_lds, decltype(Ic)::value, PH * PP); });
+          }
+          constexpr int WAITS[8] = {6, 8, 8 + nA2, 6 + nA2, 4, 4, 2, 0};
+          lgkm_wait<WAITS[PH]>();
+          tie(Bq[PH % 3][0]);
+          tie(Bq[PH % 3][1]);
+          if constexpr (c == 0) static_for<0, MF>([&](auto Ic) { tie(A[ks][decltype(Ic)::value]); });
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[PH % 3][0], A[ks][0], acc[0][c * NC], 0, 0, 0);
+          if (PH == 2 * NCH - 1 && HN) {
+            __builtin_amdgcn_sched_barrier(0);
+            // k-tile t+1 (this wave's DMA pieces) landed; every read of stage t&1 by this wave has returned (lgkmcnt(0) above)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage_advance();
+            const unsigned na0 = fa + (STAGE - sb), nb0 = fb + (STAGE - sb);
+            Bq[0][0] = ld128_asm<0>(nb0);
+            Bq[0][1] = ld128_asm<2048>(nb0);
+            static_for<0, MF>([&](auto Ic) { A[0][decltype(Ic)::value] = ld128_asm<decltype(Ic)::value * 2048>(na0); });
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jj = 0; jj < NC; ++jj)
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+              if (jj + i > 0)
+                acc[i][c * NC + jj] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[PH % 3][jj], A[ks][i], acc[i][c * NC + jj], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+      if (nt > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned na0 = fa, nb0 = fb;
+        Bq[0][0] = ld128_asm<0>(nb0);
+        Bq[0][1] = ld128_asm<2048>(nb0);
+        static_for<0, MF>([&](auto Ic) { A[0][decltype(Ic)::value] = ld128_asm<decltype(Ic)::value * 2048>(na0); });
+        if ((dbg & 0xfff) == 200) ts1 = __builtin_amdgcn_s_memrealtime();
+        for (int t = 0; t < nt; ++t) k_tile(t);
+      }
+    } else {
     if (nt > 0) {
       if (nt > 1) {
         if (!DMA_PH) stage(1);
@@ -440,7 +567,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
               constexpr int PP = (NP + DMA_PH - 1) / (DMA_PH ? DMA_PH : 1);
 #pragma unroll
               for (int i = 0; i < NP; ++i)
-                if (i >= ph * PP && i < (ph + 1) * PP) piece(lds, i);
+                if (i >= ph * PP && i < (ph + 1) * PP) piece(lds, i, ph * PP);
             }
             const int ks2 = (c + 1 < NCH) ? ks : ks + 1;
             const int c2 = (c + 1 < NCH) ? c + 1 : 0;
@@ -487,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         cur_kt = kt_begin;
         ++cur_seg;
       }
+    }
     }
     if ((dbg & 0xfff) == 200) ts2 = __builtin_amdgcn_s_memrealtime();
     if (stamp_on && v == 0) {

@@ -196,6 +196,9 @@ int egv_relu_split(const float* x, int64_t ldx, int32_t rows, int32_t cols, egv_
                    int64_t ldo, void* stream);
 /* scatter rows of a small matrix into a zeroed big one: dst[r * ld_dst + c] = src[r, c] (CLS-row grads). */
 int egv_version(void);
+/* diagnostics, not on the product path: `iters` rounds of 40 independent MFMA 16x16x32 bf16 per wave, `waves` (1..8) waves
+ * per workgroup, one workgroup per CU, no memory traffic -- the chip's sustained MFMA rate (tools/mfma_peak.py). */
+int egv_diag_mfma_peak(int32_t iters, int32_t waves, float* out, void* stream);
 
 #ifdef __cplusplus
 }
