@@ -13,8 +13,20 @@ __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(int iters, float* out
 #pragma unroll
   for (int i = 0; i < 40; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 av = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, (short)(0x3F80 + (threadIdx.x & 1))};
-  bf16x8_t a = __builtin_bit_cast(bf16x8_t, av), b = a;
+  s16x8 av = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, (short)(0x3F80 + (threadIdx.x & 1))};
+  s16x8 bv = av;
+  if (iters < 0) {   // random bf16 in (-2, 2): realistic multiplier toggling (the sustained rate is power-limited and data-dependent)
+    iters = -iters;
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h = h * 1664525u + 1013904223u;
+      av[e] = (short)((h >> 16 & 0x807F) | 0x3F00 | ((h >> 8) & 0x0080));
+      h = h * 1664525u + 1013904223u;
+      bv[e] = (short)((h >> 16 & 0x807F) | 0x3F00 | ((h >> 8) & 0x0080));
+    }
+  }
+  bf16x8_t a = __builtin_bit_cast(bf16x8_t, av), b = __builtin_bit_cast(bf16x8_t, bv);
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 40; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
@@ -25,10 +37,90 @@ __global__ __launch_bounds__(512, 2) void mfma_peak_kernel(int iters, float* out
   if (s[0] + s[1] + s[2] + s[3] == -1.0f) out[threadIdx.x] = s[0];   // never true: keeps the loop alive
 }
 
+// The gemm_big wave loop without DMA and without barriers: per round 4 phases of 10 MFMAs over 5 A x 2 B fragment
+// registers into 40 accumulators.  MODE 1: fragments loaded once (register operand pattern only); MODE 2: the B fragments of
+// the phase after next are re-read from LDS in every phase and the A fragments once per round (asm reads, counted waits):
+// the LDS traffic of the GEMM main loop (13 ds_read_b128 per 40 MFMAs).
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mfma_loop_kernel(int iters, float* out) {
+  __shared__ __attribute__((aligned(16))) char lds[65536];
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  for (int i = threadIdx.x; i < 65536 / 16; i += blockDim.x) ((u4*)lds)[i] = (u4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  __syncthreads();
+  const unsigned base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds + (threadIdx.x & 63) * 16 +
+                        (threadIdx.x >> 6) * 4096;
+  f32x4_t acc[5][8];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t A[5], B[3][2];
+  auto rd = [&](unsigned off) {
+    u4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(base + off));
+    return __builtin_bit_cast(bf16x8_t, r);
+  };
+#pragma unroll
+  for (int i = 0; i < 5; ++i) A[i] = rd(i * 1024 % 4096);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { B[q][0] = rd(0); B[q][1] = rd(1024); }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ph = 0; ph < 12; ++ph) {   // 12 phases = 3 rounds so that the B ring index (ph % 3) is static
+      const int c = ph & 3;
+      if (MODE == 2) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2) : "memory");
+        asm volatile("" : "+v"(B[ph % 3][0]), "+v"(B[ph % 3][1]));
+        if (c == 0) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(A[i]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const int jj = k / 5, i = k % 5;
+        acc[i][c * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B[ph % 3][jj], A[i], acc[i][c * 2 + jj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 2 && k == 0) {
+          B[(ph + 2) % 3][0] = rd(((ph * 2) & 3) * 1024);
+          B[(ph + 2) % 3][1] = rd(((ph * 2 + 1) & 3) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE == 2 && c == 3 && k >= 1 && k <= 5) {   // A fragments of the next round, one per MFMA, behind their last use
+          // (A[k-1] was last read by MFMA k-1+5 at the latest in this phase only when jj == 1; keep it simple: reload at the end)
+        }
+      }
+      if (MODE == 2 && c == 3) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) A[i] = rd(i * 1024 % 4096);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4) : "memory");   // the A reads have landed; two B sets may be in flight
+      }
+    }
+  }
+  f32x4_t s = acc[0][0];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[i][j];
+  if (s[0] + s[1] + s[2] + s[3] == -1.0f) out[threadIdx.x] = s[0];
+}
+
 }  // namespace
 
 extern "C" int egv_diag_mfma_peak(int32_t iters, int32_t waves, float* out, void* stream) {
-  if (iters <= 0 || waves < 1 || waves > 8 || !out) return EGV_ERR_ARG;
+  if (iters == 0 || waves < 1 || waves > 8 + 200 || !out) return EGV_ERR_ARG;   // iters < 0: random operands (plain kernel)
+  if (waves >= 200) {        // 200 + w: LDS-fed loop;  100 + w: register-operand pattern only (iters = rounds of 120 MFMAs)
+    EGV_LAUNCH(mfma_loop_kernel<2>, dim3(256), dim3(64 * (waves - 200)), 0, (hipStream_t)stream, iters, out);
+    EGV_CHECK_LAUNCH();
+    return EGV_OK;
+  }
+  if (waves >= 100) {
+    EGV_LAUNCH(mfma_loop_kernel<1>, dim3(256), dim3(64 * (waves - 100)), 0, (hipStream_t)stream, iters, out);
+    EGV_CHECK_LAUNCH();
+    return EGV_OK;
+  }
   EGV_LAUNCH(mfma_peak_kernel, dim3(256), dim3(64 * waves), 0, (hipStream_t)stream, iters, out);
   EGV_CHECK_LAUNCH();
   return EGV_OK;

@@ -14,12 +14,21 @@ from egovlp_amd import _lib, ops  # noqa: E402
 m, n, k = [int(x) for x in sys.argv[1:4]]
 tn = len(sys.argv) > 4 and sys.argv[4] == "tn"
 ksplit = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+def gen(r, c):   # TRACE_DATA=ones|zeros: operand bit patterns that barely toggle the multipliers (power / clock experiment)
+    kind = os.environ.get("TRACE_DATA", "rand")
+    if kind == "ones":
+        return torch.ones(r, c, device="cuda")
+    if kind == "zeros":
+        return torch.zeros(r, c, device="cuda")
+    return torch.rand(r, c, device="cuda") * 2 - 1
+
+
 if tn:
-    a = ops.split_f32(torch.rand(k, m, device="cuda") * 2 - 1, 1)[0]
-    b = ops.split_f32(torch.rand(k, n, device="cuda") * 2 - 1, 1)[0]
+    a = ops.split_f32(gen(k, m), 1)[0]
+    b = ops.split_f32(gen(k, n), 1)[0]
 else:
-    a = ops.split_f32(torch.rand(m, k, device="cuda") * 2 - 1, 1)[0]
-    b = ops.split_f32(torch.rand(n, k, device="cuda") * 2 - 1, 1)[0]
+    a = ops.split_f32(gen(m, k), 1)[0]
+    b = ops.split_f32(gen(n, k), 1)[0]
 out = torch.empty(m, n, device="cuda")
 partial = torch.empty(ksplit * (m * n + m), device="cuda") if ksplit > 1 else None
 ts = torch.zeros(8192 * 4, dtype=torch.int64, device="cuda")
