@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass bf16 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the RCCL process group, DDP wrapper and the fused all-gather even at world size 1 "
+                         "(smoke test of the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,9 +89,15 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if args.force_dist:
+            os.environ["EGV_FORCE_GATHER"] = "1"
 
     from egovlp_amd import ops
     from egovlp_amd.model.loss import EgoNCE
@@ -106,7 +115,7 @@ def main():
     B, T, L = args.batch, args.frames, 32
     model = build_model(args.arch, 16).cuda().train()
     net = model
-    if world > 1:
+    if use_dist:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=100,
                                                         gradient_as_bucket_view=True)
     opt = AdamW(model.parameters(), lr=3e-5)
@@ -116,7 +125,7 @@ def main():
             "noun_vec": batch["noun_vec"].cuda(), "verb_vec": batch["verb_vec"].cuda()}
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,7 +139,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax), float(loss)
 
@@ -193,7 +202,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,38 @@
+"""The N>1 code path of bench.py on a 1-GPU box: RCCL process group (`backend='nccl'`), DistributedDataParallel around the
+drop-in model (custom autograd nodes, raw-pointer AdamW on bucket-view gradients) and the fused all-gather, at world size 1.
+The loss after the same steps must equal the plain single-process run: DDP / the collective must not change the arithmetic."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_under_rccl_ddp_world1_matches_single_process():
+    common = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-fast-mode",
+              "--no-kernel-timing", "--precision", "bf16x3"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = _run([sys.executable] + common, env)
+    dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                 "--master-port", str(_free_port())] + common + ["--force-dist"], env)
+    assert dist["n_gpus"] == 1 and dist["config"]["parallelism"] == "dp1"
+    assert abs(dist["loss"] - plain["loss"]) <= 1e-5 * max(1.0, abs(plain["loss"])), (dist["loss"], plain["loss"])
