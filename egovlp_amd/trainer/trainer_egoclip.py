@@ -103,6 +103,8 @@ class Multi_Trainer_dist:
         self.args, self.config = args, config
         self.model, self.loss, self.optimizer = model, loss, optimizer
         self.data_loader = data_loader
+        self.valid_data_loader = valid_data_loader
+        self.metrics = metrics if metrics is not None else []
         self.len_epoch = min(len(x) for x in data_loader) if len_epoch is None else len_epoch
         self.tokenizer = tokenizer
         self.max_samples_per_epoch = max_samples_per_epoch
@@ -150,3 +152,44 @@ class Multi_Trainer_dist:
         log = {f'loss_{i}': float(t) / max(steps, 1) for i, t in enumerate(total_loss)}
         self._adjust_learning_rate(self.optimizer, epoch, self.args)        # :178
         return log
+
+    def _valid_epoch(self, epoch):
+        """EgoMCQ validation = reference trainer/trainer_egoclip.py:182-275: for every question the text query and its five
+        candidate clips go through the same encoders in eval mode (`model(data, return_embeds=True)`, :211), the prediction
+        is `sim_matrix(text, video)` [1, 5] (:214), predictions / answers / types are all-gathered over the ranks (:225-235)
+        and scored by the configured metrics (model/metric.py:218-234).  Differences: the gathers are one collective each
+        (`all_gather_into_tensor`) and are skipped without a process group; results stay on the device until the end."""
+        self.model.eval()
+        n_loaders = len(self.valid_data_loader)
+        gt_arr = {x: [] for x in range(n_loaders)}
+        pred_arr = {x: [] for x in range(n_loaders)}
+        type_arr = {x: [] for x in range(n_loaders)}
+        world = _world()
+        with torch.no_grad():
+            for dl_idx, dl in enumerate(self.valid_data_loader):
+                for data in dl:
+                    data['video'] = data['video'][0]                                    # remove batch (:205)
+                    if self.tokenizer is not None:
+                        data['text'] = self.tokenizer(data['text'], return_tensors='pt', padding=True, truncation=True)
+                    data['text'] = {key: val.to(self.device) for key, val in data['text'].items()}
+                    data['video'] = data['video'].to(self.device)
+                    text_embed, vid_embed = self.model(data, return_embeds=True)       # :211
+                    data_gt = data['correct'][0].to(self.device).unsqueeze(0)
+                    data_pred = sim_matrix(text_embed, vid_embed)                        # :214
+                    data_type = data['type'][0].to(self.device).unsqueeze(0)
+                    gt_arr[dl_idx].append(_gather_rows(data_gt, world))
+                    pred_arr[dl_idx].append(_gather_rows(data_pred, world))
+                    type_arr[dl_idx].append(_gather_rows(data_type, world))
+        nested_metrics = {x: {} for x in range(n_loaders)}
+        for dl_idx in range(n_loaders):
+            gt_cat = torch.cat(gt_arr[dl_idx]).cpu()
+            pred_cat = torch.cat(pred_arr[dl_idx]).cpu()
+            type_cat = torch.cat(type_arr[dl_idx]).cpu()
+            for metric in self.metrics:
+                nested_metrics[dl_idx][metric.__name__] = metric(pred_cat, gt_cat, type_cat)
+        res_dict = {}
+        if self.args.rank == 0:
+            res_dict = {f'val_loss_{dl_idx}': 0.0 for dl_idx in range(n_loaders)}       # the reference never accumulates it (:192)
+            res_dict['nested_val_metrics'] = nested_metrics
+        self.last_val_predictions = {x: torch.cat(pred_arr[x]).cpu() for x in range(n_loaders)}
+        return res_dict

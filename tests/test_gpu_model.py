@@ -199,3 +199,43 @@ def test_other_baseline_configs_video_encoder_matches_oracle(name, kw, T, B):
         rg = rel(got, want)
         print("  grad %-36s rel %.2e" % (pname, rg))
         assert rg < 3 * PARITY, (pname, rg)
+
+
+def test_egomcq_validation_epoch_matches_oracle(full):
+    """`Multi_Trainer_dist._valid_epoch` (reference trainer/trainer_egoclip.py:182-275): six synthetic EgoMCQ questions (one
+    text query, five candidate clips each) through the drop-in in eval mode vs the CPU oracle on the same weights."""
+    import types as _types
+    from egovlp_amd.model.metric import egomcq_accuracy_metrics
+    from egovlp_amd.trainer.trainer_egoclip import Multi_Trainer_dist
+    m, sd = full
+    g = torch.Generator().manual_seed(99)
+    questions = []
+    for q in range(6):
+        video = torch.randn(1, 5, 4, 3, 224, 224, generator=g)
+        ids = torch.randint(1000, 30000, (1, 16), generator=g)
+        ids[:, 0] = 101
+        mask = torch.ones(1, 16, dtype=torch.long)
+        mask[:, 10 + q:] = 0
+        questions.append({"video": video, "text": {"input_ids": ids, "attention_mask": mask},
+                          "correct": torch.tensor([q % 5]), "type": torch.tensor([1 + q % 2])})
+
+    class Loader(list):
+        batch_size = 1
+        dataset_name = "EgoMCQ-synthetic"
+
+    args = _types.SimpleNamespace(world_size=1, rank=0, local_rank=0)
+    tr = Multi_Trainer_dist(args, m, None, [egomcq_accuracy_metrics], None, None, [Loader()],
+                            valid_data_loader=[Loader([dict(q) for q in questions])], len_epoch=1)
+    res = tr._valid_epoch(1)
+    pred = tr.last_val_predictions[0]
+    assert pred.shape == (6, 5)
+    ref = []
+    with torch.no_grad():
+        for q in questions:
+            te, ve = O.frozen_in_time({"video": q["video"][0], "text": q["text"]}, sd, O.VideoCfg(), O.TextCfg())
+            ref.append(O.sim_matrix(te, ve))
+    ref = torch.cat(ref)
+    assert rel(pred, ref) < PARITY
+    want = egomcq_accuracy_metrics(ref, torch.cat([q["correct"] for q in questions]), torch.cat([q["type"] for q in questions]))
+    assert res["nested_val_metrics"][0]["egomcq_accuracy_metrics"] == want
+    m.train()
