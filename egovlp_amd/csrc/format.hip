@@ -102,10 +102,12 @@ __global__ __launch_bounds__(256) void relu_split_kernel(const float* __restrict
 // P % 4 == 0 -- ViT-B/16 -- else 2 -- ViT-L/14).  Source rows are W*4 B contiguous, so a wave reads one image row
 // segment: coalesced.  Columns K .. lda-1 of the output planes (K padded to the GEMM's k-tile) are left untouched:
 // the caller zero-fills them once.
-template <int G>
-__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ video, int BT, int C, int H, int W,
+struct PatchNorm { float mean[4], std[4]; };   // per-channel Normalize constants of the uint8 path (C <= 4)
+
+template <int G, bool U8>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const void* __restrict__ video_, int BT, int C, int H, int W,
                                                            int P, bf16_t* __restrict__ ahi, bf16_t* __restrict__ alo,
-                                                           long lda) {
+                                                           long lda, const PatchNorm nrm) {
   // thread -> (image bt, channel c, image row y, G-pixel group xg)
   const int WG = W / G;
   const long total = (long)BT * C * H * WG;
@@ -117,13 +119,27 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
   t /= H;
   const int c = (int)(t % C);
   const int bt = (int)(t / C);
-  const float* src = video + (((long)bt * C + c) * H + y) * W + xg * G;
+  const long soff = (((long)bt * C + c) * H + y) * W + xg * G;
   float v[G];
-  if (G == 4) {
-    const f32x4_t q = *(const f32x4_t*)src;
-    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+  if (U8) {
+    // decoded frames as they come off the decoder (uint8): ToTensor's x / 255 and Normalize's (x - mean) / std happen here,
+    // in that order and in fp32 with IEEE division = bit-identical to the host transform (data_loader/transforms.py:38-39,
+    // base/base_dataset.py read_frames `/ 255`); the H2D copy and the HBM read are 4x smaller
+    const unsigned char* src = (const unsigned char*)video_ + soff;
+    const float mu = nrm.mean[c], sd = nrm.std[c];
+    unsigned bits;
+    if (G == 4) bits = *(const unsigned*)src;
+    else bits = *(const unsigned short*)src;
+#pragma unroll
+    for (int e = 0; e < G; ++e) v[e] = ((float)((bits >> (8 * e)) & 0xffu) / 255.0f - mu) / sd;
   } else {
-    v[0] = src[0]; v[1] = src[1];
+    const float* src = (const float*)video_ + soff;
+    if (G == 4) {
+      const f32x4_t q = *(const f32x4_t*)src;
+      v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    } else {
+      v[0] = src[0]; v[1] = src[1];
+    }
   }
   const int gw = W / P, gh = H / P;
   const int py = y / P, iy = y % P;
@@ -296,20 +312,39 @@ extern "C" int egv_relu_split(const float* x, int64_t ldx, int32_t rows, int32_t
   return EGV_OK;
 }
 
-extern "C" int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
-                                egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream) {
+template <bool U8>
+static int patch_gather_launch(const void* video, int BT, int C, int H, int W, int P, egv_bf16* a_hi, egv_bf16* a_lo,
+                               int64_t lda, const PatchNorm& nrm, void* stream) {
   if (!video || !a_hi || P % 2 != 0 || W % P != 0 || H % P != 0 || lda % 2 != 0) return EGV_ERR_ARG;
   if (P % 4 == 0) {
     const long total = (long)BT * C * H * (W / 4);
-    EGV_LAUNCH(patch_gather_kernel<4>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C, H, W, P,
-               a_hi, a_lo, lda);
+    EGV_LAUNCH((patch_gather_kernel<4, U8>), dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C, H, W,
+               P, a_hi, a_lo, lda, nrm);
   } else {
     const long total = (long)BT * C * H * (W / 2);
-    EGV_LAUNCH(patch_gather_kernel<2>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C, H, W, P,
-               a_hi, a_lo, lda);
+    EGV_LAUNCH((patch_gather_kernel<2, U8>), dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, video, BT, C, H, W,
+               P, a_hi, a_lo, lda, nrm);
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;
+}
+
+extern "C" int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
+                                egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream) {
+  return patch_gather_launch<false>(video, BT, C, H, W, P, a_hi, a_lo, lda, PatchNorm{}, stream);
+}
+
+extern "C" int egv_patch_gather_u8(const uint8_t* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
+                                   const float* mean, const float* std, egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda,
+                                   void* stream) {
+  if (!mean || !std || C < 1 || C > 4) return EGV_ERR_ARG;
+  PatchNorm nrm{};
+  for (int c = 0; c < C; ++c) {
+    if (!(std[c] > 0.f)) return EGV_ERR_ARG;
+    nrm.mean[c] = mean[c];
+    nrm.std[c] = std[c];
+  }
+  return patch_gather_launch<true>(video, BT, C, H, W, P, a_hi, a_lo, lda, nrm, stream);
 }
 
 extern "C" int egv_assemble_tokens(const float* pe, const float* cls, const float* pos, const float* temporal,

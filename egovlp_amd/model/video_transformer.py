@@ -176,10 +176,11 @@ class _PatchTokensFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, video, geom, wc, proj_w, proj_b, cls_token, pos_embed, temporal_embed):
-        B, T, n, P_, D, T_model = geom
+        B, T, n, P_, D, T_model = geom[:6]
         Pp = Precision.fwd_passes
         _GRAD_PLANES.clear()
-        a = ops.patch_gather(video.contiguous(), P_, Pp)
+        mean, std = geom[6] if len(geom) > 6 else (ops.IMAGENET_MEAN, ops.IMAGENET_STD)
+        a = ops.patch_gather(video.contiguous(), P_, Pp, mean, std)   # uint8 frames: /255 + Normalize inside the gather
         K = proj_w[0].numel()
         if a.cols == K:
             w_pl = wc.get(proj_w, need_t=False)[0]
@@ -194,7 +195,7 @@ class _PatchTokensFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx):
-        B, T, n, P_, D, T_model = ctx.geom
+        B, T, n, P_, D, T_model = ctx.geom[:6]
         Pb = Precision.bwd_passes
         _GRAD_PLANES.clear()      # block 0's input-gradient planes have no consumer
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
@@ -372,7 +373,9 @@ class SpaceTimeTransformer(nn.Module):
         n = (Hh // P_) * (Ww // P_)
         if n != self.patches_per_frame:
             raise NotImplementedError("input resolution must match the positional embedding")
-        geom = (b, curr_frames, n, P_, self.embed_dim, self.num_frames)
+        # `input_norm` = (mean, std) of the loader's Normalize (data_loader/transforms.py:34-39); only used when the frames
+        # arrive as decoded uint8 (then x / 255 and the normalisation are fused into the patch gather on the device)
+        geom = (b, curr_frames, n, P_, self.embed_dim, self.num_frames, getattr(self, "input_norm", (ops.IMAGENET_MEAN, ops.IMAGENET_STD)))
         x = _PatchTokensFn.apply(x, geom, self._wc, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
                                  self.cls_token, self.pos_embed, self.temporal_embed)
         for blk in self.blocks:                                                # :325-328

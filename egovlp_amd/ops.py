@@ -282,14 +282,25 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
 
 
 # ------------------------------------------------------------------------------------------ video tokens
-def patch_gather(video5d, P, passes) -> Planes:
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)    # data_loader/transforms.py:34-35 defaults
+
+
+def patch_gather(video5d, P, passes, norm_mean=IMAGENET_MEAN, norm_std=IMAGENET_STD) -> Planes:
     """im2col planes [B*T*patches, K = C*P*P]; K is padded with zero columns to a multiple of 64 (the GEMM k-tile;
-    588 -> 640 for ViT-L/14), `cols` of the returned planes is the PADDED width."""
+    588 -> 640 for ViT-L/14), `cols` of the returned planes is the PADDED width.  A uint8 `video5d` (decoded frames) is
+    scaled and normalised in the kernel (x / 255, then (x - mean) / std per channel) -- the loader's host transform."""
     B, T, Cc, H, W = video5d.shape
     rows = B * T * (H // P) * (W // P)
     K = Cc * P * P
     Kp = (K + 63) // 64 * 64
     pl = empty_planes(rows, Kp, passes, video5d.device, zero=(Kp != K))
+    if video5d.dtype == torch.uint8:
+        if len(norm_mean) != Cc or len(norm_std) != Cc:
+            raise ValueError("patch_gather: one mean / std per channel")
+        mean, std = (C.c_float * Cc)(*norm_mean), (C.c_float * Cc)(*norm_std)
+        check(_lib.lib().egv_patch_gather_u8(_p(video5d), B * T, Cc, H, W, P, mean, std, _p(pl.hi), _p(pl.lo), pl.ld,
+                                             _stream()), "egv_patch_gather_u8")
+        return pl
     check(_lib.lib().egv_patch_gather(_p(video5d), B * T, Cc, H, W, P, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
           "egv_patch_gather")
     return pl

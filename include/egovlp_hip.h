@@ -104,6 +104,11 @@ int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy
  * A[(bt*gh + py)*gw + px][c*P*P + i*P + j] split planes, K = C*P*P (a multiple of 32 for P=16/C=3).   */
 int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
                      egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream);
+/* The same gather straight from decoded uint8 frames [B*T,C,H,W]: ToTensor's x/255 and
+ * Normalize's (x - mean[c]) / std[c] (data_loader/transforms.py:38-39; base/base_dataset.py `frames.float() / 255`) are
+ * applied in the kernel, fp32, same operation order = bit-identical planes; `mean` / `std` are HOST arrays of C <= 4 floats. */
+int egv_patch_gather_u8(const uint8_t* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
+                        const float* mean, const float* std, egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream);
 /* x[b,0,:] = cls + pos[0]; x[b,1+f*n+i,:] = pe[(b*T+f)*n+i,:] + pos[1+i] + temporal[f]
  * (model/video_transformer.py:305-320; pos tiling by the MODEL's num_frames, sliced to T).          */
 int egv_assemble_tokens(const float* pe, const float* cls, const float* pos, const float* temporal,

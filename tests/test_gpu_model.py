@@ -239,3 +239,19 @@ def test_egomcq_validation_epoch_matches_oracle(full):
     want = egomcq_accuracy_metrics(ref, torch.cat([q["correct"] for q in questions]), torch.cat([q["type"] for q in questions]))
     assert res["nested_val_metrics"][0]["egomcq_accuracy_metrics"] == want
     m.train()
+
+
+def test_uint8_frames_give_the_same_video_embeddings(full):
+    """Decoded uint8 frames in (x / 255 and ImageNet Normalize fused into the patch gather) == fp32 frames normalised on the host."""
+    from egovlp_amd import ops
+    m, _ = full
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (2, 4, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean, std = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1), torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    host = (u8.float() / 255).sub(mean).div(std)
+    m.eval()
+    with torch.no_grad():
+        a = m.compute_video(u8.cuda())
+        b = m.compute_video(host.cuda())
+    assert torch.equal(a, b)
+    m.train()

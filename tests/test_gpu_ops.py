@@ -65,6 +65,14 @@ def test_patch_gather_and_assemble(ops):
     a14 = ops.patch_gather(v14.cuda(), 14, 3)
     r14 = F.unfold(v14.view(4, 3, 28, 42), kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588)
     assert a14.cols == 640 and rel(a14.float()[:, :588], r14) < 1e-5 and float(a14.float()[:, 588:].abs().max()) == 0.0
+    # decoded uint8 frames: x / 255 then (x - mean) / std inside the gather == the loader's host transform, bit for bit
+    # (base/base_dataset.py `frames.float() / 255`, data_loader/transforms.py:38-39 Normalize)
+    for (shape, Pq) in (((2, 3, 3, 32, 48), 16), ((2, 2, 3, 28, 42), 14)):
+        u8 = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+        mean, std = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1), torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+        host = (u8.float() / 255).sub(mean).div(std)
+        got, want = ops.patch_gather(u8.cuda(), Pq, 3), ops.patch_gather(host.cuda(), Pq, 3)
+        assert torch.equal(got.hi, want.hi) and torch.equal(got.lo, want.lo)
     n = (H // P) * (W // P)
     pe = torch.randn(B * T * n, D, generator=g)
     cls, pos, tmp = torch.randn(1, 1, D, generator=g), torch.randn(1, n + 1, D, generator=g), torch.randn(1, 5, D, generator=g)
