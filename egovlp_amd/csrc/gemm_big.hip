@@ -46,10 +46,6 @@
 #include "common.h"
 #include "egovlp_hip.h"
 
-#ifndef EGV_GEMM_RING
-#define EGV_GEMM_RING 1   // NT main loop: 1 = four-stage ring of 32-deep k-tiles, 0 = two stages of 64 (kept for A/B builds)
-#endif
-
 namespace {
 
 constexpr int KT = 64;    // contraction depth of one LDS tile
@@ -112,12 +108,6 @@ __device__ __forceinline__ void lgkm_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void tie(bf16x8_t& x) { asm volatile("" : "+v"(x)); }
-
-__device__ __forceinline__ const char* uniform_ptr(const char* q) {   // wave-uniform by construction: tell the compiler
-  const unsigned long long v = (unsigned long long)q;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const char*)(((unsigned long long)hi << 32) | lo);
-}
 
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -272,30 +262,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 
   // TN keeps ONE fragment set: the pending halves of the asm reads are its second buffer (commit happens after the
   // phase's MFMAs), which keeps the kernel under 256 VGPRs without spills -- a spilled pending half would be read early.
-  bf16x8_t A[TN ? 1 : 2][MF], Bq[TN ? 1 : 4][NC];
+  bf16x8_t A[TN ? 1 : 2][MF], Bq[TN ? 1 : 3][NC];
   // NT: plain LDS loads straight into the destination fragments (issue = load, commit = nothing).
   // TN: asm transpose reads into pending halves (issue), combined into the fragment after the hand-placed wait (commit).
   u32x2_t pa[TN ? MF : 1][2], pb[TN ? NC : 1][2];
   const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
   const unsigned fa = lds0 + a_rd0, fb = lds0 + b_rd0;   // NT asm fragment reads (the stages are 128-B aligned: k-step 1 = ^ 64)
-
-  // ---- NT ring (EGV_GEMM_RING): four LDS stages of a 32-deep k-tile each, (BM + 256) rows of 64 B -------------------------
-  // LDS image: 64-B rows, 16-B chunk index XOR g[(row >> 2) & 3], g = {0,2,3,1} (conflict-free for the four 16-lane groups a
-  // ds_read_b128 is served in; the DMA destination is lane-linear, so the same involution goes on the per-lane SOURCE chunk).
-  // A DMA piece = 16 rows x 64 B; loader wave w (0..3) owns A pieces w*MF .. w*MF+MF-1 and B pieces 4w .. 4w+3 of every k-tile.
-  constexpr bool RING = !TN && (EGV_GEMM_RING != 0);
-  constexpr int STAGE_R = (BM + BNB) * 64, A_R = BM * 64, NPL = MF + 4;
-  static_assert(4 * STAGE_R == 2 * STAGE, "the ring occupies exactly the two 64-deep stages");
-  unsigned r_avo = 0, r_bvo = 0, fa_r = 0, fb_r = 0;
-  if (RING) {
-    const int srcchunk = (lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3);
-    r_avo = (unsigned)(((lane >> 2) + (wave & 3) * MF * 16) * p.lda * 2 + srcchunk * 16);
-    r_bvo = (unsigned)(((lane >> 2) + (wave & 3) * 64) * p.ldb * 2 + srcchunk * 16);
-    const int fr = lane & 15;
-    const int foff = fr * 64 + (((lane >> 4) ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) * 16);
-    fa_r = lds0 + (wm * MF * 16) * 64 + foff;
-    fb_r = lds0 + A_R + (wn * 128) * 64 + foff;
-  }
   auto issue_a = [&](int sb, int ks, bf16x8_t (&dst)[MF], int f0 = 0, int f1 = MF) {
 #pragma unroll
     for (int f = 0; f < MF; ++f) {
@@ -426,48 +398,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     stage_advance();
   };
 
-  const char *dma_a = nullptr, *dma_b = nullptr;   // scalar base of the k-tile being staged (opaque: not re-derived per piece)
-  // ring staging: piece i (0..NPL-1) of this loader's share of the k-tile being staged (32-deep: st_kt counts 32s)
-  auto r_bases = [&]() {
-    if (RING) {
-      dma_a = uniform_ptr((const char*)(seg_a(st_seg) + (long)sm0 * p.lda + (long)st_kt * 32));
-      dma_b = uniform_ptr((const char*)(seg_b(st_seg) + (long)sn0 * p.ldb + (long)st_kt * 32));
-      asm volatile("" : "+s"(dma_a), "+s"(dma_b));
-    }
-  };
-  auto r_piece = [&](char* lds, int i, int i0) {
-    if (i < MF) {
-      if (i == i0) run = r_avo + (unsigned)(i * 32 * p.lda);
-      glds16(dma_a + (size_t)run, lds + ((wave & 3) * MF + i) * 1024);
-      run += (unsigned)(32 * p.lda);
-    } else {
-      const int j = i - MF;
-      if (i == i0 || j == 0) run = r_bvo + (unsigned)(j * 32 * p.ldb);
-      glds16(dma_b + (size_t)run, lds + A_R + ((wave & 3) * 4 + j) * 1024);
-      run += (unsigned)(32 * p.ldb);
-    }
-    asm volatile("" : "+v"(run));
-  };
-  auto r_stage = [&](int slot) {   // burst: one whole k-tile -> ring slot (prologue / hand-over only)
-    if (loader) {
-      r_bases();
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) r_piece(smem + slot * STAGE_R, i, 0);
-    }
-    stage_advance();
-  };
-
   int v = blockIdx.x;
   if (v >= total) return;
   decode(v, m0, n0, z, tn, kt_begin, kt_end);
-  if (RING) { kt_begin *= 2; kt_end *= 2; }   // the ring counts 32-deep k-tiles
   nt = max(kt_end - kt_begin, 0) * nseg;
   sm0 = m0; sn0 = n0; skt_begin = kt_begin; skt_end = kt_end; st_seg = 0; st_kt = kt_begin;
-  if (RING) {
-    for (int u = 0; u < min(nt, 3); ++u) r_stage(u);
-  } else if (nt > 0) {
-    stage(0);
-  }
+  if (nt > 0) stage(0);
 
   for (;;) {
     if ((dbg & 0xfff) == 200) ts0 = __builtin_amdgcn_s_memrealtime();
@@ -482,85 +418,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
     for (int i = 0; i < MF; ++i) cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (RING) {
-      // ---- NT main loop, four-stage ring of 32-deep k-tiles ---------------------------------------------------------------
-      // k-tile u lives in slot u & 3.  Invariant at the top of k-tile u: tiles u and u+1 are visible in LDS (made so by the
-      // barrier that ended u-1), tile u+2 is in flight, slot (u+3) & 3 = (u-1) & 3 is free.  During k-tile u the loader waves
-      // issue the DMA of tile u+3 (a few pieces per phase) and EVERY wave already fetches the first fragments of tile u+1
-      // (B two phases ahead through four register sets, the A set of u+1 over phases 0-2): the matrix pipe has its operands
-      // for the phases behind the barrier before the barrier is reached, so the barrier costs its skew, not a fragment-read
-      // burst of all eight waves; and a DMA has a full k-tile to land instead of what is left of the one it was issued in.
-      // Phase c multiplies MF x 2 fragments: A set u & 1, B set c.  Reads per phase (issued first, in this order):
-      //   c0: B(u,2) A(u+1)[0,1]   c1: B(u,3) A(u+1)[2,3]   c2: B(u+1,0) A(u+1)[4]   c3: B(u+1,1)
-      auto ring_tile = [&](auto PARc, const int u) {
-        constexpr int PAR = decltype(PARc)::value;
-        const int so = (u & 3) * STAGE_R, sn = ((u + 1) & 3) * STAGE_R;
-        const unsigned ra = fa_r + so, rb = fb_r + so, na = fa_r + sn, nb = fb_r + sn;
-        char* dma_lds = smem + ((u + 3) & 3) * STAGE_R;
-        int dma_on = __builtin_amdgcn_readfirstlane((int)(loader && u + 3 < nt));
-        asm volatile("" : "+s"(dma_on));
-        if (dma_on) r_bases();
-        constexpr int nA2 = MF > 4 ? 1 : 0;
-        static_for<0, 4>([&](auto Cc) {
-          constexpr int c = decltype(Cc)::value;
-          if constexpr (c < 2) {
-            Bq[c + 2][0] = ld128_asm<((c + 2) * NC) * 1024>(rb);
-            Bq[c + 2][1] = ld128_asm<((c + 2) * NC + 1) * 1024>(rb);
-            A[1 - PAR][2 * c] = ld128_asm<(2 * c) * 1024>(na);
-            A[1 - PAR][2 * c + 1] = ld128_asm<(2 * c + 1) * 1024>(na);
-          } else {
-            Bq[c - 2][0] = ld128_asm<((c - 2) * NC) * 1024>(nb);
-            Bq[c - 2][1] = ld128_asm<((c - 2) * NC + 1) * 1024>(nb);
-            if constexpr (c == 2 && MF > 4) A[1 - PAR][4] = ld128_asm<4 * 1024>(na);
-          }
-          if (dma_on) {
-            constexpr int P0 = c == 0 ? 0 : (NPL - 6) + 2 * (c - 1) + 0, P1 = c == 0 ? NPL - 6 : P0 + 2;   // NPL-6, 2, 2, 2 pieces
-            static_for<P0, P1>([&](auto Ic) { r_piece(dma_lds, decltype(Ic)::value, P0); });
-          }
-          constexpr int WAITS[4] = {6, 8, 8 + nA2, 6 + nA2};
-          lgkm_wait<WAITS[c]>();
-          tie(Bq[c][0]);
-          tie(Bq[c][1]);
-          if constexpr (c == 0) static_for<0, MF>([&](auto Ic) { tie(A[PAR][decltype(Ic)::value]); });
-          __builtin_amdgcn_sched_barrier(0);
-          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[c][0], A[PAR][0], acc[0][c * NC], 0, 0, 0);
-          if constexpr (c == 3) {
-            __builtin_amdgcn_sched_barrier(0);
-            // hand-over: tile u+2 (this wave's pieces) has landed -- the DMA of u+3 issued above may still be in flight;
-            // every read of slot u & 3 by this wave was issued by phase 1 and has returned (the counted waits are in order)
-            if (u + 3 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (u + 3 < nt) stage_advance();
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int jj = 0; jj < NC; ++jj)
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-              if (jj + i > 0)
-                acc[i][c * NC + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[c][jj], A[PAR][i], acc[i][c * NC + jj], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      };
-      if (nt > 0) {
-        // tiles 0 and 1 visible (tile 2, if any, may still be in flight); the epilogue stores of the previous output tile
-        // are older than every DMA of this one, so from here on vmcnt only counts DMA pieces
-        if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        Bq[0][0] = ld128_asm<0>(fb_r);
-        Bq[0][1] = ld128_asm<1024>(fb_r);
-        static_for<0, MF>([&](auto Ic) { A[0][decltype(Ic)::value] = ld128_asm<decltype(Ic)::value * 1024>(fa_r); });
-        Bq[1][0] = ld128_asm<2 * 1024>(fb_r);
-        Bq[1][1] = ld128_asm<3 * 1024>(fb_r);
-        if ((dbg & 0xfff) == 200) ts1 = __builtin_amdgcn_s_memrealtime();
-        for (int u = 0; u < nt; u += 2) {      // nt is even: K % 64 == 0
-          ring_tile(std::integral_constant<int, 0>{}, u);
-          ring_tile(std::integral_constant<int, 1>{}, u + 1);
-        }
-      }
-    } else if constexpr (!TN) {
+    if constexpr (!TN) {
       // ---- NT main loop ------------------------------------------------------------------------------------------------
       // Phase q = (k-step q/4, B column pair q%4) multiplies MF x 2 fragments: A set q/4, B set q%3.  Fetch plan per
       // k-tile (reads complete in issue order, so every wait is a count of the reads issued after the ones needed):
@@ -774,14 +632,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     if (has_next) {
       // first k-tile of the NEXT output tile -> stage 0, in flight while this tile's epilogue drains through stage 1
       decode(vn, nm0, nn0, nz, ntn, nkb, nke);
-      if (RING) { nkb *= 2; nke *= 2; }
       nnt = max(nke - nkb, 0) * nseg;
       sm0 = nm0; sn0 = nn0; skt_begin = nkb; skt_end = nke; st_seg = 0; st_kt = nkb;
-      if (RING) {   // k-tiles 0 and 1 -> ring slots 0 and 1; slots 2 and 3 are this tile's epilogue staging rows
-        for (int u = 0; u < min(nnt, 2); ++u) r_stage(u);
-      } else if (nnt > 0) {
-        stage(0);
-      }
+      if (nnt > 0) stage(0);
     }
 
     // ================= epilogue of tile v ===========================================================================
@@ -825,7 +678,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     // after the barrier stage 1 (the epilogue staging rows of every wave) may be overwritten by k-tile 1.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (RING && nt > 2) r_stage(2);   // the third k-tile follows once the staging rows (slots 2, 3) are free
   }
 }
 
