@@ -11,12 +11,12 @@ namespace {
 // block-reduced and accumulated with one atomicAdd per column per block (colsum is zeroed first).
 // SRC_PLANES: the source is already a pair of bf16 planes (value = hi + lo) instead of fp32.
 template <bool SRC_PLANES>
-__global__ __launch_bounds__(256) void split_transpose_kernel(
+__device__ __forceinline__ void split_transpose_tile(
     const float* __restrict__ x, const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, long ldx, int rows,
     int cols, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long ldo, bf16_t* __restrict__ thi,
-    bf16_t* __restrict__ tlo, long ldt, float* __restrict__ colsum) {
+    bf16_t* __restrict__ tlo, long ldt, float* __restrict__ colsum, const int r0, const int c0, const int text) {
+  // text: columns of the transposed planes this tensor owns (>= rows; rows .. text-1 are zero-filled)
   __shared__ float tile[64][65];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
   const int tr = tid >> 4;         // 0..15
   const int tc = (tid & 15) * 4;   // 0..60
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(
     for (int cc = 0; cc < 64; cc += 16) {
       const int c = c0 + cc + tr;   // output row
       const int r = r0 + tc;        // output col start (4 consecutive source rows)
-      if (c < cols && r < ldt) {
+      if (c < cols && r < text) {
         bf16_t h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -80,6 +80,39 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(
       }
     }
   }
+}
+
+template <bool SRC_PLANES>
+__global__ __launch_bounds__(256) void split_transpose_kernel(
+    const float* __restrict__ x, const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, long ldx, int rows,
+    int cols, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long ldo, bf16_t* __restrict__ thi,
+    bf16_t* __restrict__ tlo, long ldt, float* __restrict__ colsum) {
+  split_transpose_tile<SRC_PLANES>(x, xh, xl, ldx, rows, cols, hi, lo, ldo, thi, tlo, ldt, colsum, blockIdx.y * 64,
+                                   blockIdx.x * 64, (int)ldt);
+}
+
+// The same tile for MANY tensors in one launch (the once-per-optimizer-step refresh of every weight's operand planes:
+// ~100 tensors, one ~8 us launch each when done one by one).  Pointer tables travel in the kernel arguments.
+constexpr int SPLIT_MAX_T = 40;
+struct SplitTable {
+  const float* x[SPLIT_MAX_T];
+  bf16_t* hi[SPLIT_MAX_T];
+  bf16_t* lo[SPLIT_MAX_T];
+  bf16_t* thi[SPLIT_MAX_T];
+  bf16_t* tlo[SPLIT_MAX_T];
+  int ldx[SPLIT_MAX_T], ldo[SPLIT_MAX_T], ldt[SPLIT_MAX_T], rows[SPLIT_MAX_T], cols[SPLIT_MAX_T], text[SPLIT_MAX_T];
+  int tiles_x[SPLIT_MAX_T];
+  int blk_start[SPLIT_MAX_T + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void split_multi_kernel(const SplitTable t) {
+  int ti = 0;
+  while (ti + 1 < t.count && (int)blockIdx.x >= t.blk_start[ti + 1]) ++ti;
+  const int local = (int)blockIdx.x - t.blk_start[ti];
+  const int ty = local / t.tiles_x[ti], tx = local - ty * t.tiles_x[ti];
+  split_transpose_tile<false>(t.x[ti], nullptr, nullptr, t.ldx[ti], t.rows[ti], t.cols[ti], t.hi[ti], t.lo[ti], t.ldo[ti],
+                              t.thi[ti], t.tlo[ti], t.ldt[ti], nullptr, ty * 64, tx * 64, t.text[ti]);
 }
 
 // relu(x) -> split planes (txt_proj's ReLU, model/model.py:73)
@@ -284,6 +317,44 @@ extern "C" int egv_split_f32(const float* x, int64_t ldx, int32_t rows, int32_t 
                      ldo, t_hi, t_lo, ldt, colsum);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
+}
+
+extern "C" int egv_split_f32_multi(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows,
+                                   const int32_t* cols, egv_bf16* const* hi, egv_bf16* const* lo, const int64_t* ldo,
+                                   egv_bf16* const* t_hi, egv_bf16* const* t_lo, const int64_t* ldt, const int32_t* t_cols,
+                                   void* stream) {
+  if (count < 0 || !x || !ldx || !rows || !cols || !hi || !lo || !ldo || !t_hi || !t_lo || !ldt || !t_cols) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SplitTable t;
+  int nt = 0, nb = 0;
+  auto flush = [&]() -> int {
+    if (nt == 0) return EGV_OK;
+    t.blk_start[nt] = nb;
+    t.count = nt;
+    EGV_LAUNCH(split_multi_kernel, dim3(nb), dim3(256), 0, s, t);
+    EGV_CHECK_LAUNCH();
+    nt = 0;
+    nb = 0;
+    return EGV_OK;
+  };
+  for (int i = 0; i < count; ++i) {
+    if (!x[i] || rows[i] <= 0 || cols[i] <= 0 || cols[i] % 4 != 0 || (!hi[i] && !t_hi[i])) return EGV_ERR_ARG;
+    if (t_hi[i] && (ldt[i] < rows[i] || ldt[i] % 4 != 0 || t_cols[i] < rows[i] || t_cols[i] > ldt[i] || t_cols[i] % 4 != 0)) return EGV_ERR_ARG;
+    if (ldx[i] > 0x7fffffff || ldo[i] > 0x7fffffff || ldt[i] > 0x7fffffff) return EGV_ERR_ARG;
+    if (nt == SPLIT_MAX_T) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+    const int row_extent = t_hi[i] ? t_cols[i] : rows[i];   // cover this tensor's share of the zero pad of the transposed planes
+    const int tx = (cols[i] + 63) / 64, ty = (row_extent + 63) / 64;
+    t.x[nt] = x[i]; t.hi[nt] = hi[i]; t.lo[nt] = lo[i]; t.thi[nt] = t_hi[i]; t.tlo[nt] = t_lo[i];
+    t.ldx[nt] = (int)ldx[i]; t.ldo[nt] = (int)ldo[i]; t.ldt[nt] = (int)ldt[i]; t.rows[nt] = rows[i]; t.cols[nt] = cols[i]; t.text[nt] = t_hi[i] ? t_cols[i] : rows[i];
+    t.tiles_x[nt] = tx;
+    t.blk_start[nt] = nb;
+    nb += tx * ty;
+    ++nt;
+  }
+  return flush();
 }
 
 extern "C" int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, int32_t rows, int32_t cols,

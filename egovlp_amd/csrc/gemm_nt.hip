@@ -196,8 +196,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const egv_gemm_desc p) 
 
 // out[m][n] = sum_z partial[z][m][n] (+bias); fp32, vectorised, HBM-bound.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                            long mn, int ksplit, int accumulate) {
-  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+                                                            long mn, int ksplit, int accumulate,
+                                                            const float* __restrict__ partial2, float* __restrict__ out2,
+                                                            long n2, int blocks1) {
+  // second segment (blocks >= blocks1): the column-sum slab of a wgrad (bias gradient) rides in the same launch
+  if ((int)blockIdx.x >= blocks1) {
+    partial = partial2;
+    out = out2;
+    mn = n2;
+    accumulate = 0;
+  }
+  const long i4 = ((long)((int)blockIdx.x >= blocks1 ? (int)blockIdx.x - blocks1 : (int)blockIdx.x) * blockDim.x + threadIdx.x) * 4;
   if (i4 >= mn) return;
   f32x4_t s = *(const f32x4_t*)(partial + i4);
   for (int z = 1; z < ksplit; ++z) s += *(const f32x4_t*)(partial + (long)z * mn + i4);
@@ -263,15 +272,12 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
     if (!p.out_f32 || p.ldo != p.N) return EGV_ERR_ARG;
     const long mn = (long)p.M * p.N;
     const int blocks = (int)((mn / 4 + 255) / 256);
-    EGV_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.partial, p.out_f32, mn, ks,
-                       p.accumulate);
+    // the ksplit x M column-sum slab (bias gradient) sits behind the ksplit x M x N product slab: one launch reduces both
+    if (p.colsum && p.M % 4 != 0) return EGV_ERR_ARG;
+    const int blocks2 = p.colsum ? (p.M / 4 + 255) / 256 : 0;
+    EGV_LAUNCH(splitk_reduce_kernel, dim3(blocks + blocks2), dim3(256), 0, s, p.partial, p.out_f32, mn, ks, p.accumulate,
+               p.partial + (long)ks * mn, p.colsum, (long)p.M, blocks);
     EGV_CHECK_LAUNCH();
-    if (p.colsum) {   // the ksplit x M column-sum slab sits behind the ksplit x M x N product slab
-      if (p.M % 4 != 0) return EGV_ERR_ARG;
-      EGV_LAUNCH(splitk_reduce_kernel, dim3((p.M / 4 + 255) / 256), dim3(256), 0, s, p.partial + (long)ks * mn,
-                 p.colsum, (long)p.M, ks, 0);
-      EGV_CHECK_LAUNCH();
-    }
   }
   return EGV_OK;
 }

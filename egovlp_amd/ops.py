@@ -212,6 +212,27 @@ def split_f32(x2d: torch.Tensor, passes, *, want_rowmajor=True, want_transposed=
     return pl, tp, cs
 
 
+def split_f32_multi(jobs):
+    """One launch for many fp32 -> split-plane conversions.  jobs: (x2d [rows, cols] fp32, hi, lo, ldo, t_hi, t_lo, ldt, t_cols)
+    with hi / lo / t_hi / t_lo raw device addresses (or None); see egv_split_f32_multi."""
+    n = len(jobs)
+    if n == 0:
+        return
+    vp, i64, i32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+    X = vp(*[j[0].data_ptr() for j in jobs])
+    LDX = i64(*[j[0].stride(0) for j in jobs])
+    R = i32(*[j[0].shape[0] for j in jobs])
+    Cc = i32(*[j[0].shape[1] for j in jobs])
+    HI, LO = vp(*[j[1] for j in jobs]), vp(*[j[2] for j in jobs])
+    LDO = i64(*[j[3] for j in jobs])
+    THI, TLO = vp(*[j[4] for j in jobs]), vp(*[j[5] for j in jobs])
+    LDT = i64(*[j[6] for j in jobs])
+    TC = i32(*[j[7] for j in jobs])
+    for j in jobs:
+        _need_cuda(j[0])
+    check(_lib.lib().egv_split_f32_multi(n, X, LDX, R, Cc, HI, LO, LDO, THI, TLO, LDT, TC, _stream()), "egv_split_f32_multi")
+
+
 def transpose_planes(x: Planes, passes, want_colsum=False):
     """Planes [rows, cols] -> Planes [cols, pad32(rows)] (zero pad) (+ column sums of hi+lo)."""
     dev = x.hi.device

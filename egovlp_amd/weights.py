@@ -1,9 +1,11 @@
-"""Split-bf16 operand planes of the 2-D weights, refreshed lazily when a parameter changes.
+"""Split-bf16 operand planes of the 2-D weights, refreshed when a parameter changes.
 
 Parameters stay ordinary fp32 `nn.Parameter`s (checkpoints, optimizers and DDP keep working, SURVEY
-8b "Ownership"); the GEMMs read derived bf16 planes W[N,K] (forward) and W^T[K,N] (dgrad).  A plane
-set is rebuilt by one egv_split_f32 launch when (param._version, EPOCH) differs from the cached one;
-optimizers that update weights through raw pointers (egovlp_amd.optim.AdamW) bump EPOCH.
+8b "Ownership"); the GEMMs read derived bf16 planes W[N,K] (forward) and W^T[K,N] (dgrad).  The planes of a
+weight are allocated once and live as long as the cache entry; they are stale when (param._version, EPOCH,
+data_ptr) differs from what they were built from -- optimizers that update weights through raw pointers
+(egovlp_amd.optim.AdamW) bump EPOCH.  The first stale weight touched after an optimizer step refreshes EVERY stale
+entry of the cache in place with ONE egv_split_f32_multi launch (~100 tensors; one ~8 us launch each otherwise).
 """
 from __future__ import annotations
 
@@ -19,35 +21,79 @@ def bump_epoch():
     EPOCH += 1
 
 
+class _Entry:
+    __slots__ = ("params", "ver", "pl", "tp")
+
+    def __init__(self, params):
+        self.params, self.ver, self.pl, self.tp = params, None, None, None
+
+    def version(self):
+        return tuple((p._version, EPOCH, p.data_ptr()) for p in self.params)
+
+    def shapes_ok(self):
+        n = sum(p.shape[0] for p in self.params)
+        k = self.params[0][0].numel() if self.params[0].dim() > 1 else 1
+        return self.pl is not None and (self.pl.rows, self.pl.cols) == (n, k)
+
+
 class WeightCache:
     def __init__(self):
         self._c = {}
 
+    # -- one launch for every stale entry that already owns its planes
+    def _refresh_all(self):
+        jobs, done = [], []
+        for ent in self._c.values():
+            ver = ent.version()
+            if ent.ver == ver or ent.pl is None or not ent.shapes_ok():
+                continue
+            off = 0
+            for i, p in enumerate(ent.params):
+                w2 = p.detach().reshape(p.shape[0], -1)
+                if not w2.is_contiguous():
+                    w2 = w2.contiguous()
+                n_i, last = w2.shape[0], i == len(ent.params) - 1
+                hi = ent.pl.hi.data_ptr() + off * ent.pl.ld * 2
+                lo = ent.pl.lo.data_ptr() + off * ent.pl.ld * 2
+                if ent.tp is not None:
+                    thi, tlo = ent.tp.hi.data_ptr() + off * 2, ent.tp.lo.data_ptr() + off * 2
+                    ldt, tcols = ent.tp.ld, (ent.tp.ld - off if last else n_i)
+                else:
+                    thi = tlo = None
+                    ldt, tcols = 0, n_i
+                jobs.append((w2, hi, lo, ent.pl.ld, thi, tlo, ldt, tcols))
+                off += n_i
+            done.append((ent, ver))
+        ops.split_f32_multi(jobs)
+        for ent, ver in done:
+            ent.ver = ver
+
+    def _get(self, params, need_t: bool):
+        key = tuple(id(p) for p in params)
+        ent = self._c.get(key)
+        if ent is None:
+            ent = self._c[key] = _Entry(list(params))
+        if ent.ver == ent.version() and (ent.tp is not None or not need_t):
+            return ent.pl, ent.tp
+        if ent.pl is not None and ent.shapes_ok() and (ent.tp is not None or not need_t):
+            self._refresh_all()                 # stale after an optimizer step: refresh the whole cache in one launch
+            return ent.pl, ent.tp
+        # first use (or the transposed planes are wanted for the first time): allocate and fill this entry alone
+        w2 = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], dim=0) if len(params) > 1 \
+            else params[0].detach().reshape(params[0].shape[0], -1)
+        # planes always carry lo; single-pass GEMMs simply ignore it
+        ent.pl, ent.tp, _ = ops.split_f32(w2, 3, want_rowmajor=True, want_transposed=need_t or ent.tp is not None)
+        ent.ver = ent.version()
+        return ent.pl, ent.tp
+
     def get(self, param: torch.Tensor, need_t: bool):
         """-> (Planes [N,K], Planes [K,N] | None).  `param` is [N, ...] (conv weights are flattened to [N, K])."""
-        key = id(param)
-        ver = (param._version, EPOCH, param.data_ptr())
-        ent = self._c.get(key)
-        if ent is None or ent[0] != ver or (need_t and ent[2] is None):
-            w2 = param.detach().reshape(param.shape[0], -1)
-            passes = 3  # planes always carry lo; single-pass GEMMs simply ignore it
-            pl, tp, _ = ops.split_f32(w2, passes, want_rowmajor=True, want_transposed=need_t or (ent is not None and ent[2] is not None))
-            ent = (ver, pl, tp)
-            self._c[key] = ent
-        return ent[1], ent[2]
+        return self._get((param,), need_t)
 
     def get_cat(self, params, need_t: bool):
         """Planes of the row-wise concatenation of several [N_i, K] weights (DistilBERT's q/k/v projections run as ONE
         [3*768, 768] GEMM) -> (Planes [sum N_i, K], Planes [K, sum N_i] | None)."""
-        key = tuple(id(p) for p in params)
-        ver = tuple((p._version, EPOCH, p.data_ptr()) for p in params)
-        ent = self._c.get(key)
-        if ent is None or ent[0] != ver or (need_t and ent[2] is None):
-            w2 = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], dim=0)
-            pl, tp, _ = ops.split_f32(w2, 3, want_rowmajor=True, want_transposed=need_t or (ent is not None and ent[2] is not None))
-            ent = (ver, pl, tp)
-            self._c[key] = ent
-        return ent[1], ent[2]
+        return self._get(tuple(params), need_t)
 
     def clear(self):
         self._c.clear()

@@ -74,6 +74,13 @@ int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
 int egv_split_f32(const float* x, int64_t ldx, int32_t rows, int32_t cols,
                   egv_bf16* hi, egv_bf16* lo, int64_t ldo,
                   egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream);
+/* The same for `count` tensors in one launch (host arrays of device pointers / sizes; no column sums): the once-per-
+ * optimizer-step refresh of every weight's operand planes W[N,K] and W^T[K,N] (~100 tensors per step).
+ * t_cols[i] = columns of the transposed planes tensor i owns (rows[i] <= t_cols[i] <= ldt[i]; rows[i] .. t_cols[i]-1 are
+ * zero-filled) -- several tensors may share one pair of transposed planes side by side (DistilBERT's fused q/k/v weight). */
+int egv_split_f32_multi(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
+                        egv_bf16* const* hi, egv_bf16* const* lo, const int64_t* ldo, egv_bf16* const* t_hi,
+                        egv_bf16* const* t_lo, const int64_t* ldt, const int32_t* t_cols, void* stream);
 /* split planes [rows, cols] -> transposed planes [cols, ldt] (+ zero pad, + colsum of hi+lo).        */
 int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, int32_t rows, int32_t cols,
                          egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream);

@@ -354,3 +354,34 @@ def test_adamw_matches_transformers_4_2_1_semantics(ops):
             O.adamw_step(p, gr, m, v, step, lr=1e-2, weight_decay=0.01)
     for p, r in zip(params, ref_p):
         assert rel(p, r) < 1e-6
+
+
+def test_weight_cache_multi_tensor_refresh(ops):
+    """After an optimizer step every stale weight's planes (row-major, transposed, fused q/k/v) are rebuilt in place by ONE
+    egv_split_f32_multi launch; the result must equal a fresh one-by-one split, including the zero pad of W^T."""
+    from egovlp_amd import weights
+    g = torch.Generator().manual_seed(11)
+    ws = [torch.nn.Parameter(torch.randn(n, k, generator=g).cuda()) for n, k in ((768, 768), (3072, 768), (200, 64), (256, 768, ))]
+    conv = torch.nn.Parameter(torch.randn(64, 3, 4, 4, generator=g).cuda())
+    q, k_, v = [torch.nn.Parameter(torch.randn(40, 64, generator=g).cuda()) for _ in range(3)]
+    wc = weights.WeightCache()
+    for w in ws + [conv]:
+        wc.get(w, need_t=True)
+    wc.get_cat((q, k_, v), need_t=True)
+    ptrs = {id(w): wc.get(w, need_t=True)[0].hi.data_ptr() for w in ws}
+    with torch.no_grad():
+        for w in ws + [conv, q, k_, v]:
+            w.add_(torch.randn(w.shape, generator=g).cuda())        # bumps _version (an optimizer through raw pointers bumps EPOCH)
+    weights.bump_epoch()
+    pl0, tp0 = wc.get(ws[0], need_t=True)                            # refreshes the whole cache
+    assert pl0.hi.data_ptr() == ptrs[id(ws[0])]                      # in place
+    for w in ws + [conv]:
+        pl, tp = wc.get(w, need_t=True)
+        w2 = w.detach().reshape(w.shape[0], -1)
+        rp, rt, _ = ops.split_f32(w2, 3, want_rowmajor=True, want_transposed=True)
+        assert torch.equal(pl.hi, rp.hi) and torch.equal(pl.lo, rp.lo)
+        assert torch.equal(tp.hi, rt.hi) and torch.equal(tp.lo, rt.lo)
+    pl, tp = wc.get_cat((q, k_, v), need_t=True)
+    cat = torch.cat([q.detach(), k_.detach(), v.detach()], 0)
+    rp, rt, _ = ops.split_f32(cat, 3, want_rowmajor=True, want_transposed=True)
+    assert torch.equal(pl.hi, rp.hi) and torch.equal(pl.lo, rp.lo) and torch.equal(tp.hi, rt.hi) and torch.equal(tp.lo, rt.lo)
