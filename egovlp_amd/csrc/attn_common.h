@@ -28,7 +28,7 @@ __device__ __forceinline__ int att_off(int row, int col) {
 // row_ptr(r) returns the global pointer of row r (64 contiguous floats).  256 threads.
 template <typename RowPtr>
 __device__ __forceinline__ void att_stage(char* hi, char* lo, int nrows, int prows, float scale, RowPtr row_ptr) {
-  for (int t = threadIdx.x; t < prows * 8; t += 256) {
+  for (int t = threadIdx.x; t < prows * 8; t += blockDim.x) {
     const int row = t >> 3, chunk = t & 7;
     f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = a;
     if (row < nrows) {
@@ -117,7 +117,7 @@ __device__ __forceinline__ void att_gfrag(const float* rowp, int ks, int lane, f
 template <typename RowOff>
 __device__ __forceinline__ void att_stage_planes(char* hi, char* lo, const bf16_t* ph, const bf16_t* pl, int nrows,
                                                  int prows, RowOff row_off) {
-  for (int t = threadIdx.x; t < prows * 8; t += 256) {
+  for (int t = threadIdx.x; t < prows * 8; t += blockDim.x) {
     const int row = t >> 3, chunk = t & 7;
     u32x4_t a = {0u, 0u, 0u, 0u}, b = a;
     if (row < nrows) {

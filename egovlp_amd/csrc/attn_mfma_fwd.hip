@@ -2,7 +2,7 @@
 //   space attention of the SpaceTimeTransformer (model/video_transformer.py:114-133: per (b, frame, head)
 //   196 queries x (CLS + 196) keys) and DistilBERT's masked MHA (L x L per (b, head)).
 //
-// One workgroup (4 waves) per group.  The whole K and V of a group (<= 288 keys x 64) live in LDS as
+// One workgroup (4 waves; 8 in three-pass mode) per group.  The whole K and V of a group (<= 288 keys x 64) live in LDS as
 // swizzled split-bf16 planes, so scores never touch HBM (the reference materialises a 237 MB score
 // tensor per block) and no online-softmax rescaling is needed: a wave takes a 16-query
 // tile, computes S^T = K.Q^T for ALL keys into registers, does the row softmax with two wave shuffles
@@ -21,7 +21,7 @@ namespace {
 // partials of a (clip, head).  The CLS key is counted for the CLS query in frame-group 0 only.
 // q is NOT pre-scaled: scores are multiplied by 64^-0.5 after the MFMA (exact for the power of two).
 template <int MODE, int NKF, int PASSES>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
+__global__ __launch_bounds__(PASSES == 3 ? 512 : 256) void attn_fwd_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
                                                        bf16_t* __restrict__ out_lo, long out_stride,
                                                        float* __restrict__ lse, float* __restrict__ cls_ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* 
     att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
     att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
   }
-  for (int j = threadIdx.x; j < NKP; j += 256) {
+  for (int j = threadIdx.x; j < NKP; j += blockDim.x) {
     float bias = (j < g.nk) ? 0.f : -1e30f;
     if (MODE == MODE_TEXT && j < g.nk && g.mask[(long)grp.b * g.S + j] == 0) bias = -1e30f;
     kbias[j] = bias;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttGeom g, bf16_t* 
   const int gq = lane >> 4;  // lane group
   const int nq_all = SP ? g.nq + 1 : g.nq;          // + the CLS query row
   const int ntiles = (nq_all + 15) / 16;
-  for (int qt = wave; qt < ntiles; qt += 4) {
+  for (int qt = wave; qt < ntiles; qt += (int)(blockDim.x >> 6)) {
     asm volatile("" ::: "memory");  // K/V fragments are loop-invariant: stop LICM from hoisting ~900 VGPRs of them
     const int qi = qt * 16 + (lane & 15);
     const bool is_cls = SP && qi >= g.nq;           // rows past n all alias the CLS row; only qi == n is stored
@@ -163,7 +163,9 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
   if (passes == 3) {
     auto kern = attn_fwd_kernel<MODE, NKF, 3>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, ol, ostride, lse, cls_ws);
+    // three-pass mode keeps four K/V planes in LDS (115 KiB: one workgroup per CU), so it runs 8 waves per workgroup to have
+    // two waves per SIMD; the single-pass kernel fits two 4-wave workgroups per CU
+    EGV_LAUNCH(kern, dim3(ngroups), dim3(512), lds, s, g, oh, ol, ostride, lse, cls_ws);
   } else {
     auto kern = attn_fwd_kernel<MODE, NKF, 1>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,15 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from egovlp_amd import ops
+B, T, n, H = 32, 4, 196, 12
+S = 1 + T * n
+for passes in (3, 1):
+    qkv = ops.split_f32(torch.randn(B * S, 3 * H * 64, device="cuda"), passes)[0]
+    for mode, name in ((0, "space"), (1, "time")):
+        f = lambda: ops.divided_attn_fwd(qkv, B, T, n, H, mode, passes)
+        for _ in range(3): f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        print("passes=%d %s attention fwd: %.1f us" % (passes, name, e0.elapsed_time(e1) * 100))
