@@ -9,6 +9,8 @@
 //               (dV^T = dO^T . P, dK^T = Q^T . dS, transposed fragments again by transpose-read of the
 //               row-major Q / dO images in LDS).
 // CLS-key gradients of the space mode are shared by the T frame-groups of a clip: atomicAdd.
+#include <cstdlib>
+
 #include "attn_common.h"
 #include "egovlp_hip.h"
 
@@ -43,7 +45,7 @@ __device__ __forceinline__ void store_planes4(bf16_t* hi, bf16_t* lo, long off, 
 // MODE_SPACE: operands are planes; the clip's CLS query rides as query row n (see attn_mfma_fwd.hip): its L and delta
 // are the GLOBAL ones (lse[b,h,0], delta[b,h,0]); its dq partial over this frame's keys is accumulated atomically.
 template <int MODE, int NKF, int PASSES>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const AttGrad gr) {
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const AttGrad gr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKP = NKF * 16;
   constexpr int PLANE = NKP * ATT_ROW_BYTES;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
     att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
     att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
   }
-  for (int j = threadIdx.x; j < NKP; j += 256) {
+  for (int j = threadIdx.x; j < NKP; j += blockDim.x) {
     float bias = (j < g.nk) ? 0.f : -1e30f;
     if (MODE == MODE_TEXT && j < g.nk && g.mask[(long)grp.b * g.S + j] == 0) bias = -1e30f;
     kbias[j] = bias;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
   const int gq = lane >> 4;
   const int nq_all = SP ? g.nq + 1 : g.nq;
   const int ntiles = (nq_all + 15) / 16;
-  for (int qt = wave; qt < ntiles; qt += 4) {
+  for (int qt = wave; qt < ntiles; qt += (int)(blockDim.x >> 6)) {
     asm volatile("" ::: "memory");  // K/V fragments are loop-invariant: stop LICM from hoisting ~900 VGPRs of them
     const int qi = qt * 16 + (lane & 15);
     const bool is_cls = SP && qi >= g.nq;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttGeom g, const
 
 // ----------------------------------------------------------------------------------------------- dKV
 template <int MODE, int NQF, int PASSES>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, const AttGrad gr) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttGeom g, const AttGrad gr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NQP = NQF * 16;
   constexpr int PLANE = NQP * ATT_ROW_BYTES;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
     att_stage(q_hi, q_lo, g.nq, NQP, 1.0f, [&](int r) { return g.q + grp.q_tok(g, r) * g.tok_stride + hoff; });
     att_stage(o_hi, o_lo, g.nq, NQP, 1.0f, [&](int r) { return gr.d_out + grp.q_tok(g, r) * gr.do_stride + hoff; });
   }
-  for (int i = threadIdx.x; i < NQP; i += 256) {
+  for (int i = threadIdx.x; i < NQP; i += blockDim.x) {
     float L = 1e30f, dl = 0.f;  // padded query rows: P = exp(s - 1e30) = 0
     if (i < nq_all) {
       const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (qrow_tok(i) - grp.tok0);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttGeom g, cons
 
   const int gq = lane >> 4;
   const int nkfrags = (g.nk + 15) / 16;
-  for (int kf = wave; kf < nkfrags; kf += 4) {
+  for (int kf = wave; kf < nkfrags; kf += (int)(blockDim.x >> 6)) {
     const int kj = kf * 16 + (lane & 15);
     const int kc = min(kj, g.nk - 1);
     const long ktok = grp.k_tok(g, kc);
@@ -335,9 +337,10 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
     auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
     (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    EGV_LAUNCH(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
+    static const int nthr = getenv("EGV_ATTN_BWD_THREADS") ? atoi(getenv("EGV_ATTN_BWD_THREADS")) : 512;   // 8 waves per group (A/B: 256)
+    EGV_LAUNCH(k1, dim3(ngroups), dim3(nthr), lds, s, g, gr);
     EGV_CHECK_LAUNCH();
-    EGV_LAUNCH(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+    EGV_LAUNCH(k2, dim3(ngroups), dim3(nthr), lds, s, g, gr);
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;

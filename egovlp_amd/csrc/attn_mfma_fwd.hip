@@ -10,6 +10,8 @@
 // operand of O^T = V^T.P^T -- V^T fragments come from the row-major V image through the CDNA4
 // transpose read.  q/k/v are read directly out of the fused qkv buffer with index arithmetic; none
 // of the reference's rearrange / repeat / cat copies exist.
+#include <cstdlib>
+
 #include "attn_common.h"
 #include "egovlp_hip.h"
 
@@ -21,7 +23,7 @@ namespace {
 // partials of a (clip, head).  The CLS key is counted for the CLS query in frame-group 0 only.
 // q is NOT pre-scaled: scores are multiplied by 64^-0.5 after the MFMA (exact for the power of two).
 template <int MODE, int NKF, int PASSES>
-__global__ __launch_bounds__(PASSES == 3 ? 512 : 256) void attn_fwd_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
                                                        bf16_t* __restrict__ out_lo, long out_stride,
                                                        float* __restrict__ lse, float* __restrict__ cls_ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,7 +171,8 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
   } else {
     auto kern = attn_fwd_kernel<MODE, NKF, 1>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    EGV_LAUNCH(kern, dim3(ngroups), dim3(256), lds, s, g, oh, nullptr, ostride, lse, cls_ws);
+    static const int nthr = getenv("EGV_ATTN_FWD_THREADS") ? atoi(getenv("EGV_ATTN_FWD_THREADS")) : 512;   // A/B diagnostics
+    EGV_LAUNCH(kern, dim3(ngroups), dim3(nthr), lds, s, g, oh, nullptr, ostride, lse, cls_ws);
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;
