@@ -45,6 +45,34 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// One 4-column piece of one output row: alpha, + bias, activation, + residual, stores (include/egovlp_hip.h order).
+__device__ __forceinline__ void nt_epilogue4(const egv_gemm_desc& p, f32x4_t v, int m, int n) {
+  if (p.alpha != 1.0f) v *= p.alpha;
+  if (p.bias) v += *(const f32x4_t*)(p.bias + n);
+  if (p.act == EGV_ACT_GELU) {
+    if (p.aux_out) *(f32x4_t*)(p.aux_out + (long)m * p.ldaux + n) = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+  } else if (p.act == EGV_ACT_GELU_BWD) {
+    const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(zv[e]);
+  } else if (p.act == EGV_ACT_RELU_BWD) {
+    const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = zv[e] > 0.f ? v[e] : 0.f;
+  }
+  if (p.residual) v += *(const f32x4_t*)(p.residual + (long)m * p.ldr + n);
+  if (p.out_f32) *(f32x4_t*)(p.out_f32 + (long)m * p.ldo + n) = v;
+  if (p.out_hi) {
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+    *(u32x2_t*)(p.out_hi + (long)m * p.ldoh + n) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
+    if (p.out_lo) *(u32x2_t*)(p.out_lo + (long)m * p.ldoh + n) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+  }
+}
+
 template <int PASSES>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const egv_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,31 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const egv_gemm_desc p) 
         *(f32x4_t*)(p.partial + ((long)z * p.M + m) * p.N + n) = v;
         continue;
       }
-      if (p.alpha != 1.0f) v *= p.alpha;
-      if (p.bias) v += *(const f32x4_t*)(p.bias + n);
-      if (p.act == EGV_ACT_GELU) {
-        if (p.aux_out) *(f32x4_t*)(p.aux_out + (long)m * p.ldaux + n) = v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-      } else if (p.act == EGV_ACT_GELU_BWD) {
-        const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(zv[e]);
-      } else if (p.act == EGV_ACT_RELU_BWD) {
-        const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = zv[e] > 0.f ? v[e] : 0.f;
-      }
-      if (p.residual) v += *(const f32x4_t*)(p.residual + (long)m * p.ldr + n);
-      if (p.out_f32) *(f32x4_t*)(p.out_f32 + (long)m * p.ldo + n) = v;
-      if (p.out_hi) {
-        bf16_t h[4], l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
-        *(u32x2_t*)(p.out_hi + (long)m * p.ldoh + n) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
-        if (p.out_lo)
-          *(u32x2_t*)(p.out_lo + (long)m * p.ldoh + n) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
-      }
+      nt_epilogue4(p, v, m, n);
     }
   }
 }
@@ -219,6 +223,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int egv_gemm_nt_v2_launch(const egv_gemm_desc& p, hipStream_t s);          // gemm_nt_v2.hip
 int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant);  // gemm_big.hip
 bool egv_gemm_big_supports(const egv_gemm_desc& p);
+
+// Split-K for the small-M NT problems (DistilBERT: M = 1024 -> 48..192 tiles of 128x128 on 256 CUs, 24..96 k-steps each): the
+// k-slices run as separate workgroups and this kernel sums their slabs and applies the FULL fused epilogue (bias, GELU / GELU'
+// / ReLU', residual, fp32 and / or plane outputs), one 4-column piece per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_epilogue_kernel(const egv_gemm_desc p, int ksplit) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long mn = (long)p.M * p.N;
+  if (i4 >= mn) return;
+  f32x4_t s = *(const f32x4_t*)(p.partial + i4);
+  for (int z = 1; z < ksplit; ++z) s += *(const f32x4_t*)(p.partial + (long)z * mn + i4);
+  const int m = (int)(i4 / p.N), n = (int)(i4 - (long)m * p.N);
+  nt_epilogue4(p, s, m, n);
+}
 
 // kernel choice: gemm_big (320/256 x 256 tile, k-tile 64) for the token-major GEMMs and every TN (wgrad) problem;
 // v1 (128x128, 2-stage) when M is too small to fill big tiles (DistilBERT, projections); v2 (256x128, BK = 32) only
@@ -268,7 +285,13 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
     EGV_LAUNCH(gemm_nt_kernel<1>, grid, block, 2 * 2 * PLANE_BYTES, s, p);
   }
   EGV_CHECK_LAUNCH();
-  if (ks > 1) {
+  if (ks > 1 && !p.trans && variant < 3) {
+    // small-tile NT kernels: slabs -> sum -> fused epilogue (any combination of outputs)
+    if (p.accumulate) return EGV_ERR_ARG;
+    const long mn4 = (long)p.M * p.N / 4;
+    EGV_LAUNCH(splitk_reduce_epilogue_kernel, dim3((int)((mn4 + 255) / 256)), dim3(256), 0, s, p, ks);
+    EGV_CHECK_LAUNCH();
+  } else if (ks > 1) {
     if (!p.out_f32 || p.ldo != p.N) return EGV_ERR_ARG;
     const long mn = (long)p.M * p.N;
     const int blocks = (int)((mn / 4 + 255) / 256);

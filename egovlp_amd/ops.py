@@ -11,6 +11,7 @@ MFMA), `passes` = 1 uses hi only (plain bf16).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -114,10 +115,12 @@ def pad32(n):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_NONE, aux_in=None, aux_out=None,
-            out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=1, K=None):
+            out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=None, K=None):
     """C[M,N] = A[M,K] . B[N,K]^T with the fused epilogue of egv_gemm_nt.  A.rows = M, B.rows = N."""
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
+    if ksplit is None:
+        ksplit = auto_ksplit_nt(M, N, K)
     d = GemmDesc()
     d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
     d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
@@ -143,6 +146,20 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
                           lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"), passes)
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
+
+
+def auto_ksplit_nt(M, N, K):
+    """Split-K factor for the small-M NT problems that run on the 128x128 kernel (DistilBERT's M = B*L = 1024 rows make
+    48..192 tiles for 256 CUs): enough k-slices to put about one workgroup on every CU, at least 6 k-steps of 32 each; the
+    slabs are summed by a reduce kernel that applies the full fused epilogue.  1 for everything else."""
+    if SMALL_SPLITK == 0 or uses_big_gemm(M, N, K) or M >= 4096 or K % 32:
+        return 1
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ks = max(1, min(4, round(256 / max(tiles, 1)), (K // 32) // 6))
+    return ks
+
+
+SMALL_SPLITK = int(os.environ.get("EGV_SMALL_SPLITK", "1"))   # 0: off (A/B diagnostics)
 
 
 def uses_big_gemm(M, N, K):
