@@ -76,3 +76,20 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libegovlp_hip.so")
     with pytest.raises(_lib.EgovlpHipError):
         _lib.lib()
+
+
+def test_small_gemm_splitk_policy():
+    """Host-side kernel choice for NT GEMMs (egovlp_amd.ops): token-major shapes go to the big-tile kernel un-split, the
+    DistilBERT-sized ones (M = 1024) get 2-4 k-slices of at least 6 k-steps each, nothing is split beyond 4."""
+    from egovlp_amd import ops
+    for (M, N, K) in [(25120, 768, 768), (25120, 2304, 768), (25120, 768, 3072), (50192, 768, 768), (16400, 1024, 4096)]:
+        assert ops.uses_big_gemm(M, N, K) and ops.auto_ksplit_nt(M, N, K) == 1
+    want = {(1024, 768, 768): 4, (1024, 2304, 768): 2, (1024, 3072, 768): 1, (1024, 768, 3072): 4}
+    for shape, ks in want.items():
+        assert not ops.uses_big_gemm(*shape)
+        assert ops.auto_ksplit_nt(*shape) == ks
+    for M in (32, 128, 512, 1024, 3140):
+        for N in (256, 768, 2304, 3072):
+            for K in (256, 768, 3072):
+                ks = ops.auto_ksplit_nt(M, N, K)
+                assert 1 <= ks <= 4 and (ks == 1 or (K // 32) // ks >= 6 or (K // 32) // 6 >= ks)
