@@ -255,3 +255,25 @@ def test_uint8_frames_give_the_same_video_embeddings(full):
         b = m.compute_video(host.cuda())
     assert torch.equal(a, b)
     m.train()
+
+
+def test_full_size_batch_is_consistent_with_oracle_rows_and_with_its_halves(full):
+    """BASELINE configs[1] size (B = 32, T = 4: the 25 120-token GEMM shapes bench.py runs): the embeddings of the full batch
+    must (a) equal the CPU oracle on a few of its rows computed one clip at a time (the encoders are per-sample), and (b) not
+    depend on how the batch is cut (two halves of 16: other tile counts, same numbers up to summation order)."""
+    m, sd = full
+    batch = synth_batch(32, T=4, L=32, seed=2024, ragged=True)
+    dev = to_dev(batch)
+    m.eval()
+    with torch.no_grad():
+        te, ve = m(dev)
+        halves = [m({"video": dev["video"][i:i + 16], "text": {k: v[i:i + 16] for k, v in dev["text"].items()}}) for i in (0, 16)]
+    te2, ve2 = torch.cat([h[0] for h in halves]), torch.cat([h[1] for h in halves])
+    assert rel(te2, te) < 1e-4 and rel(ve2, ve) < 1e-4      # other tile counts and split-K factors: bf16x3 noise level (~2e-5)
+    rows = [0, 13, 31]
+    with torch.no_grad():
+        for r in rows:
+            one = {"video": batch["video"][r:r + 1], "text": {k: v[r:r + 1] for k, v in batch["text"].items()}}
+            rt, rv = O.frozen_in_time(one, sd, O.VideoCfg(), O.TextCfg())
+            assert rel(te[r:r + 1], rt) < PARITY and rel(ve[r:r + 1], rv) < PARITY, r
+    m.train()
