@@ -8,9 +8,13 @@
 //     issues 2*(MF+8) ds_read_b128 for 16*MF MFMAs (MF = 5: 26 reads / 80 MFMAs; 128x128: 16 / 32);
 //   * k-tile = 64 bf16 = one full 128-B line per row per DMA piece (the BK = 32 kernels fetched half lines);
 //   * two LDS stages of (64*MF + 256) x 128 B (144 KiB at MF = 5) filled by LDS-DMA (global_load_lds_dwordx4);
-//     ONE barrier per k-tile; the DMA of tile t+2 is issued right after the barrier that retires tile t's buffer;
-//   * fragments are register double-buffered in 8 "phases" per k-tile: while phase p multiplies, the ds_reads of
-//     phase p+1 are in flight -- including across the k-tile boundary.
+//     ONE barrier per k-tile.  Only waves 0-3 (one per SIMD) issue DMA.  NT: the pieces of k-tile t+1 are issued over
+//     the first four of the eight phases of k-tile t (a burst of 18 blocks the issuing wave ~1300 cycles on the L1->LDS
+//     path); TN: k-tile t+2 is issued in one burst right after the barrier that retires k-tile t's stage;
+//   * a k-tile is 8 "phases" of MF x 2 MFMAs.  NT fetches fragments with inline-asm ds_read_b128 and hand-counted
+//     s_waitcnt lgkmcnt(N) (hipcc only emits lgkmcnt(0) here): B fragments two phases ahead through three register sets,
+//     the A fragments of k-step 1 over phases 0-2, the first fragments of k-tile t+1 right behind the barrier.  TN
+//     fetches through asm transpose reads into pending halves that are committed one phase later.
 // (2) Instruction fetch.  A per-block timeline (tools/gemm_trace.py, s_memrealtime stamps) of the first version showed
 //     11 us between kernel entry and the first MFMA and 20 us of epilogue per output tile -- next to 23 us of main loop
 //     for K = 768 -- with the stores compiled out: straight-line code that runs once per workgroup (a 40x unrolled,
