@@ -113,6 +113,11 @@ __device__ __forceinline__ void lgkm_wait() {
 }
 __device__ __forceinline__ void tie(bf16x8_t& x) { asm volatile("" : "+v"(x)); }
 
+// Loop condition of the ROLLED epilogue loops.  LLVM's block-frequency estimate multiplies by ~32 per loop level, so a
+// rolled two-level epilogue loop looks "hotter" than the k-tile loop and the register allocator spills the main loop's
+// A / B fragments to keep epilogue temporaries in registers; a 50 % back-edge probability tells it the truth.
+#define EGV_COLD_LOOP(c) __builtin_expect_with_probability((c), 1, 0.5)
+
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (B < E) {
@@ -169,8 +174,13 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
 }
 
 template <int MF, bool TN, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg) {
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef EGV_DIAG
+  const int dbg = dbg_arg;      // `make diag` build only (tools/gemm_trace.py, tools/gemm_bench.py with EGV_GEMM_DBG)
+#else
+  constexpr int dbg = 0;        // product library: every diagnostic branch below folds away
+#endif
   constexpr int BM = MF * 64;
   constexpr int A_BYTES = BM * 128;
   constexpr int B_BYTES = BNB * 128;
@@ -408,6 +418,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   nt = max(kt_end - kt_begin, 0) * nseg;
   sm0 = m0; sn0 = n0; skt_begin = kt_begin; skt_end = kt_end; st_seg = 0; st_kt = kt_begin;
   if (nt > 0) stage(0);
+  if (!TN) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
   for (;;) {
     if ((dbg & 0xfff) == 200) ts0 = __builtin_amdgcn_s_memrealtime();
@@ -501,13 +515,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         });
       };
       if (nt > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // k-tile 0 has landed and every wave is past a barrier behind that (before the tile loop for the first tile, at the
+        // end of the previous epilogue otherwise) -- no wait here: the epilogue stores of the previous tile are still draining
         const unsigned na0 = fa, nb0 = fb;
         Bq[0][0] = ld128_asm<0>(nb0);
         Bq[0][1] = ld128_asm<2048>(nb0);
         static_for<0, MF>([&](auto Ic) { A[0][decltype(Ic)::value] = ld128_asm<decltype(Ic)::value * 2048>(na0); });
         if ((dbg & 0xfff) == 200) ts1 = __builtin_amdgcn_s_memrealtime();
+        // NOT unrolled: two k-tile bodies in one loop cost ~15 registers the MF = 5 instance does not have (A fragments spill)
+#pragma unroll 1
         for (int t = 0; t < nt; ++t) k_tile(t);
       }
     } else {
@@ -633,6 +649,83 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     const int vn = v + gridDim.x;
     const bool has_next = vn < total;
     int nm0 = 0, nn0 = 0, nz = 0, ntn = 0, nkb = 0, nke = 0, nnt = 0;
+
+    // ================= epilogue of tile v ===========================================================================
+    // Fragment (i, j) of this wave: lane holds C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) .. +3].  A 16-row group
+    // (fixed i, all 8 j: 16 x 128 fp32 = 8 KiB) goes through this wave's private staging rows in LDS stage 1 (512-B rows,
+    // 16-B chunk index XOR (row & 7): conflict-free for the 8-lane ds_write_b128 groups and for the row-wise reads) and is
+    // read back ROW-WISE, so that every global access of the epilogue is a run of whole 128-B lines:
+    //   f32 layout   (no plane output): lane -> 4 columns, 32 lanes = one 512-B row, 2 rows per wave instruction;
+    //   plane layout (out_hi given):    lane -> 8 columns (one 16-B store per bf16 plane), 16 lanes = one row, 4 rows.
+    // The first version stored 16-column pieces (32-B bf16 / 64-B fp32 segments) and re-loaded the bias in each of its 40
+    // rolled iterations -- on gfx9 loads and stores retire through ONE in-order counter, so waiting for that load waited for
+    // every store issued before it: the epilogue ran at one store round trip per iteration and cost 35-40 % of the K = 768
+    // GEMMs (profiles/r01_e_gemm_ceiling.txt).  Now no load is ever issued behind a store whose latency it would expose:
+    // the bias is read once per tile, residual / GELU' inputs are prefetched a 16-row group ahead (two register sets), and
+    // the stores of tile v drain under the main loop of tile v + 1 (counted vmcnt at the end, see below).
+    constexpr int EPW = 16 * 512;
+    static_assert(8 * EPW <= STAGE, "epilogue staging must fit in one LDS stage");
+    // every lane-derived address of the epilogue hangs off `el`, opaque per tile: hoisted out of the tile loop they would
+    // be live across the main loop, which has no register to spare (the A / B fragments spill)
+    int el = lane;
+    asm volatile("" : "+v"(el));
+    char* const ep = smem + STAGE + wave * EPW;
+    const int mw = m0 + wm * MF * 16;
+    const int nw = n0 + wn * 128;
+    const int wsw = el & 7;
+    char* const wbase = ep + (el & 15) * 512 + (((el >> 4) ^ (wsw & 3)) << 4);
+    char* const w_even = wbase + ((wsw >> 2) << 6);
+    char* const w_odd = wbase + (((wsw >> 2) ^ 1) << 6);
+    auto put = [&](auto Ic) {   // accumulators of group i -> staging rows
+      constexpr int i = decltype(Ic)::value;
+      static_for<0, NFW>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        *(f32x4_t*)(((j & 1) ? w_odd : w_even) + ((j & ~1) << 6)) = acc[i][j];
+      });
+      // a DISTINCT statement at the end of every group's block: without it SimplifyCFG sinks the "identical" stores of the
+      // switch cases below into one block that indexes acc[] with a phi -- and the whole accumulator array moves to scratch
+      asm volatile("; accumulators of group %0 staged" ::"n"(i) : "memory");
+    };
+    // The group loop is ROLLED (the body is shared by all MF groups; only `put` depends on i, through a switch), so the
+    // epilogue stays a few KB of code whatever its flavour.
+    auto put_i = [&](int i) {
+      switch (i) {
+        case 0: put(std::integral_constant<int, 0>{}); break;
+        case 1: put(std::integral_constant<int, 1>{}); break;
+        case 2: put(std::integral_constant<int, 2>{}); break;
+        case 3: put(std::integral_constant<int, 3>{}); break;
+        default: if constexpr (MF > 4) put(std::integral_constant<int, MF - 1>{}); break;
+      }
+    };
+    const bool lay16 = (EPI != EPI_RAW) && p.out_hi != nullptr;
+    // f32 layout: row = 2 it + (lane >> 5), columns 4 (lane & 31) ..; plane layout: row = 4 it + (lane >> 4), columns 8 (lane & 15) ..
+    const int L32 = el & 31, rs32 = el >> 5, L16 = el & 15, rs16 = el >> 4;
+    const unsigned r32 = (unsigned)(size_t)(ep - smem) + rs32 * 512 + ((L32 ^ rs32) << 4);          // + it * 1024, ^ ((it & 3) << 5)
+    const unsigned r16 = (unsigned)(size_t)(ep - smem) + rs16 * 512 + (((2 * L16) ^ rs16) << 4);    // + it * 2048, ^ ((it & 1) << 6)
+    // Streams that have to be READ by the epilogue (the residual of proj / fc2 forward; the saved pre-activation of the
+    // fc2 dgrad) are loaded a whole 16-row group at a time, at the top of the group: within the group no load is issued
+    // behind a store, so the only store round trip a wave waits for is the previous group's (MF per tile, not 8 MF).
+    const bool pf_res = (EPI == EPI_LINEAR) && !lay16 && p.residual != nullptr;
+    const bool pf_aux = (EPI == EPI_GELU_BWD) && lay16 && p.aux_bf16 != 0 && p.aux_in != nullptr;
+    constexpr int NPF = (EPI == EPI_LINEAR) ? 8 : ((EPI == EPI_GELU_BWD) ? 4 : 1);
+    f32x4_t pre[NPF];
+    const float* pf_ptr = nullptr;       // this lane's address in the first row of the group to be fetched next
+    long pf_ld = 0;                      // distance between consecutive iterations' rows, in floats
+    if constexpr (EPI == EPI_LINEAR) {
+      if (pf_res) {
+        pf_ptr = p.residual + (long)(mw + rs32) * p.ldr + nw + 4 * L32;
+        pf_ld = 2 * p.ldr;
+      }
+    } else if constexpr (EPI == EPI_GELU_BWD) {
+      if (pf_aux) {
+        pf_ptr = (const float*)((const bf16_t*)p.aux_in + (long)(mw + rs16) * p.ldaux + nw + 8 * L16);
+        pf_ld = 2 * p.ldaux;             // 4 bf16 rows, counted in floats
+      }
+    }
+    auto pf_issue = [&]() {
+      static_for<0, NPF>([&](auto Tc) { pre[decltype(Tc)::value] = *(const f32x4_t*)pf_ptr; pf_ptr += pf_ld; });
+    };
+    __builtin_amdgcn_sched_barrier(0);
     if (has_next) {
       // first k-tile of the NEXT output tile -> stage 0, in flight while this tile's epilogue drains through stage 1
       decode(vn, nm0, nn0, nz, ntn, nkb, nke);
@@ -640,47 +733,176 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       sm0 = nm0; sn0 = nn0; skt_begin = nkb; skt_end = nke; st_seg = 0; st_kt = nkb;
       if (nnt > 0) stage(0);
     }
-
-    // ================= epilogue of tile v ===========================================================================
-    // fragment (i, j) of this wave: lane holds C[m = 16 i + (lane & 15)][n = 16 j + 4 (lane >> 4) .. +3].  Per j, the
-    // MF fragments are written to this wave's private staging rows ([16 MF][16 + 4 pad] floats; the pad makes the
-    // 8-lane ds_write_b128 groups conflict-free) and read back as 64-B row segments by a rolled loop.
-    {
-      char* ep = smem + STAGE + wave * EP_WAVE;
-      const int wr_off = ((lane & 15) * EP_LD + 4 * (lane >> 4)) * 4;
-      const int rd_row = lane >> 2, rd_c4 = (lane & 3) * 4;
-      const int mw = m0 + wm * MF * 16;
-      const int nw = n0 + wn * 128;
-#pragma unroll
-      for (int j = 0; j < NFW; ++j) {
-#pragma unroll
-        for (int i = 0; i < MF; ++i) *(f32x4_t*)(ep + wr_off + i * 16 * EP_LD * 4) = acc[i][j];
-        if ((dbg & 0xfff) >= 100) continue;   // EXPERIMENT: nothing stored (main-loop-only timing)
+    __builtin_amdgcn_sched_barrier(0);
+    int nvm = 0;                // VMEM instructions this wave issues behind that DMA (a lower bound is all that is needed)
+#ifdef EGV_DIAG
+    const bool no_store = (dbg & 0xfff) >= 100;     // EXPERIMENT: nothing stored (main-loop-only timing)
+#else
+    constexpr bool no_store = false;
+#endif
+    if (no_store) {
 #pragma unroll 1
-        for (int r = 0; r < MF; ++r) {
-          const int row = r * 16 + rd_row;
-          const f32x4_t val = *(const f32x4_t*)(ep + (row * EP_LD + rd_c4) * 4);
-          epilogue4<EPI>(p, val, mw + row, nw + j * 16 + rd_c4, z, ksplit);
+      for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) put_i(i);
+    } else if (!lay16) {
+      // ---------------- f32 layout: lane -> 4 columns, two 512-B rows per wave instruction ----------------
+      const int n = nw + 4 * L32;
+      if (EPI == EPI_RAW || EPI == EPI_LINEAR) {
+        float* d;
+        long ld2;
+        f32x4_t bias4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_RAW) {
+          d = (ksplit > 1) ? p.partial + ((long)z * p.M + mw + rs32) * p.N + n : p.out_f32 + (long)(mw + rs32) * p.ldo + n;
+          ld2 = 2 * ((ksplit > 1) ? (long)p.N : p.ldo);
+        } else {
+          d = p.out_f32 + (long)(mw + rs32) * p.ldo + n;
+          ld2 = 2 * p.ldo;
+          if (p.bias) bias4 = *(const f32x4_t*)(p.bias + n);
+        }
+        if (EPI == EPI_LINEAR && pf_res) {
+#pragma unroll 1
+          for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+            pf_issue();
+            put_i(i);
+            static_for<0, 8>([&](auto Tc) {
+              constexpr int it = decltype(Tc)::value;
+              const f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5))) + bias4 + pre[it < NPF ? it : 0];
+              *(f32x4_t*)d = val;
+              d += ld2;
+            });
+          }
+        } else {
+#pragma unroll 1
+          for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+            put_i(i);
+#pragma unroll 1
+            for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
+              f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5)));
+              if (EPI == EPI_LINEAR) val += bias4;
+              *(f32x4_t*)d = val;
+              d += ld2;
+            }
+          }
+        }
+        nvm = MF * 8;
+      } else {
+        // GELU / GELU' / generic epilogues without plane outputs (test shapes): loads in the loop
+#pragma unroll 1
+        for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+          put_i(i);
+#pragma unroll 1
+          for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
+            const f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5)));
+            epilogue4<EPI>(p, val, mw + 16 * i + 2 * it + rs32, n, z, ksplit);
+          }
         }
       }
-      if (do_cs && (lane >> 4) == 0) {
+    } else {
+      // ---------------- plane layout: lane -> 8 columns (16 B of every bf16 plane), four 256-B rows per instruction ----------------
+      const int n = nw + 8 * L16;
+      const bool fast = (EPI == EPI_LINEAR && !p.residual && !p.out_f32) ||
+                        (EPI == EPI_GELU && !p.residual && !p.out_f32 && (!p.aux_out || p.aux_bf16)) ||
+                        (EPI == EPI_GELU_BWD && pf_aux && !p.residual && !p.out_f32);
+      if ((EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_GELU_BWD) && fast) {
+        f32x4_t b0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (EPI != EPI_GELU_BWD && p.bias) {
+          b0 = *(const f32x4_t*)(p.bias + n);
+          b1 = *(const f32x4_t*)(p.bias + n + 4);
+        }
+        bf16_t* dh = p.out_hi + (long)(mw + rs16) * p.ldoh + n;
+        const long dlo = p.out_lo ? (long)(p.out_lo - p.out_hi) : 0;      // the lo plane, at a fixed element distance from hi
+        const long ld4 = 4 * p.ldoh;
+        bf16_t* dz = nullptr;
+        if (EPI == EPI_GELU && p.aux_out) dz = (bf16_t*)p.aux_out + (long)(mw + rs16) * p.ldaux + n;
+        const long ldz4 = 4 * p.ldaux;
+        auto row16 = [&](const int it, const f32x4_t zin) {
+          const unsigned a0 = (r16 + it * 2048) ^ ((it & 1) << 6);
+          f32x4_t v0 = *(const f32x4_t*)(smem + a0) + b0, v1 = *(const f32x4_t*)(smem + (a0 ^ 16u)) + b1;
+          if constexpr (EPI == EPI_GELU) {
+            if (dz) {
+              *(u32x4_t*)dz = (u32x4_t){pack2(f32_to_bf16(v0[0]), f32_to_bf16(v0[1])), pack2(f32_to_bf16(v0[2]), f32_to_bf16(v0[3])),
+                                        pack2(f32_to_bf16(v1[0]), f32_to_bf16(v1[1])), pack2(f32_to_bf16(v1[2]), f32_to_bf16(v1[3]))};
+              dz += ldz4;
+            }
 #pragma unroll
-        for (int i = 0; i < MF; ++i) {
-          const int m = mw + i * 16 + (lane & 15);
-          if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
-          else p.colsum[m] = cs[i][0];
+            for (int e = 0; e < 4; ++e) { v0[e] = gelu_f(v0[e]); v1[e] = gelu_f(v1[e]); }
+          } else if constexpr (EPI == EPI_GELU_BWD) {
+            const u32x4_t zb = __builtin_bit_cast(u32x4_t, zin);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              v0[2 * e] *= gelu_grad_f(__uint_as_float(zb[e] << 16));
+              v0[2 * e + 1] *= gelu_grad_f(__uint_as_float(zb[e] & 0xffff0000u));
+              v1[2 * e] *= gelu_grad_f(__uint_as_float(zb[2 + e] << 16));
+              v1[2 * e + 1] *= gelu_grad_f(__uint_as_float(zb[2 + e] & 0xffff0000u));
+            }
+          }
+          bf16_t h[8], l[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { split_bf16(v0[e], h[e], l[e]); split_bf16(v1[e], h[4 + e], l[4 + e]); }
+          *(u32x4_t*)dh = (u32x4_t){pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
+          if (dlo) *(u32x4_t*)(dh + dlo) = (u32x4_t){pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])};
+          dh += ld4;
+        };
+#pragma unroll 1
+        for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+          if constexpr (EPI == EPI_GELU_BWD) {
+            pf_issue();
+            put_i(i);
+            // the four pre-activation rows sit in four registers quads: pick by a rolled index through a tiny select chain
+#pragma unroll 1
+            for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) {
+              const f32x4_t zin = it == 0 ? pre[0] : (it == 1 ? pre[NPF > 1 ? 1 : 0] : (it == 2 ? pre[NPF > 2 ? 2 : 0] : pre[NPF > 3 ? 3 : 0]));
+              row16(it, zin);
+            }
+          } else {
+            put_i(i);
+#pragma unroll 1
+            for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) row16(it, b0);
+          }
+        }
+        nvm = MF * 4 * (1 + (dlo ? 1 : 0) + (dz ? 1 : 0));
+      } else {
+        // plane output together with fp32 side outputs / in-loop inputs (test shapes, the all-bf16x3 mode's fp32 z): rolled
+#pragma unroll 1
+        for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+          put_i(i);
+#pragma unroll 1
+          for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) {
+            const unsigned a0 = (r16 + it * 2048) ^ ((it & 1) << 6);
+            const int m = mw + 16 * i + 4 * it + rs16;
+            epilogue4<EPI>(p, *(const f32x4_t*)(smem + a0), m, n, z, ksplit);
+            epilogue4<EPI>(p, *(const f32x4_t*)(smem + (a0 ^ 16u)), m, n + 4, z, ksplit);
+          }
         }
       }
     }
+    if (do_cs && (lane >> 4) == 0) {
+#pragma unroll
+      for (int i = 0; i < MF; ++i) {
+        const int m = mw + i * 16 + (lane & 15);
+        if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
+        else p.colsum[m] = cs[i][0];
+      }
+    }
+#ifdef EGV_DIAG
     if ((dbg & 0xfff) == 200 && tid == 0) {
       unsigned long long* tsb = (unsigned long long*)p.aux_out + (long)v * 4;
       tsb[0] = ts0; tsb[1] = ts1; tsb[2] = ts2; tsb[3] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
     if (!has_next) break;
     v = vn; m0 = nm0; n0 = nn0; z = nz; tn = ntn; kt_begin = nkb; kt_end = nke; nt = nnt;
-    // k-tile 0 of the new tile has landed (and this wave's epilogue stores have drained: vmcnt counts them too);
-    // after the barrier stage 1 (the epilogue staging rows of every wave) may be overwritten by k-tile 1.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // k-tile 0 of the new tile must have landed before the barrier.  Only the DMA-issuing waves have anything to wait for,
+    // and the DMA is OLDER than the nvm epilogue accesses issued behind it (one in-order counter): vmcnt(N <= nvm) retires
+    // the DMA and leaves the last N stores in flight under the next main loop (they are waited for with the DMA of k-tile 1,
+    // a whole k-tile later).  Waves 4-7 issued no DMA: their stores simply drain.  After the barrier stage 1 (the staging
+    // rows of every wave, all read back: lgkmcnt(0)) may be overwritten by k-tile 1.
+    if (loader) {
+      if (nvm >= 60) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+      else if (nvm >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      else if (nvm >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 }
@@ -700,8 +922,12 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s) {
       return EGV_ERR_LAUNCH + (int)hipGetLastError();
     attr_set = true;
   }
+#ifdef EGV_DIAG
   static const int dbg = getenv("EGV_GEMM_DBG") ? atoi(getenv("EGV_GEMM_DBG")) : 0;
   if ((dbg & 0x4000) && lds + 16384 <= 163840) lds_launch += 16384;   // stamp area of the hand-over diagnostic
+#else
+  constexpr int dbg = 0;
+#endif
   // persistent workgroups: one per CU (144 KiB of LDS each); G = 256 keeps v % 8 == blockIdx % 8 (XCD affinity)
   const int grid = total < 256 ? total : 256;
   EGV_LAUNCH(k, dim3(grid), dim3(512), lds_launch, s, p, dbg);

@@ -1,5 +1,9 @@
 """Micro-benchmark of egv_gemm_nt on the hot-path shapes (uniform random operands, HIP-event timed).
-usage: [EGV_GEMM_KERNEL=1|2|3|4|5|14] python tools/gemm_bench.py [passes]     (wgrad rows use the TN kernel)"""
+usage: [EGV_GEMM_KERNEL=1|2|3|4|5] [BENCH_EPI=real|f32|bf16] python tools/gemm_bench.py [passes [bwd_passes]]
+BENCH_EPI=real (default): every shape runs with the epilogue and output formats the EgoClip step gives it in the mode
+"forward = passes, backward = bwd_passes" (planes for qkv / h / dZ, fp32 + residual for proj / fc2, GELU + saved pre-activation
+for fc1, GELU' for the fc2 dgrad, split-K slabs + column sums for the wgrads); f32 / bf16: plain fp32 / bf16-plane output + bias
+(the round-1 table).  The wgrad rows use the TN kernel.  Prints one line per shape and the aggregate."""
 import os
 import sys
 import torch
@@ -8,30 +12,68 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egovlp_amd import ops  # noqa: E402
 
 passes_list = [int(sys.argv[1])] if len(sys.argv) > 1 else [3, 1]
-M = 32 * 785
-# (name, M, N, K, kind): kind 1 = NT with bias epilogue, 0 = wgrad (TN, contraction over the M token rows)
-shapes = [("qkv   fwd", M, 2304, 768, 1), ("proj  fwd", M, 768, 768, 1), ("fc1   fwd", M, 3072, 768, 1),
-          ("fc2   fwd", M, 768, 3072, 1), ("qkv dgrad", M, 768, 2304, 1), ("qkv wgrad", 2304, 768, M, 0),
-          ("proj wgrad", 768, 768, M, 0), ("fc1 wgrad", 3072, 768, M, 0), ("fc2 wgrad", 768, 3072, M, 0),
-          ("text  lin", 1024, 768, 768, 1), ("text wgrad", 768, 768, 1024, 0)]
-for passes in passes_list:
-    tot_t = tot_f = 0.0
-    for name, m, n, k, kind in shapes:
-        if kind:
-            a = ops.split_f32(torch.rand(m, k, device="cuda") * 2 - 1, passes)[0]
-            b = ops.split_f32(torch.rand(n, k, device="cuda") * 2 - 1, passes)[0]
-            out = torch.empty(m, n, device="cuda")
-            bias = torch.zeros(n, device="cuda")
-            if os.environ.get("BENCH_OUT") == "bf16":
-                outp = ops.empty_planes(m, n, 1, "cuda")
-                run = lambda: ops.gemm_nt(a, b, passes=passes, out_planes=outp, bias=bias)
+bwd_passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+EPI = os.environ.get("BENCH_EPI", "real")
+M = int(os.environ.get("BENCH_TOKENS", 32 * 785))
+D, H3, HD = 768, 2304, 3072
+dev = "cuda"
+
+
+def rnd(r, c, p):
+    return ops.split_f32(torch.rand(r, c, device=dev) * 2 - 1, p)[0]
+
+
+def cases(P, Pb):
+    """(name, flops, callable) in the order of one SpaceTimeBlock forward + backward."""
+    out = []
+
+    def nt(name, m, n, k, p, kw=None):
+        a, b = rnd(m, k, p), rnd(n, k, p)
+        bias = torch.zeros(n, device=dev)
+        if EPI != "real":
+            if EPI == "bf16":
+                o = ops.empty_planes(m, n, 1, dev)
+                out.append((name, m, n, k, p, lambda: ops.gemm_nt(a, b, passes=p, out_planes=o, bias=bias)))
             else:
-                run = lambda: ops.gemm_nt(a, b, passes=passes, out_f32=out, bias=bias)
-        else:
-            a = ops.split_f32(torch.rand(k, m, device="cuda") * 2 - 1, passes)[0]
-            b = ops.split_f32(torch.rand(k, n, device="cuda") * 2 - 1, passes)[0]
-            out = torch.empty(m, n, device="cuda")
-            run = lambda: ops.gemm_tn(a, b, passes=passes, out_f32=out, want_colsum=True)
+                o = torch.empty(m, n, device=dev)
+                out.append((name, m, n, k, p, lambda: ops.gemm_nt(a, b, passes=p, out_f32=o, bias=bias)))
+            return
+        out.append((name, m, n, k, p, lambda: ops.gemm_nt(a, b, passes=p, **kw(bias))))
+
+    def tn(name, m, n, k, p):
+        a, b = rnd(k, m, p), rnd(k, n, p)
+        o = torch.empty(m, n, device=dev)
+        out.append((name, m, n, k, p, lambda: ops.gemm_tn(a, b, passes=p, out_f32=o, want_colsum=True)))
+
+    res = torch.rand(M, D, device=dev)
+    o32 = torch.empty(M, D, device=dev)
+    qkv_pl = ops.empty_planes(M, H3, P, dev)
+    h_pl = ops.empty_planes(M, HD, P, dev)
+    z = torch.empty(M, HD, device=dev, dtype=torch.bfloat16 if Pb == 1 else torch.float32)
+    zin = (torch.rand(M, HD, device=dev) * 4 - 2).to(z.dtype)
+    dz_pl = ops.empty_planes(M, HD, Pb, dev)
+    dx_pl = ops.empty_planes(M, D, Pb, dev)
+    nt("qkv   fwd", M, H3, D, P, kw=lambda bias: dict(bias=bias, out_planes=qkv_pl))
+    nt("proj  fwd", M, D, D, P, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
+    nt("fc1   fwd", M, HD, D, P, kw=lambda bias: dict(bias=bias, act=ops.ACT_GELU, aux_out=z, out_planes=h_pl))
+    nt("fc2   fwd", M, D, HD, P, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
+    nt("fc2 dgrad", M, HD, D, Pb, kw=lambda bias: dict(act=ops.ACT_GELU_BWD, aux_in=zin, out_planes=dz_pl))
+    nt("fc1 dgrad", M, D, HD, Pb, kw=lambda bias: dict(out_f32=o32))
+    nt("proj dgrad", M, D, D, Pb, kw=lambda bias: dict(out_planes=dx_pl))
+    nt("qkv dgrad", M, D, H3, Pb, kw=lambda bias: dict(out_f32=o32))
+    tn("qkv wgrad", H3, D, M, Pb)
+    tn("proj wgrad", D, D, M, Pb)
+    tn("fc1 wgrad", HD, D, M, Pb)
+    tn("fc2 wgrad", D, HD, M, Pb)
+    nt("text  lin", 1024, D, D, P, kw=lambda bias: dict(bias=bias, out_f32=torch.empty(1024, D, device=dev)))
+    tn("text wgrad", D, D, 1024, Pb)
+    return out
+
+
+for P in passes_list:
+    Pb = bwd_passes if EPI == "real" else P
+    tot_t = tot_f = 0.0
+    for name, m, n, k, p, run in cases(P, Pb):
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,6 +84,8 @@ for passes in passes_list:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 10 * 1e3
         tf = 2.0 * m * n * k / us / 1e6
-        tot_t += us; tot_f += 2.0 * m * n * k
-        print(f"passes={passes} {name:10s} M={m:6d} N={n:5d} K={k:6d}: {us:8.1f} us  {tf:7.1f} TF algorithmic  ({tf*passes:7.1f} TF MFMA issue)")
-    print(f"passes={passes} TOTAL {tot_f/tot_t/1e6:.1f} TF algorithmic, variant={os.environ.get('EGV_GEMM_KERNEL','auto')}")
+        tot_t += us
+        tot_f += 2.0 * m * n * k
+        print(f"passes={p} {name:10s} M={m:6d} N={n:5d} K={k:6d}: {us:8.1f} us  {tf:7.1f} TF algorithmic  ({tf * p:7.1f} TF MFMA issue)")
+    print(f"fwd passes={P} bwd passes={Pb} epi={EPI} TOTAL {tot_f / tot_t / 1e6:.1f} TF algorithmic, {tot_t:.0f} us per block-equivalent, "
+          f"variant={os.environ.get('EGV_GEMM_KERNEL', 'auto')} lib={os.path.basename(os.environ.get('EGOVLP_HIP_LIB', 'libegovlp_hip.so'))}")
