@@ -44,6 +44,7 @@ class GemmDesc(C.Structure):
 # name -> (restype, argtypes); mirrors include/egovlp_hip.h one to one (tests/test_abi.py checks it)
 PROTOTYPES = {
     "egv_gemm_nt": (i32, [C.POINTER(GemmDesc), c_p]),
+    "egv_gemm_set_grid": (i32, [i32]),
     "egv_split_f32": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p, i64, c_p, c_p]),
     "egv_transpose_planes": (i32, [c_p, c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p]),
     "egv_layernorm_fwd": (i32, [c_p, c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
@@ -67,6 +68,8 @@ PROTOTYPES = {
     "egv_sim_matrix_bwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, f32, c_p, c_p, c_p]),
     "egv_egonce_from_sim": (i32, [c_p, c_p, c_p, i32, f32, i32, i32, c_p, c_p, c_p, c_p]),
     "egv_adamw_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, f32, f32, f32, f32, f32, i32, i32, f32, c_p]),
+    "egv_grad_pack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, f32, c_p]),
+    "egv_grad_unpack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, c_p]),
     "egv_relu_split": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p]),
     "egv_version": (i32, []),
     "egv_split_f32_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

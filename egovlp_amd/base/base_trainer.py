@@ -1,0 +1,172 @@
+"""Epoch loop, monitoring and checkpoint format of the reference's `Multi_BaseTrainer_dist`
+(base/base_trainer.py:239-480) -- the part of the boundary `run/train_egoclip.py:88-98` calls (`trainer.train()`).
+
+Kept as in the reference: constructor signature, `config` duck type (`config['trainer'][...]`, `config['n_gpu']`,
+`config.get_logger`, `config.save_dir`, `config.resume` -- the reference's `ConfigParser` works unchanged, and so does
+`egovlp_amd.utils.config.DictConfig`), `train()` bookkeeping (log dict, `monitor` modes, save_period), and the checkpoint
+file: `{'arch', 'epoch', 'state_dict', 'optimizer', 'monitor_best', 'config'}` as `checkpoint-epoch{N}.pth` /
+`model_best.pth`, rank 0 only; `_resume_checkpoint` accepts state_dicts with or without the DDP `module.` prefix.
+
+Different by design: the reference wraps the model in `DistributedDataParallel(find_unused_parameters=True)`
+(:258, fp32 bucketed all-reduce + a graph walk per step although no parameter is ever unused).  Here the model is NOT
+wrapped: at world size > 1 gradients are averaged by `egovlp_amd.dist.Bf16GradSync` (bf16 buckets, RCCL all-reduce launched
+from grad-ready hooks while backward is still running).  `self.model` therefore has the same attribute surface and
+`state_dict` keys (no `module.` prefix) on every world size.
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+
+import torch
+import torch.distributed as dist
+from numpy import inf
+
+from ..utils.util import load_checkpoint_file
+
+
+class Multi_BaseTrainer_dist:
+    def __init__(self, args, model, loss, metrics, optimizer, config, writer=None, init_val=False):
+        self.config = config
+        self.logger = config.get_logger('trainer', config['trainer']['verbosity'])
+        self.init_val = init_val
+        self.args = args
+        if not torch.cuda.is_available():
+            raise RuntimeError("egovlp_amd trains on an MI355X: no HIP device is visible (there is no CPU path)")
+        local_rank = getattr(args, 'local_rank', 0)
+        torch.cuda.set_device(local_rank)            # every egovlp_amd op launches on the CURRENT device's current stream
+        self.device = torch.device('cuda', local_rank)
+        self.model = model.to(self.device)
+        self.model.device = self.device
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.grad_sync = None
+        if self.world_size > 1:
+            from ..dist import Bf16GradSync
+            self.grad_sync = Bf16GradSync(self.model.parameters())
+        self.loss = loss.to(self.device) if hasattr(loss, 'to') else loss
+        self.metrics = metrics
+        self.optimizer = optimizer
+
+        cfg_trainer = config['trainer']
+        self.epochs = cfg_trainer['epochs']
+        self.save_period = cfg_trainer['save_period']
+        self.monitor = cfg_trainer.get('monitor', 'off')
+        self.init_val = cfg_trainer.get('init_val', True)
+        if self.monitor == 'off':
+            self.mnt_mode = 'off'
+            self.mnt_best = 0
+        else:
+            self.mnt_mode, self.mnt_metric = self.monitor.split()
+            assert self.mnt_mode in ['min', 'max']
+            self.mnt_best = inf if self.mnt_mode == 'min' else -inf
+            self.early_stop = cfg_trainer.get('early_stop', inf)
+        self.start_epoch = 1
+        self.checkpoint_dir = config.save_dir
+        self.writer = writer
+        if getattr(config, 'resume', None) is not None:
+            self._resume_checkpoint(config.resume)
+
+    @abstractmethod
+    def _train_epoch(self, epoch):
+        raise NotImplementedError
+
+    @abstractmethod
+    def _valid_epoch(self, epoch):
+        raise NotImplementedError
+
+    def train(self):
+        """Full training logic (base/base_trainer.py:313-380)."""
+        not_improved_count = 0
+        if self.init_val:
+            _ = self._valid_epoch(-1)
+        for epoch in range(self.start_epoch, self.epochs + 1):
+            result = self._train_epoch(epoch)
+            log = {'epoch': epoch}
+            for key, value in result.items():
+                if self.args.rank == 0:
+                    if key == 'metrics':
+                        log.update({mtr.__name__: value[i] for i, mtr in enumerate(self.metrics)})
+                    elif key == 'val_metrics':
+                        log.update({'val_' + mtr.__name__: value[i] for i, mtr in enumerate(self.metrics)})
+                    elif key == 'nested_val_metrics':
+                        for subkey, subval in value.items():
+                            for subsubkey, subsubval in subval.items():
+                                for subsubsubkey, subsubsubval in subsubval.items():
+                                    log[f"val_{subkey}_{subsubkey}_{subsubsubkey}"] = subsubsubval
+                    else:
+                        log[key] = value
+            for key, value in log.items():
+                if self.args.rank == 0:
+                    self.logger.info('    {:15s}: {}'.format(str(key), value))
+            best = False
+            if self.mnt_mode != 'off' and self.args.rank == 0:
+                try:
+                    improved = (self.mnt_mode == 'min' and log[self.mnt_metric] <= self.mnt_best) or \
+                               (self.mnt_mode == 'max' and log[self.mnt_metric] >= self.mnt_best)
+                except KeyError:
+                    self.logger.warning("Warning: Metric '{}' is not found. "
+                                        "Model performance monitoring is disabled.".format(self.mnt_metric))
+                    self.mnt_mode = 'off'
+                    improved = False
+                if improved:
+                    self.mnt_best = log[self.mnt_metric]
+                    not_improved_count = 0
+                    best = True
+                else:
+                    not_improved_count += 1
+            if epoch % self.save_period == 0 or best:
+                if self.args.rank == 0:
+                    self._save_checkpoint(epoch, save_best=best)
+        return not_improved_count
+
+    def _save_checkpoint(self, epoch, save_best=False):
+        """base/base_trainer.py:399-422, same keys and file names."""
+        arch = type(self.model).__name__
+        state = {
+            'arch': arch,
+            'epoch': epoch,
+            'state_dict': self.model.state_dict(),
+            'optimizer': self.optimizer.state_dict(),
+            'monitor_best': self.mnt_best,
+            'config': self.config,
+        }
+        filename = str(self.checkpoint_dir / 'checkpoint-epoch{}.pth'.format(epoch))
+        torch.save(state, filename)
+        self.logger.info("Saving checkpoint: {} ...".format(filename))
+        if save_best:
+            best_path = str(self.checkpoint_dir / 'model_best.pth')
+            torch.save(state, best_path)
+            self.logger.info("Saving current best: model_best.pth ...")
+
+    def _resume_checkpoint(self, resume_path):
+        """base/base_trainer.py:424-480."""
+        resume_path = str(resume_path)
+        self.logger.info("Loading checkpoint: {} ...".format(resume_path))
+        checkpoint = load_checkpoint_file(resume_path, map_location=self.device)
+        self.start_epoch = checkpoint['epoch'] + 1
+        self.mnt_best = checkpoint['monitor_best']
+        try:
+            if checkpoint['config']['arch'] != self.config['arch']:
+                self.logger.warning("Warning: Architecture configuration given in config file is different from that of "
+                                    "checkpoint. This may yield an exception while state_dict is being loaded.")
+        except (KeyError, TypeError):
+            pass
+        state_dict = checkpoint['state_dict']
+        load_keys = list(state_dict.keys())
+        curr_keys = list(self.model.state_dict().keys())
+        if not curr_keys[0].startswith('module.') and load_keys[0].startswith('module.'):
+            state_dict = type(state_dict)((k[7:], v) for k, v in state_dict.items())
+        elif curr_keys[0].startswith('module.') and not load_keys[0].startswith('module.'):
+            state_dict = type(state_dict)(('module.' + k, v) for k, v in state_dict.items())
+        self.model.load_state_dict(state_dict)
+        from .. import weights
+        weights.bump_epoch()        # parameters changed under the cached bf16 operand planes
+        try:
+            same_opt = checkpoint['config']['optimizer']['type'] == self.config['optimizer']['type']
+        except (KeyError, TypeError):
+            same_opt = True
+        if not same_opt:
+            self.logger.warning("Warning: Optimizer type given in config file is different from that of checkpoint. "
+                                "Optimizer parameters not being resumed.")
+        else:
+            self.optimizer.load_state_dict(checkpoint['optimizer'])
+        self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))

@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t, float lr,
   bf16_t* wh = t.wh[ti];
   bf16_t* wl = t.wl[ti];
   const long end = min(n, base + CHUNK);
-  const bool vec = ((n & 3) == 0);
+  // 16-byte accesses only where all four streams allow them (bucket views / odd offsets fall back to the scalar loop)
+  const bool vec = ((n & 3) == 0) && (((((size_t)p) | ((size_t)g) | ((size_t)m) | ((size_t)v)) & 15) == 0) &&
+                   (!wh || (((size_t)wh) & 7) == 0) && (!wl || (((size_t)wl) & 7) == 0);
   if (vec) {
     for (long i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
       f32x4_t pv = *(f32x4_t*)(p + i), gv = *(const f32x4_t*)(g + i), mv = *(f32x4_t*)(m + i), vv = *(f32x4_t*)(v + i);

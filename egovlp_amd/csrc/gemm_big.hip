@@ -1,7 +1,7 @@
 // gemm_big: the token-major GEMM of the EgoClip step (every qkv / proj / fc1 / fc2 forward, dgrad and wgrad of
 // the 12 SpaceTimeBlocks = ~95 % of the step's FLOPs), built around what bounds an MFMA GEMM on a CDNA4 CU.
 //
-// (1) LDS bytes per MFMA.  rocprofv3 on the 128x128 and 256x128 kernels (gemm_nt.hip, gemm_nt_v2.hip; 580-670 TF)
+// (1) LDS bytes per MFMA.  rocprofv3 on the round-1 128x128 and 256x128 kernels (580-670 TF)
 //     showed the LDS array -- fragment reads plus LDS-DMA writes -- busy about as long as the matrix pipe, so:
 //   * (64*MF) x 256 block tile, MF = 5 (320 rows) or 4 (256 rows): 8 waves as 4 (M) x 2 (N), each wave
 //     (16*MF) x 128 = MF x 8 MFMA 16x16x32 fragments (160 / 128 fp32 accumulator registers); per 64-deep k-tile a wave
@@ -67,7 +67,8 @@ enum { EPI_RAW = 0,      // store the accumulators (split-K partial slab, or pla
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
 typedef __attribute__((ext_vector_type(8))) short s16x8v;
 
-__device__ uint4 g_zero_page[64];  // 1 KiB of zeros: DMA source for k-rows past the end (TN)
+__device__ uint4 g_zero_page[64];
+int g_grid_cap = 256;            // persistent workgroups per launch (process-wide tuning knob, see egv_gemm_set_grid)  // 1 KiB of zeros: DMA source for k-rows past the end (TN)
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   const int wm = wave >> 1, wn = wave & 1;
   // DIAGNOSTIC (EGV_GEMM_DBG=200, tools/gemm_trace.py): per-tile 100 MHz timestamps into p.aux_out
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-  // DIAGNOSTIC (`make stamps` build, -DEGV_GEMM_STAMPS, + EGV_GEMM_DBG bit 0x4000): workgroup 0 stamps s_memtime around the
+  // DIAGNOSTIC (`make diag` build, + EGV_GEMM_DBG bit 0x4000): workgroup 0 stamps s_memtime around the
   // k-tile hand-over of its first output tile, per wave, into 16 KiB of LDS behind the two stages ([wave][k-tile < 64]
   // [4 stamps]); dumped after the tile.  Compiled out of the product library.
 #ifdef EGV_GEMM_STAMPS
@@ -928,8 +929,9 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s) {
 #else
   constexpr int dbg = 0;
 #endif
-  // persistent workgroups: one per CU (144 KiB of LDS each); G = 256 keeps v % 8 == blockIdx % 8 (XCD affinity)
-  const int grid = total < 256 ? total : 256;
+  // persistent workgroups: one per CU (144 KiB of LDS each); a grid that is a multiple of 8 keeps v % 8 == blockIdx % 8
+  // (XCD affinity).  g_grid_cap < 256 (egv_gemm_set_grid) leaves CUs to the RCCL kernels of an overlapped collective.
+  const int grid = total < g_grid_cap ? total : g_grid_cap;
   EGV_LAUNCH(k, dim3(grid), dim3(512), lds_launch, s, p, dbg);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -948,6 +950,15 @@ int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// Persistent-workgroup cap of the big-tile GEMM: 256 = one per CU (default).  In a data-parallel job the gradient
+// all-reduce runs as RCCL kernels UNDER the backward GEMMs; a grid that owns every CU for the whole launch starves them, so
+// multi-GPU runs set e.g. 248 (8 CUs, one per XCD, stay free).  Multiples of 8 in [8, 256]; returns the previous value.
+extern "C" int egv_gemm_set_grid(int32_t workgroups) {
+  const int prev = g_grid_cap;
+  if (workgroups >= 8 && workgroups <= 256 && workgroups % 8 == 0) g_grid_cap = workgroups;
+  return prev;
+}
 
 // Can the big kernel run this problem?  (NT: K % 64 == 0; both: M, N at least one tile, 16-B aligned rows.)
 bool egv_gemm_big_supports(const egv_gemm_desc& p) {

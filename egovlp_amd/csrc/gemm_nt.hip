@@ -24,8 +24,6 @@
 // float4 and the stores are 16 B (fp32) or 8 B (bf16 planes) per lane.
 // Block ids are remapped XCD-aware (common.h) so the ~6-24 blocks that share an A row-panel, and
 // the weight panel they all stream, sit in one XCD's L2.
-#include <cstdlib>
-
 #include "common.h"
 #include "egovlp_hip.h"
 
@@ -220,7 +218,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-int egv_gemm_nt_v2_launch(const egv_gemm_desc& p, hipStream_t s);          // gemm_nt_v2.hip
 int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant);  // gemm_big.hip
 bool egv_gemm_big_supports(const egv_gemm_desc& p);
 
@@ -237,23 +234,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue_kernel(const egv_g
   nt_epilogue4(p, s, m, n);
 }
 
-// kernel choice: gemm_big (320/256 x 256 tile, k-tile 64) for the token-major GEMMs and every TN (wgrad) problem;
-// v1 (128x128, 2-stage) when M is too small to fill big tiles (DistilBERT, projections); v2 (256x128, BK = 32) only
-// where K is not a multiple of 64.  EGV_GEMM_KERNEL = 1 | 2 | 3 (big, auto MF) | 4 | 5 (big, MF forced) | 14 (big,
-// MF = 4, 4-fragment phases) forces one variant -- A/B benchmarking only.
+// kernel choice: gemm_big (320/256 x 256 tile, k-tile 64) for the token-major GEMMs and every TN (wgrad) problem; the
+// 128x128 two-stage kernel of this file where M is too small to fill big tiles (DistilBERT, projections) or K is not a
+// multiple of 64.  -> 3 = big, 1 = small, -1 = unsupported.
 static int gemm_variant(const egv_gemm_desc& p) {
-  static const int forced = [] {
-    const char* e = getenv("EGV_GEMM_KERNEL");
-    return e ? atoi(e) : 0;
-  }();
   const bool big_ok = egv_gemm_big_supports(p);
   if (p.trans) return big_ok ? 3 : -1;
-  if (forced == 1 || forced == 2) return forced;
-  if (forced >= 3 && big_ok) return forced;
   // big tiles only when there are enough of them to occupy the chip (DistilBERT's M = 1024 GEMMs make 12)
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
   if (big_ok && big_tiles >= 128) return 3;
-  return (p.M >= 4096) ? 2 : 1;
+  return 1;
 }
 
 extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
@@ -275,9 +265,6 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (variant >= 3) {
     const int rc = egv_gemm_big_launch(p, s, variant);
-    if (rc) return rc;
-  } else if (variant == 2) {
-    const int rc = egv_gemm_nt_v2_launch(p, s);
     if (rc) return rc;
   } else if (p.passes == 3) {
     EGV_LAUNCH(gemm_nt_kernel<3>, grid, block, 2 * 4 * PLANE_BYTES, s, p);

@@ -1,0 +1,94 @@
+// Gradient exchange format of the data-parallel step (replaces DDP's fp32 buckets, base/base_trainer.py:258):
+// the fp32 gradients of a bucket of parameters are scaled by 1/W, rounded to bf16 and packed back to back into ONE flat
+// buffer that RCCL all-reduces over xGMI (half the bytes of the reference's fp32 all-reduce: 362 MB instead of 724 MB per
+// step for the 180.9 M parameters), then unpacked into the fp32 .grad tensors the optimizer reads.  Both directions are one
+// multi-tensor launch per bucket (pointer tables travel in the kernel arguments), 16-byte accesses, pure HBM traffic:
+// 4 B read + 2 B written per element packing, 2 B + 4 B unpacking.
+#include "common.h"
+#include "egovlp_hip.h"
+
+namespace {
+
+constexpr int MAX_T = 96;        // tensors per launch
+constexpr int CHUNK = 16384;     // elements per block
+
+struct PackTable {
+  float* f32[MAX_T];             // the fp32 side (source when packing, destination when unpacking)
+  long off[MAX_T];               // element offset of the tensor inside the flat bf16 buffer
+  long numel[MAX_T];
+  int blk_start[MAX_T + 1];
+  int count;
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void grad_pack_kernel(const PackTable t, bf16_t* __restrict__ flat, float scale) {
+  int ti = 0;
+  while (ti + 1 < t.count && (int)blockIdx.x >= t.blk_start[ti + 1]) ++ti;
+  const long base = (long)((int)blockIdx.x - t.blk_start[ti]) * CHUNK;
+  const long n = t.numel[ti];
+  float* __restrict__ f = t.f32[ti];
+  bf16_t* __restrict__ b = flat + t.off[ti];
+  const long end = min(n, base + CHUNK);
+  const bool vec = ((n & 3) == 0) && ((((size_t)f) & 15) == 0) && ((((size_t)b) & 7) == 0);
+  if (vec) {
+    for (long i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
+      if (PACK) {
+        const f32x4_t v = *(const f32x4_t*)(f + i) * scale;
+        *(u32x2_t*)(b + i) = (u32x2_t){pack2(f32_to_bf16(v[0]), f32_to_bf16(v[1])), pack2(f32_to_bf16(v[2]), f32_to_bf16(v[3]))};
+      } else {
+        const u32x2_t w = *(const u32x2_t*)(b + i);
+        *(f32x4_t*)(f + i) = (f32x4_t){__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u),
+                                       __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+      }
+    }
+  } else {
+    for (long i = base + threadIdx.x; i < end; i += 256) {
+      if (PACK) b[i] = f32_to_bf16(f[i] * scale);
+      else f[i] = bf16_to_f32(b[i]);
+    }
+  }
+}
+
+template <bool PACK>
+int run(int32_t count, float* const* f32, const int64_t* numel, bf16_t* flat, const int64_t* off, float scale, hipStream_t s) {
+  if (count < 0 || !f32 || !numel || !flat || !off) return EGV_ERR_ARG;
+  PackTable t;
+  int nt = 0, nb = 0;
+  auto flush = [&]() -> int {
+    if (nt == 0) return EGV_OK;
+    t.blk_start[nt] = nb;
+    t.count = nt;
+    EGV_LAUNCH(grad_pack_kernel<PACK>, dim3(nb), dim3(256), 0, s, t, flat, scale);
+    EGV_CHECK_LAUNCH();
+    nt = 0;
+    nb = 0;
+    return EGV_OK;
+  };
+  for (int i = 0; i < count; ++i) {
+    if (numel[i] <= 0) continue;
+    if (!f32[i] || off[i] < 0) return EGV_ERR_ARG;
+    if (nt == MAX_T) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+    t.f32[nt] = f32[i];
+    t.off[nt] = off[i];
+    t.numel[nt] = numel[i];
+    t.blk_start[nt] = nb;
+    nb += (int)((numel[i] + CHUNK - 1) / CHUNK);
+    ++nt;
+  }
+  return flush();
+}
+
+}  // namespace
+
+extern "C" int egv_grad_pack_bf16(int32_t count, const float* const* grads, const int64_t* numel, egv_bf16* flat,
+                                  const int64_t* offsets, float scale, void* stream) {
+  return run<true>(count, (float* const*)grads, numel, flat, offsets, scale, (hipStream_t)stream);
+}
+
+extern "C" int egv_grad_unpack_bf16(int32_t count, float* const* grads, const int64_t* numel, const egv_bf16* flat,
+                                    const int64_t* offsets, void* stream) {
+  return run<false>(count, grads, numel, (bf16_t*)flat, offsets, 1.0f, (hipStream_t)stream);
+}

@@ -1,0 +1,164 @@
+"""Data-parallel gradient averaging for MI355X nodes: `Bf16GradSync` replaces the reference's
+`DistributedDataParallel(model, find_unused_parameters=True)` (base/base_trainer.py:258).
+
+What the reference does per step: DDP copies every fp32 gradient into 25 MB fp32 buckets, all-reduces them with NCCL
+(724 MB on the wire per rank for the 180.93 M parameters), divides by the world size, and walks the autograd graph looking
+for unused parameters (there are none).  What this does instead, sized for xGMI (point-to-point links, ring collectives
+are per-link bound):
+
+  * the exchange format is **bf16**: a bucket's fp32 gradients are scaled by 1/W, rounded and packed back to back into one
+    flat bf16 buffer by ONE multi-tensor kernel (`egv_grad_pack_bf16`) -- half the bytes on the links;
+  * buckets are **large and few** (default 64 MB of bf16 = 32 M parameters, ~6 collectives per step instead of DDP's ~29),
+    built from the order in which gradients actually became ready in the first backward;
+  * each bucket's `all_reduce` (RCCL, SUM of pre-scaled values = the mean) is issued **from the grad-ready hook of its last
+    parameter**, asynchronously, while backward keeps running; `finish()` (called between backward and optimizer.step)
+    waits for the collectives and unpacks the means into the fp32 `.grad` tensors (`egv_grad_unpack_bf16`);
+  * no graph walk, no module wrapper: `model.state_dict()` keeps the reference's key names on every world size.
+
+Semantics equal DDP's: after `finish()` every rank holds (1/W) * sum_r grad_r in p.grad (up to bf16 rounding of the
+exchanged values, 2^-9 relative -- the single-pass backward that produces them rounds its GEMM operands the same way).
+Initial parameters are broadcast from rank 0 at construction, as DDP does.
+
+The pack / unpack kernels are the HIP ones on the device; `pack_fn` / `unpack_fn` exist so that the HOST logic (bucket
+layout, hook accounting, collective calls) can be exercised on CPU tensors with gloo in tests -- there is no CPU default.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def _hip_pack(grads, flat, offsets, scale):
+    from . import _lib, ops
+    n = len(grads)
+    P = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+    N = (C.c_int64 * n)(*[g.numel() for g in grads])
+    O = (C.c_int64 * n)(*offsets)
+    _lib.check(_lib.lib().egv_grad_pack_bf16(n, P, N, flat.data_ptr(), O, float(scale), ops._stream()), "egv_grad_pack_bf16")
+
+
+def _hip_unpack(grads, flat, offsets):
+    from . import _lib, ops
+    n = len(grads)
+    P = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+    N = (C.c_int64 * n)(*[g.numel() for g in grads])
+    O = (C.c_int64 * n)(*offsets)
+    _lib.check(_lib.lib().egv_grad_unpack_bf16(n, P, N, flat.data_ptr(), O, ops._stream()), "egv_grad_unpack_bf16")
+
+
+class _Bucket:
+    __slots__ = ("params", "offsets", "flat", "pending", "work", "numel")
+
+    def __init__(self, params, device):
+        self.params = params
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8          # every tensor starts on a 16-byte boundary of the bf16 buffer
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.bfloat16, device=device)     # the padding stays zero forever
+        self.pending = len(params)
+        self.work = None
+
+
+class Bf16GradSync:
+    def __init__(self, params, process_group=None, bucket_mb: float = 64.0,
+                 pack_fn: Optional[Callable] = None, unpack_fn: Optional[Callable] = None, broadcast: bool = True):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("Bf16GradSync: no trainable parameters")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 2)
+        self.pack_fn = pack_fn or _hip_pack
+        self.unpack_fn = unpack_fn or _hip_unpack
+        dev = self.params[0].device
+        if pack_fn is None and dev.type != "cuda":
+            raise RuntimeError("Bf16GradSync packs gradients with HIP kernels: parameters must live on an MI355X")
+        self.device = dev
+        if broadcast:
+            with torch.no_grad():
+                for p in self.params:
+                    dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                                   group=process_group)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._ready_order: List[int] = []
+        self._buckets: Optional[List[_Bucket]] = None       # built after the first backward, from its ready order
+        self._bucket_of = {}
+        self._seen = set()
+        self.stats = {"buckets": 0, "collectives_last_step": 0, "bytes_last_step": 0}
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_ready) for p in self.params]
+
+    # ---- hooks (run on the autograd engine thread, in the order gradients become final) ----------------------------
+    def _on_ready(self, p):
+        i = self._index[id(p)]
+        if self._buckets is None:
+            if i not in self._seen:
+                self._seen.add(i)
+                self._ready_order.append(i)
+            return
+        b = self._bucket_of.get(i)
+        if b is None:
+            return
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        grads = [p.grad for p in b.params]
+        for g in grads:
+            if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+                raise RuntimeError("Bf16GradSync needs dense contiguous fp32 gradients")
+        self.pack_fn(grads, b.flat, b.offsets, 1.0 / self.world)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.stats["collectives_last_step"] += 1
+        self.stats["bytes_last_step"] += b.numel * 2
+
+    def _build_buckets(self):
+        order = self._ready_order + [i for i in range(len(self.params)) if i not in self._seen]
+        buckets, cur, cur_n = [], [], 0
+        for i in order:
+            p = self.params[i]
+            if cur and cur_n + p.numel() > self.bucket_elems:
+                buckets.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            buckets.append(cur)
+        self._buckets = [_Bucket(ps, self.device) for ps in buckets]
+        self._bucket_of = {self._index[id(p)]: b for b in self._buckets for p in b.params}
+        self.stats["buckets"] = len(self._buckets)
+
+    # ---- between backward and optimizer.step -------------------------------------------------------------------------
+    def finish(self):
+        """Wait for the bucket all-reduces of this backward and leave the rank-mean gradient in every p.grad."""
+        if self._buckets is None:
+            # first step: the ready order is known only now -> build the buckets and reduce them all here (no overlap)
+            self._build_buckets()
+            self.stats["collectives_last_step"] = self.stats["bytes_last_step"] = 0
+            for b in self._buckets:
+                b.params = [p for p in b.params]
+                if any(p.grad is None for p in b.params):
+                    raise RuntimeError("Bf16GradSync: a parameter received no gradient (unused parameters are not supported; "
+                                       "the EgoClip step uses every parameter, SURVEY 7)")
+                self._launch(b)
+        for b in self._buckets:
+            if b.work is None:
+                raise RuntimeError("Bf16GradSync.finish(): a bucket was never launched -- some parameter received no "
+                                   "gradient in this backward")
+            b.work.wait()
+            self.unpack_fn([p.grad for p in b.params], b.flat, b.offsets)
+            b.work = None
+            b.pending = len(b.params)
+        out = dict(self.stats)
+        self.stats["collectives_last_step"] = self.stats["bytes_last_step"] = 0
+        return out
+
+    def remove_hooks(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -20,26 +20,10 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..ops import ACT_RELU_BWD, Precision
+from ..utils.util import load_checkpoint_file, state_dict_data_parallel_fix
 from ..weights import WeightCache
 from .text_transformer import DistilBertModel
 from .video_transformer import SpaceTimeTransformer, _lin_bwd
-
-
-def state_dict_data_parallel_fix(load_state_dict, curr_state_dict):
-    """utils/util.py:25-51: add / strip the DDP 'module.' prefix so that key sets line up."""
-    load_keys = list(load_state_dict.keys())
-    curr_keys = list(curr_state_dict.keys())
-    redo_dp = False
-    undo_dp = False
-    if not curr_keys[0].startswith('module.') and load_keys[0].startswith('module.'):
-        undo_dp = True
-    elif curr_keys[0].startswith('module.') and not load_keys[0].startswith('module.'):
-        redo_dp = True
-    if undo_dp:
-        return type(load_state_dict)((k[7:], v) for k, v in load_state_dict.items())
-    if redo_dp:
-        return type(load_state_dict)(('module.' + k, v) for k, v in load_state_dict.items())
-    return load_state_dict
 
 
 class _ProjFn(torch.autograd.Function):
@@ -122,7 +106,7 @@ class FrozenInTime(BaseModel):
             model.pre_logits = nn.Identity()
             ftr_dim = model.embed_dim
             if load_checkpoint in ["", None] and vit_path and os.path.exists(vit_path):
-                vit_checkpoint = torch.load(vit_path, map_location="cpu")
+                vit_checkpoint = load_checkpoint_file(vit_path, map_location="cpu")
                 new_vit_dict = state_dict_data_parallel_fix(vit_checkpoint, model.state_dict())
                 model.load_state_dict(new_vit_dict, strict=False)                                # :58-63
             self.video_model = model
@@ -145,7 +129,9 @@ class FrozenInTime(BaseModel):
         if load_checkpoint not in ["", None]:
             local_rank = int(os.environ.get('LOCAL_RANK', 0))
             dev = 'cuda:{}'.format(local_rank) if torch.cuda.is_available() else 'cpu'
-            checkpoint = torch.load(load_checkpoint, map_location=dev)
+            # reference checkpoints pickle their ConfigParser next to the weights (base/base_trainer.py:407-414): read them
+            # with the lenient unpickler of utils/util.py (torch >= 2.6 refuses the global under weights_only=True)
+            checkpoint = load_checkpoint_file(load_checkpoint, map_location=dev)
             state_dict = checkpoint['state_dict']
             new_state_dict = state_dict_data_parallel_fix(state_dict, self.state_dict())
             new_state_dict = self._inflate_positional_embeds(new_state_dict)

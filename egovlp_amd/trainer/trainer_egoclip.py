@@ -17,6 +17,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ..base.base_trainer import Multi_BaseTrainer_dist
 from ..model.model import sim_matrix
 
 
@@ -67,16 +68,21 @@ class AllGatherFused(torch.autograd.Function):
         return gv[lo:hi], gt[lo:hi], None, None, None, None
 
 
-def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_head=True):
+def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_head=True, grad_sync=None):
     """One optimisation step = trainer/trainer_egoclip.py:123-141 (zero_grad, forward, gathers,
-    similarity + loss, backward, optimizer.step).  Returns the (device) loss tensor; no host sync."""
+    similarity + loss, backward, optimizer.step).  Returns the (device) loss tensor; no host sync.
+    `grad_sync` (egovlp_amd.dist.Bf16GradSync, world size > 1) averages the gradients over the ranks -- its all-reduces
+    are launched by grad-ready hooks during backward; `finish()` waits for them before the optimizer reads p.grad."""
     optimizer.zero_grad(set_to_none=True)
     text_embeds, video_embeds = model(data)
     n_embeds, v_embeds = data['noun_vec'], data['verb_vec']
     video_embeds, text_embeds, n_embeds, v_embeds = AllGatherFused.apply(
         video_embeds, text_embeds, n_embeds, v_embeds, world_size, rank)
     is_ego = type(loss_fn).__name__ == 'EgoNCE'
-    if fused_head and hasattr(loss_fn, 'fused'):
+    n, D = text_embeds.shape
+    # the one-launch head covers global batches up to 1024 rows of <= 256 features (8 x 128 per GPU); beyond that the
+    # API-compatible sim_matrix + loss.forward path takes over (n <= 4096)
+    if fused_head and hasattr(loss_fn, 'fused') and n <= 1024 and D <= 256 and D % 4 == 0:
         loss = loss_fn.fused(text_embeds, video_embeds, n_embeds, v_embeds) if is_ego \
             else loss_fn.fused(text_embeds, video_embeds)
     else:
@@ -88,32 +94,41 @@ def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_he
         else:
             loss = loss_fn(output)
     loss.backward()                                                         # :139
+    if grad_sync is not None:
+        grad_sync.finish()
     optimizer.step()                                                        # :141
     return loss.detach()
 
 
-class Multi_Trainer_dist:
-    """The reference's trainer class reduced to the training hot loop (`_train_epoch`, :82-180) -- the
-    epoch/ckpt/validation scaffolding of base/base_trainer.py is boundary code that stays in Python in
-    the reference and is not rebuilt here (SURVEY 2 #6)."""
+class Multi_Trainer_dist(Multi_BaseTrainer_dist):
+    """Drop-in for the reference's trainer class (trainer/trainer_egoclip.py:29-275): same constructor, `train()` /
+    checkpointing from the base class (egovlp_amd.base.Multi_BaseTrainer_dist == base/base_trainer.py:239-480), the
+    training hot loop `_train_epoch` (:82-180) and the EgoMCQ validation `_valid_epoch` (:182-275)."""
 
     def __init__(self, args, model, loss, metrics, optimizer, config, data_loader, valid_data_loader=None,
                  lr_scheduler=None, len_epoch=None, writer=None, visualizer=None, tokenizer=None,
                  max_samples_per_epoch=50000):
-        self.args, self.config = args, config
-        self.model, self.loss, self.optimizer = model, loss, optimizer
+        super().__init__(args, model, loss, metrics, optimizer, config, writer)
+        self.config = config
+        self.args = args
         self.data_loader = data_loader
+        if len_epoch is None:
+            self.len_epoch = min(len(x) for x in data_loader)               # epoch-based training (:44-47)
+        else:
+            self.len_epoch = len_epoch
         self.valid_data_loader = valid_data_loader
+        self.do_validation = self.valid_data_loader is not None
+        self.lr_scheduler = lr_scheduler
+        self.visualizer = visualizer
+        self.val_chunking = True
         self.metrics = metrics if metrics is not None else []
-        self.len_epoch = min(len(x) for x in data_loader) if len_epoch is None else len_epoch
+        self.batch_size = self.data_loader[0].batch_size
+        self.log_step = int(np.sqrt(self.batch_size))
+        self.total_batch_sum = sum(x.batch_size for x in self.data_loader)
         self.tokenizer = tokenizer
         self.max_samples_per_epoch = max_samples_per_epoch
         self.n_gpu = self.args.world_size
         self.allgather = AllGather_multi.apply
-        self.batch_size = self.data_loader[0].batch_size
-        self.log_step = int(np.sqrt(self.batch_size))
-        self.total_batch_sum = sum(x.batch_size for x in self.data_loader)
-        self.device = torch.device('cuda', getattr(args, 'local_rank', 0))
 
     def _adjust_learning_rate(self, optimizer, epoch, args):
         lr = args.learning_rate1                                            # :75-80
@@ -127,13 +142,12 @@ class Multi_Trainer_dist:
         total_loss = [torch.zeros((), device=self.device) for _ in self.data_loader]
         for loader in self.data_loader:
             if hasattr(loader, 'train_sampler'):
-                loader.train_sampler.set_epoch(epoch)
-        steps = 0
+                loader.train_sampler.set_epoch(epoch)                       # :101-102
         for batch_idx, data_li in enumerate(zip(*self.data_loader)):
             if (batch_idx + 1) * self.total_batch_sum > self.max_samples_per_epoch:
                 break
             for dl_idx, data in enumerate(data_li):
-                if 'video_neg' in data.keys():                              # :109-113
+                if 'video_neg' in data.keys():                              # :109-113, scene-aware negatives: B -> 2B
                     data['text'] = data['text'] + data['text_neg']
                     data['video'] = torch.cat((data['video'], data['video_neg']), axis=0)
                     data['noun_vec'] = torch.cat((data['noun_vec'], data['noun_vec_neg']), axis=0)
@@ -144,12 +158,24 @@ class Multi_Trainer_dist:
                 data['video'] = data['video'].to(self.device)
                 data['noun_vec'] = data['noun_vec'].to(self.device)
                 data['verb_vec'] = data['verb_vec'].to(self.device)
-                loss = egoclip_step(self.model, self.loss, self.optimizer, data, self.n_gpu, self.args.rank)
-                total_loss[dl_idx] += loss      # stays on device: no per-step .item() sync (reference :148,150)
-            steps += 1
+                loss = egoclip_step(self.model, self.loss, self.optimizer, data, self.n_gpu, self.args.rank,
+                                    grad_sync=self.grad_sync)
+                total_loss[dl_idx] += loss      # stays on the device: no per-step .item() sync (reference :148,150)
+                if self.writer is not None and self.args.rank == 0 and batch_idx % self.log_step == 0:
+                    total = int(self.data_loader[dl_idx].n_samples / self.n_gpu) if hasattr(self.data_loader[dl_idx], 'n_samples') else 0
+                    current = batch_idx * self.data_loader[dl_idx].batch_size
+                    final_total = (epoch - 1) * total + current
+                    self.writer.add_scalar(f'Loss_training/loss_{dl_idx}', float(loss), final_total)   # :143-148
             if batch_idx == self.len_epoch:
                 break
-        log = {f'loss_{i}': float(t) / max(steps, 1) for i, t in enumerate(total_loss)}
+        log = {f'loss_{dl_idx}': float(total_loss[dl_idx]) / self.len_epoch for dl_idx in range(len(self.data_loader))}   # :162-164
+        if self.writer is not None and self.args.rank == 0:
+            for dl_idx in range(len(self.data_loader)):
+                self.writer.add_scalar(f'Loss_training/loss_total_{dl_idx}', log[f'loss_{dl_idx}'], epoch - 1)
+        if self.do_validation:                                              # :172-175
+            val_log = self._valid_epoch(epoch)
+            if self.args.rank == 0:
+                log.update(val_log)
         self._adjust_learning_rate(self.optimizer, epoch, self.args)        # :178
         return log
 

@@ -1,0 +1,83 @@
+"""Checkpoint plumbing of the drop-in boundary (reference: utils/util.py:25-51, base/base_trainer.py:399-480).
+
+The reference's checkpoints are `torch.save({'arch', 'epoch', 'state_dict', 'optimizer', 'monitor_best', 'config'})`
+where `config` is the live `parse_config.ConfigParser` object (base/base_trainer.py:407-414).  Unpickling such a file
+needs (a) `weights_only=False` -- torch >= 2.6 defaults to the safe unpickler, which rejects the ConfigParser global --
+and (b) a `parse_config` module on the path, which this package does not ship.  `load_checkpoint_file` therefore reads
+TRUSTED checkpoint files with an unpickler that maps every global it cannot import to an inert placeholder: tensors,
+optimizer state and plain containers load normally, the pickled config object becomes a `_Placeholder` that still exposes
+its `_config` dict (so `checkpoint['config']['arch']` keeps working as in `_resume_checkpoint`).
+"""
+from __future__ import annotations
+
+import pickle
+
+import torch
+
+
+def state_dict_data_parallel_fix(load_state_dict, curr_state_dict):
+    """utils/util.py:25-51: add / strip the DDP 'module.' prefix so that key sets line up."""
+    load_keys = list(load_state_dict.keys())
+    curr_keys = list(curr_state_dict.keys())
+    redo_dp = False
+    undo_dp = False
+    if not curr_keys[0].startswith('module.') and load_keys[0].startswith('module.'):
+        undo_dp = True
+    elif curr_keys[0].startswith('module.') and not load_keys[0].startswith('module.'):
+        redo_dp = True
+    if undo_dp:
+        return type(load_state_dict)((k[7:], v) for k, v in load_state_dict.items())
+    if redo_dp:
+        return type(load_state_dict)(('module.' + k, v) for k, v in load_state_dict.items())
+    return load_state_dict
+
+
+class _Placeholder:
+    """Stands in for a pickled object whose class is not importable here (e.g. parse_config.ConfigParser)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__['_state'] = state
+
+    # ConfigParser-like read access: checkpoint['config']['arch'] (base/base_trainer.py:438,471)
+    def __getitem__(self, name):
+        cfg = self.__dict__.get('_config')
+        if cfg is None:
+            raise KeyError(name)
+        return cfg[name]
+
+
+class _LenientUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            return type(name, (_Placeholder,), {'__module__': module})
+
+
+class _LenientPickle:
+    """`pickle_module` for torch.load: the stdlib pickle with the lenient Unpickler."""
+    __name__ = 'pickle'
+    Unpickler = _LenientUnpickler
+    load = staticmethod(lambda f, **kw: _LenientUnpickler(f, **kw).load())
+    loads = staticmethod(pickle.loads)
+    dump = staticmethod(pickle.dump)
+    dumps = staticmethod(pickle.dumps)
+    Pickler = pickle.Pickler
+    PickleError = pickle.PickleError
+    UnpicklingError = pickle.UnpicklingError
+    HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
+
+
+def load_checkpoint_file(path, map_location=None):
+    """torch.load for the reference's (trusted) checkpoint files, see the module docstring.  Plain state_dict files and
+    files whose globals are importable take the safe path first."""
+    try:
+        return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception:
+        return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_LenientPickle)

@@ -66,6 +66,10 @@ typedef struct egv_gemm_desc {
                        with ksplit > 1, partial must hold ksplit*M*N + ksplit*M floats.                              */
 } egv_gemm_desc;
 int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
+/* Persistent-workgroup count of the big-tile GEMM kernel (default 256 = one per CU).  Data-parallel runs lower it (e.g. 248)
+ * so that the RCCL kernels of the overlapped gradient all-reduce find free CUs.  Multiples of 8 in [8, 256] are accepted;
+ * returns the previous value (process-wide, read at every launch).                                                    */
+int egv_gemm_set_grid(int32_t workgroups);
 
 /* ---- format kernels (HBM-bound) -----------------------------------------------------------------
  * fp32 [rows, cols] -> split planes, optionally also the TRANSPOSED planes t_*[cols, ldt] (ldt >= rows,
@@ -191,6 +195,16 @@ int egv_sim_matrix_bwd(const float* g, const float* an, const float* bn, const f
 int egv_egonce_from_sim(const float* x, const float* sim_v, const float* sim_n, int32_t n, float temperature,
                         int32_t use_noun, int32_t use_verb, float* loss, float* dx,
                         float* work /* n*n + 6n floats */, void* stream);
+
+/* ---- gradient exchange (data parallel) ------------------------------------------------------------------
+ * Replaces the fp32 bucket copies of DistributedDataParallel (base/base_trainer.py:258): `count` fp32 gradient tensors
+ * (HOST arrays of device pointers / sizes) are scaled by `scale` (= 1 / world size), rounded to bf16 (RNE) and written to
+ * flat[offsets[i] .. offsets[i] + numel[i]) -- the buffer RCCL all-reduces -- and read back into the fp32 tensors
+ * afterwards.  offsets are in elements; multiples of 8 keep every access 16 bytes wide.                               */
+int egv_grad_pack_bf16(int32_t count, const float* const* grads, const int64_t* numel, egv_bf16* flat,
+                       const int64_t* offsets, float scale, void* stream);
+int egv_grad_unpack_bf16(int32_t count, float* const* grads, const int64_t* numel, const egv_bf16* flat,
+                         const int64_t* offsets, void* stream);
 
 /* ---- optimizer ----------------------------------------------------------------------------------------
  * transformers==4.2.1 AdamW (run/train_egoclip.py:73, configs/pt/egoclip.json:49-54) over a list of

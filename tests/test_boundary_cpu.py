@@ -1,0 +1,119 @@
+"""The drop-in boundary on the CPU (no GPU needed: modules are parameter containers until `forward`).
+
+* the reference's own ConfigParser, fed `configs/pt/egoclip.json` UNCHANGED, instantiates FrozenInTime / EgoNCE / AdamW
+  from the drop-in modules by reflection, exactly as run/train_egoclip.py:63,69,73 do (327 keys, 180.93 M parameters);
+* a checkpoint in the reference's format (`module.` prefix, pickled ConfigParser) loads through
+  `FrozenInTime(load_checkpoint=...)` with strict=True in a process that has no `parse_config` module;
+* `_inflate_positional_embeds` equals the reference's own method for 16 -> 4 and 4 -> 16 frames.
+The reference-dependent halves run in a subprocess (tests/ref_boundary_probe.py) and are skipped where /root/reference is
+absent (the GPU box); the rest runs everywhere."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("EGOVLP_REFERENCE", "/root/reference")
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "model")), reason="reference checkout not present")
+
+VIDEO_PARAMS = {"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 16, "pretrained": True,
+                "time_init": "zeros"}
+TEXT_PARAMS = {"model": "distilbert-base-uncased", "pretrained": True, "input": "text"}
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    out = tmp_path_factory.mktemp("probe")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_boundary_probe.py"), str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("PROBE ")][-1]
+    return json.loads(line[6:]), out
+
+
+@needs_ref
+def test_reference_configparser_builds_the_dropin_classes_from_egoclip_json(probe):
+    res, _ = probe
+    assert res["model"] == "FrozenInTime" and res["keys"] == 327 and abs(res["params_M"] - 180.93) < 0.01
+    assert res["n_trainable"] == 327 and res["model_frames"] == 16 and res["time_init_zero"]
+    assert res["loss"] == "EgoNCE" and res["loss_temperature"] == 0.05
+    # transformers==4.2.1 AdamW defaults (run/train_egoclip.py:73)
+    assert res["optimizer"] == "AdamW" and res["lr"] == 3e-5 and res["eps"] == 1e-6
+    assert res["betas"] == [0.9, 0.999] and res["weight_decay"] == 0.0
+
+
+@needs_ref
+def test_reference_format_checkpoint_loads_strict_without_parse_config(probe):
+    from egovlp_amd.model.model import FrozenInTime
+    from egovlp_amd.synth import synth_state_dict
+    _, out = probe
+    assert "parse_config" not in sys.modules
+    path = os.path.join(str(out), "ref_format_checkpoint.pth")
+    with pytest.raises(Exception):                  # what a plain torch.load does with this file
+        torch.load(path, map_location="cpu")
+    m = FrozenInTime(video_params=dict(VIDEO_PARAMS), text_params=dict(TEXT_PARAMS), projection="minimal",
+                     load_checkpoint=path)
+    want = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=21)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, want[k]), k
+
+
+@needs_ref
+def test_inflate_positional_embeds_matches_the_reference(probe):
+    from egovlp_amd.model.model import FrozenInTime
+    _, out = probe
+    g = np.load(os.path.join(str(out), "ref_inflate.npz"))
+    for load_frames, curr_frames, fix in [(16, 4, "zeros"), (4, 16, "zeros"), (4, 16, "bilinear")]:
+        m = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": curr_frames}, text_params=dict(TEXT_PARAMS),
+                         projection="minimal", load_checkpoint="", load_temporal_fix=fix)
+        key = f"{load_frames}_{curr_frames}_{fix}"
+        sd = {"video_model.temporal_embed": torch.from_numpy(g["in_" + key]).clone(),
+              "video_model.pos_embed": torch.zeros(1, 197, 768)}
+        new = m._inflate_positional_embeds(sd)["video_model.temporal_embed"]
+        assert new.shape == (1, curr_frames, 768)
+        assert torch.equal(new, torch.from_numpy(g["out_" + key])), key
+
+
+def test_checkpoint_with_unimportable_config_object_and_module_prefix(tmp_path):
+    """The same load path without the reference: the pickled `config` is an instance of a class whose module disappears
+    before loading (as parse_config.ConfigParser does on a machine without the reference)."""
+    import types
+    from collections import OrderedDict
+    from egovlp_amd.model.model import FrozenInTime
+    from egovlp_amd.synth import synth_state_dict
+    from egovlp_amd.utils.util import load_checkpoint_file
+    m0 = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
+                      load_checkpoint="")
+    vals = synth_state_dict({k: v.shape for k, v in m0.state_dict().items()}, seed=5)
+    mod = types.ModuleType("parse_config_gone")
+
+    class ConfigParser:                               # pickled by reference (module + qualname), not by value
+        def __init__(self):
+            self._config = {"arch": {"type": "FrozenInTime"}, "optimizer": {"type": "AdamW"}}
+    ConfigParser.__module__ = "parse_config_gone"
+    ConfigParser.__qualname__ = "ConfigParser"
+    mod.ConfigParser = ConfigParser
+    sys.modules["parse_config_gone"] = mod
+    path = str(tmp_path / "checkpoint-epoch1.pth")
+    try:
+        torch.save({"arch": "FrozenInTime", "epoch": 1, "monitor_best": 0.0, "optimizer": {},
+                    "state_dict": OrderedDict(("module." + k, v) for k, v in vals.items()), "config": ConfigParser()}, path)
+    finally:
+        del sys.modules["parse_config_gone"]
+    ck = load_checkpoint_file(path, map_location="cpu")
+    assert ck["epoch"] == 1 and ck["config"]["optimizer"]["type"] == "AdamW"        # read access like _resume_checkpoint's
+    m = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
+                     load_checkpoint=path)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, vals[k]), k
+    # 16-frame checkpoint into a 4-frame model: the first 4 rows survive (model/model.py:158-159)
+    vals16 = dict(vals)
+    vals16["video_model.temporal_embed"] = torch.randn(1, 16, 768)
+    torch.save({"state_dict": vals16}, path)
+    m4 = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
+                      load_checkpoint=path)
+    assert torch.equal(m4.video_model.temporal_embed, vals16["video_model.temporal_embed"][:, :4])

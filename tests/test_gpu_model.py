@@ -11,6 +11,13 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# Gradient bound of the BENCHMARKED mode ("mixed": bf16x3 forward, single-pass bf16 backward).  The forward -- embeddings and
+# loss, what north_star puts the 1e-3 bar on -- is bit-identical to the parity mode; the backward rounds dY, W and the saved
+# activations to bf16 once per GEMM (2^-9 per operand) and that error compounds through the 12 blocks: measured rel-L2 on
+# MI355X from ~2e-3 (last block, head) to ~2e-2 (block 0's temporal-attention qkv weight, the deepest gradient of the model);
+# whole-tensor gradient norms stay within 1e-3.  The tests print every value; the bound below is what they assert.
+MIXED_GRAD = 5e-2
+
 from egovlp_amd.synth import synth_batch, synth_state_dict  # noqa: E402
 from oracle import egovlp_oracle as O  # noqa: E402
 
@@ -113,6 +120,45 @@ def test_full_model_matches_reference_golden(full, golden_dir):
         p.grad = None
 
 
+def test_full_model_golden_in_the_benchmarked_mixed_mode(full, golden_dir):
+    """bench.py's default precision (bf16x3 forward / single-pass bf16 backward) against the reference's golden vectors:
+    embeddings and losses at the parity bar, every gradient the fixture holds inside MIXED_GRAD."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.ops import Precision
+    m, sd = full
+    g = np.load(os.path.join(golden_dir, "full_b4.npz"))
+    batch = synth_batch(4, T=4, L=32, seed=1234, ragged=True)
+    try:
+        Precision.set("bf16x3", "bf16")
+        m.eval()
+        d = to_dev(batch)
+        te, ve = m(d)
+        assert rel(te, g["text_embeds"]) < PARITY and rel(ve, g["video_embeds"]) < PARITY
+        ego = EgoNCE().fused(te, ve, d["noun_vec"], d["verb_vec"])
+        assert abs(float(ego) - float(g["egonce"])) < PARITY * abs(float(g["egonce"]))
+        te.retain_grad(); ve.retain_grad()
+        ego.backward()
+        assert rel(te.grad, g["grad_text_embeds"]) < PARITY and rel(ve.grad, g["grad_video_embeds"]) < PARITY   # the head is fp32
+        params = dict(m.named_parameters())
+        worst = 0.0
+        for key in g.files:
+            if key.startswith("grad:"):
+                name = key[5:]
+                gr = params[name].grad
+                g2 = gr.reshape(gr.shape[0], -1) if gr.dim() > 1 else gr.reshape(1, -1)
+                r1 = rel(g2[:8, :64], g[key])
+                r2 = abs(float(gr.norm()) / float(g["gradnorm:" + name]) - 1)
+                worst = max(worst, r1)
+                print("  mixed grad %-55s slice rel %.2e norm rel %.2e" % (name, r1, r2))
+                assert r1 < MIXED_GRAD and r2 < MIXED_GRAD, name
+        print("full B=4 mixed: worst sentinel-gradient rel %.2e" % worst)
+    finally:
+        Precision.set("bf16x3")
+        for p_ in m.parameters():
+            p_.grad = None
+        m.train()
+
+
 def test_full_model_fast_bf16_mode_error_is_bounded(full):
     """Single-pass bf16 operands: NOT the parity mode (~6e-3 drift on the reference itself)."""
     from egovlp_amd.ops import Precision
@@ -133,12 +179,19 @@ def test_full_model_fast_bf16_mode_error_is_bounded(full):
     assert r_t < 5e-2 and r_v < 5e-2
 
 
-def test_train_step_matches_oracle(full):
-    """One full optimisation step (fwd, EgoNCE, bwd, AdamW) vs the oracle + torch autograd on the CPU."""
+@pytest.mark.parametrize("mode", ["bf16x3", "mixed"])
+def test_train_step_matches_oracle(full, mode):
+    """One full optimisation step (fwd, EgoNCE, bwd, AdamW) vs the oracle + torch autograd on the CPU, in the parity mode and in
+    the benchmarked mixed mode (same forward; the bound on the AdamW update is the same sign-dominated 2e-2)."""
     from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.ops import Precision
     from egovlp_amd.optim import AdamW
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
     m, sd = full
+    if mode == "mixed":
+        Precision.set("bf16x3", "bf16")
+    else:
+        Precision.set("bf16x3")
     B = 4
     batch = synth_batch(B, T=4, L=32, seed=4321, ragged=True)
     m.load_state_dict(sd, strict=True)
@@ -160,9 +213,10 @@ def test_train_step_matches_oracle(full):
         upd_ref = p - sd[name]
         upd = new[name].detach().cpu() - sd[name]
         r = rel(upd, upd_ref)
-        print("  update %-55s rel %.2e" % (name, r))
+        print("  %s update %-55s rel %.2e" % (mode, name, r))
         assert r < 2e-2, name      # Adam's m/sqrt(v) is sign-like at step 1: tiny grads flip easily
     m.load_state_dict(sd, strict=True)
+    Precision.set("bf16x3")
 
 
 @pytest.mark.parametrize("name,kw,T,B", [
@@ -223,8 +277,12 @@ def test_egomcq_validation_epoch_matches_oracle(full):
         batch_size = 1
         dataset_name = "EgoMCQ-synthetic"
 
+    import tempfile
+    from egovlp_amd.utils.config import DictConfig
     args = _types.SimpleNamespace(world_size=1, rank=0, local_rank=0)
-    tr = Multi_Trainer_dist(args, m, None, [egomcq_accuracy_metrics], None, None, [Loader()],
+    config = DictConfig({"n_gpu": 1, "trainer": {"epochs": 1, "save_period": 1, "verbosity": 2, "monitor": "off",
+                                                 "init_val": False}}, save_dir=tempfile.mkdtemp())
+    tr = Multi_Trainer_dist(args, m, None, [egomcq_accuracy_metrics], None, config, [Loader()],
                             valid_data_loader=[Loader([dict(q) for q in questions])], len_epoch=1)
     res = tr._valid_epoch(1)
     pred = tr.last_val_predictions[0]
@@ -277,3 +335,93 @@ def test_full_size_batch_is_consistent_with_oracle_rows_and_with_its_halves(full
             rt, rv = O.frozen_in_time(one, sd, O.VideoCfg(), O.TextCfg())
             assert rel(te[r:r + 1], rt) < PARITY and rel(ve[r:r + 1], rv) < PARITY, r
     m.train()
+
+
+def test_full_size_train_step_matches_oracle_on_the_whole_batch(full):
+    """BASELINE configs[1] at full size (B = 32, T = 4: M = 25 120 tokens -- the only size where the 320-row tiles, split-K 7..28
+    and the 25 120-row TN weight gradients all run together): loss, both embedding gradients and sentinel weight gradients of
+    ONE backward against the CPU oracle on the whole batch (fp32 autograd, ~1 min on the box's cores), in the parity mode
+    (everything at 1e-3 / 3e-3) and in the benchmarked mixed mode (same forward, gradients inside MIXED_GRAD)."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.ops import Precision
+    m, sd = full
+    B = 32
+    batch = synth_batch(B, T=4, L=32, seed=777, ragged=True)
+    sentinels = ["video_model.blocks.0.timeattn.qkv.weight", "video_model.blocks.11.mlp.fc2.weight",
+                 "video_model.patch_embed.proj.weight", "text_model.transformer.layer.0.attention.q_lin.weight",
+                 "video_model.blocks.5.attn.proj.weight", "video_model.blocks.6.mlp.fc1.bias", "video_model.blocks.2.norm2.weight",
+                 "video_model.temporal_embed", "vid_proj.0.weight"]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sdo = {k: v.clone().requires_grad_(k in sentinels) for k, v in sd.items()}
+    rt, rv = O.frozen_in_time(batch, sdo, O.VideoCfg(), O.TextCfg())
+    rt.retain_grad(); rv.retain_grad()
+    rl, _ = O.egoclip_loss(rt, rv, batch["noun_vec"], batch["verb_vec"])
+    rl.backward()
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    dev = to_dev(batch)
+    params = dict(m.named_parameters())
+    try:
+        for mode, gbound in (("bf16x3", 3 * PARITY), ("mixed", MIXED_GRAD)):
+            Precision.set("bf16x3", "bf16" if mode == "mixed" else "bf16x3")
+            for p_ in m.parameters():
+                p_.grad = None
+            te, ve = m(dev)
+            te.retain_grad(); ve.retain_grad()
+            loss = EgoNCE().fused(te, ve, dev["noun_vec"], dev["verb_vec"])
+            loss.backward()
+            r_t, r_v, r_l = rel(te, rt), rel(ve, rv), abs(float(loss) - float(rl)) / abs(float(rl))
+            print("B=32 %s: text rel %.2e video rel %.2e loss rel %.2e | d_text %.2e d_video %.2e" % (
+                mode, r_t, r_v, r_l, rel(te.grad, rt.grad), rel(ve.grad, rv.grad)))
+            assert r_t < PARITY and r_v < PARITY and r_l < PARITY
+            assert rel(te.grad, rt.grad) < PARITY and rel(ve.grad, rv.grad) < PARITY      # the contrastive head is fp32 in every mode
+            for name in sentinels:
+                r = rel(params[name].grad, sdo[name].grad)
+                print("  B=32 %s grad %-55s rel %.2e" % (mode, name, r))
+                assert r < gbound, (mode, name, r)
+    finally:
+        Precision.set("bf16x3")
+        for p_ in m.parameters():
+            p_.grad = None
+
+
+@pytest.mark.parametrize("name,arch,T,model_frames", [("config4_T16", "base_patch16_224", 16, 16), ("config5_vitl14", "large_patch14_224", 4, 4)])
+def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T, model_frames):
+    """BASELINE configs 4 (16 frames) and 5 (ViT-L/14) through the FULL dual encoder + EgoNCE at B = 2: embeddings, loss,
+    embedding gradients and two weight gradients vs the CPU oracle, parity mode."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.model.model import FrozenInTime
+    from egovlp_amd.ops import Precision
+    Precision.set("bf16x3")
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": arch, "num_frames": model_frames,
+                                   "pretrained": True, "time_init": "rand"},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+                     projection="minimal", load_checkpoint="")
+    sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=9)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    batch = synth_batch(2, T=T, L=32, seed=31, ragged=True)
+    dev = to_dev(batch)
+    te, ve = m(dev)
+    te.retain_grad(); ve.retain_grad()
+    loss = EgoNCE().fused(te, ve, dev["noun_vec"], dev["verb_vec"])
+    loss.backward()
+    large = arch == "large_patch14_224"
+    cfg = O.VideoCfg(patch_size=14, embed_dim=1024, depth=24, num_heads=16, num_frames=model_frames) if large \
+        else O.VideoCfg(num_frames=model_frames)
+    last = cfg.depth - 1
+    watch = ["video_model.blocks.%d.mlp.fc1.weight" % last, "video_model.blocks.0.attn.qkv.weight", "txt_proj.1.weight"]
+    sdo = {k: v.clone().requires_grad_(k in watch) for k, v in sd.items()}
+    rt, rv = O.frozen_in_time(batch, sdo, cfg, O.TextCfg())
+    rt.retain_grad(); rv.retain_grad()
+    rl, _ = O.egoclip_loss(rt, rv, batch["noun_vec"], batch["verb_vec"])
+    rl.backward()
+    errs = {"text": rel(te, rt), "video": rel(ve, rv), "loss": abs(float(loss) - float(rl)) / abs(float(rl)),
+            "d_text": rel(te.grad, rt.grad), "d_video": rel(ve.grad, rv.grad)}
+    print(name, {k: "%.2e" % v for k, v in errs.items()})
+    assert all(v < PARITY for v in errs.values()), errs
+    params = dict(m.named_parameters())
+    for w in watch:
+        r = rel(params[w].grad, sdo[w].grad)
+        print("  %s grad %-45s rel %.2e" % (name, w, r))
+        assert r < 3 * PARITY, (w, r)

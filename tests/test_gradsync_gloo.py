@@ -1,0 +1,74 @@
+"""`Bf16GradSync` (the bf16 bucketed gradient all-reduce that replaces DDP, egovlp_amd/dist.py) on two gloo ranks.
+
+The HIP pack / unpack kernels cannot run here, so the test injects torch restatements of them (scale by 1/W, round to bf16,
+write at the bucket offsets; and back) -- what is exercised is the HOST logic the GPU path shares: bucket layout from the
+observed ready order, hook accounting, one async all-reduce per bucket, unpack into p.grad, the first (bucket-building) step
+and the hook-driven steps after it.  Gradients are chosen exactly representable, so (1/W) * sum_r grad_r must come back
+BIT FOR BIT; a second case with random gradients checks the bf16 rounding model bf16(bf16(g0/2) + bf16(g1/2))."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _pack(grads, flat, offsets, scale):
+    for g, o in zip(grads, offsets):
+        flat[o:o + g.numel()] = (g.reshape(-1) * scale).to(torch.bfloat16)
+
+
+def _unpack(grads, flat, offsets):
+    for g, o in zip(grads, offsets):
+        g.copy_(flat[o:o + g.numel()].float().view_as(g))
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from egovlp_amd.dist import Bf16GradSync
+    torch.manual_seed(100 + rank)                     # different initial weights per rank: the broadcast must fix that
+    net = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.ReLU(), torch.nn.Linear(40, 33), torch.nn.Linear(33, 7))
+    sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack)     # ~2 k elements per bucket
+    w0 = [p.detach().clone() for p in net.parameters()]
+    results = []
+    for step in range(3):
+        for p in net.parameters():
+            p.grad = None
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        exact = step < 2
+        # a loss whose gradient w.r.t. every parameter is a prescribed tensor: sum(p * G_p)
+        Gs = []
+        for p in net.parameters():
+            if exact:
+                G = torch.randint(-64, 64, p.shape, generator=g).float() / 8.0      # multiples of 1/8 below 8: exact in bf16, also halved and summed
+            else:
+                G = torch.randn(p.shape, generator=g)
+            Gs.append(G)
+        loss = sum((p * G).sum() for p, G in zip(net.parameters(), Gs))
+        loss.backward()
+        stats = sync.finish()
+        results.append(([p.grad.clone() for p in net.parameters()], Gs, stats))
+    torch.save({"w0": w0, "results": results}, os.path.join(out, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bf16_grad_sync_two_ranks(tmp_path):
+    world, port = 2, 29641
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"rank{i}.pt"), weights_only=False) for i in range(world)]
+    for a, b in zip(r[0]["w0"], r[1]["w0"]):
+        assert torch.equal(a, b)                      # rank 0's initial weights everywhere
+    for step in range(3):
+        g0, G0, st0 = r[0]["results"][step]
+        g1, G1, st1 = r[1]["results"][step]
+        assert st0["buckets"] >= 2 and st0["collectives_last_step"] == st0["buckets"]
+        for i in range(len(g0)):
+            assert torch.equal(g0[i], g1[i])          # every rank ends with the same gradient
+            if step < 2:
+                assert torch.equal(g0[i], (G0[i] + G1[i]) / world), (step, i)        # (1/W) * sum, bit for bit
+            else:
+                want = ((G0[i] / world).to(torch.bfloat16) + (G1[i] / world).to(torch.bfloat16)).float()
+                assert torch.equal(g0[i], want), (step, i)

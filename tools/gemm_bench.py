@@ -1,5 +1,5 @@
 """Micro-benchmark of egv_gemm_nt on the hot-path shapes (uniform random operands, HIP-event timed).
-usage: [EGV_GEMM_KERNEL=1|2|3|4|5] [BENCH_EPI=real|f32|bf16] python tools/gemm_bench.py [passes [bwd_passes]]
+usage: [BENCH_EPI=real|f32|bf16] [EGOVLP_HIP_LIB=...] python tools/gemm_bench.py [passes [bwd_passes]]
 BENCH_EPI=real (default): every shape runs with the epilogue and output formats the EgoClip step gives it in the mode
 "forward = passes, backward = bwd_passes" (planes for qkv / h / dZ, fp32 + residual for proj / fc2, GELU + saved pre-activation
 for fc1, GELU' for the fc2 dgrad, split-K slabs + column sums for the wgrads); f32 / bf16: plain fp32 / bf16-plane output + bias
@@ -88,4 +88,4 @@ for P in passes_list:
         tot_f += 2.0 * m * n * k
         print(f"passes={p} {name:10s} M={m:6d} N={n:5d} K={k:6d}: {us:8.1f} us  {tf:7.1f} TF algorithmic  ({tf * p:7.1f} TF MFMA issue)")
     print(f"fwd passes={P} bwd passes={Pb} epi={EPI} TOTAL {tot_f / tot_t / 1e6:.1f} TF algorithmic, {tot_t:.0f} us per block-equivalent, "
-          f"variant={os.environ.get('EGV_GEMM_KERNEL', 'auto')} lib={os.path.basename(os.environ.get('EGOVLP_HIP_LIB', 'libegovlp_hip.so'))}")
+          f"lib={os.path.basename(os.environ.get('EGOVLP_HIP_LIB', 'libegovlp_hip.so'))}")

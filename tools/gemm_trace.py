@@ -8,6 +8,9 @@ import sys
 import torch
 
 os.environ["EGV_GEMM_DBG"] = str(200 + int(os.environ.get("TRACE_DIAG", "0"), 0))
+# the timeline switches only exist in the diagnostics build of the library (`make -C egovlp_amd/csrc diag`)
+os.environ.setdefault("EGOVLP_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                     "egovlp_amd", "libegovlp_hip_diag.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egovlp_amd import _lib, ops  # noqa: E402
 
