@@ -31,6 +31,24 @@ import torch
 import torch.distributed as dist
 
 
+# Opt-in timing of the exchange steps (bench.py --gpus N): a list that receives (name, start_event, end_event) recorded on the
+# compute stream around the embedding all-gather and around Bf16GradSync.finish() (= the part of the gradient all-reduce
+# that backward did NOT hide, plus the unpack).
+COMM_EVENTS = None
+
+
+def timed(name, fn):
+    if COMM_EVENTS is None or not torch.cuda.is_available():
+        return fn()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    out = fn()
+    e1.record(st)
+    COMM_EVENTS.append((name, e0, e1))
+    return out
+
+
 def _hip_pack(grads, flat, offsets, scale):
     from . import _lib, ops
     n = len(grads)
@@ -136,6 +154,9 @@ class Bf16GradSync:
     # ---- between backward and optimizer.step -------------------------------------------------------------------------
     def finish(self):
         """Wait for the bucket all-reduces of this backward and leave the rank-mean gradient in every p.grad."""
+        return timed("grad_sync_exposed", self._finish)
+
+    def _finish(self):
         if self._buckets is None:
             # first step: the ready order is known only now -> build the buckets and reduce them all here (no overlap)
             self._build_buckets()

@@ -47,25 +47,33 @@ def _stream():
 
 class KernelTimer:
     """Opt-in HIP-event timing of individual C-ABI calls (bench.py's roofline leg).  Events are recorded on
-    the stream the kernel is launched on, immediately before and after the enqueue."""
+    the stream the kernel is launched on, immediately before and after the enqueue; `key` groups the launches of one
+    problem shape."""
 
     def __init__(self):
         self.records = {}
 
-    def time(self, name, flops, fn, passes=1):
+    def time(self, name, flops, fn, passes=1, key=None):
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         fn()
         e1.record(st)
-        self.records.setdefault(name, []).append((e0, e1, flops, flops * passes))
+        self.records.setdefault(name, []).append((e0, e1, flops, flops * passes, key))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
-            out[name] = {"launches": len(recs), "seconds": sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3,
-                         "flops": float(sum(r[2] for r in recs)), "issue_flops": float(sum(r[3] for r in recs))}
+            shapes = {}
+            for e0, e1, fl, ifl, key in recs:
+                d = shapes.setdefault(key, {"launches": 0, "seconds": 0.0, "flops": 0.0})
+                d["launches"] += 1
+                d["seconds"] += e0.elapsed_time(e1) * 1e-3
+                d["flops"] += fl
+            out[name] = {"launches": len(recs), "seconds": sum(d["seconds"] for d in shapes.values()),
+                         "flops": float(sum(r[2] for r in recs)), "issue_flops": float(sum(r[3] for r in recs)),
+                         "shapes": shapes}
         return out
 
 
@@ -143,7 +151,8 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
         raise ValueError("bf16 aux buffers are only supported by the big-tile GEMM kernel (see uses_big_gemm)")
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * K,
-                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"), passes)
+                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"), passes,
+                          key=f"NT M={M} N={N} K={K} x{passes}")
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
 
@@ -199,7 +208,8 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     d.trans, d.colsum, d.aux_bf16 = 1, _p(cs), 0
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * Kd,
-                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"), passes)
+                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"), passes,
+                          key=f"TN M={M} N={N} K={Kd} x{passes}")
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)")
     return cs

@@ -29,7 +29,8 @@ def _gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
     if world == 1 and os.environ.get("EGV_FORCE_GATHER") != "1":
         return t
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous())
+    from ..dist import timed
+    timed("embedding_all_gather", lambda: dist.all_gather_into_tensor(out, t.contiguous()))
     return out
 
 

@@ -1,7 +1,9 @@
-"""The N>1 code path of bench.py on a 1-GPU box: RCCL process group (`backend='nccl'`), DistributedDataParallel around the
-drop-in model (custom autograd nodes, raw-pointer AdamW on bucket-view gradients) and the fused all-gather, at world size 1.
-The loss after the same steps must match the plain single-process run (up to the run-to-run noise of the atomic reductions):
-DDP / the collective must not change the arithmetic."""
+"""The N>1 code path of bench.py on a 1-GPU box, at world size 1: RCCL process group (`backend='nccl'`), the fused embedding
+all-gather and the gradient exchange -- `Bf16GradSync` (default: HIP pack kernel -> RCCL all-reduce of the bf16 bucket from the
+grad-ready hooks -> HIP unpack kernel) and, for A/B, DistributedDataParallel around the drop-in model.  The loss after the
+same steps must match the plain single-process run (up to the run-to-run noise of the atomic reductions and, for the bf16
+exchange, the 2^-9 rounding of the exchanged gradients).  W > 1 semantics are pinned on gloo (tests/test_gradsync_gloo.py,
+tests/test_gather_gloo.py); no multi-GPU box is available to `gpurun`."""
 import json
 import os
 import socket
@@ -28,14 +30,18 @@ def _run(cmd, env):
     return json.loads(lines[0])
 
 
-def test_bench_under_rccl_ddp_world1_matches_single_process():
+@pytest.mark.parametrize("exchange", ["bf16sync", "ddp"])
+def test_bench_under_rccl_world1_matches_single_process(exchange):
     common = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-fast-mode",
               "--no-kernel-timing", "--precision", "bf16x3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     plain = _run([sys.executable] + common, env)
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                 "--master-port", str(_free_port())] + common + ["--force-dist"], env)
+                 "--master-port", str(_free_port())] + common + ["--force-dist"] + (["--ddp"] if exchange == "ddp" else []), env)
     assert dist["n_gpus"] == 1 and dist["config"]["parallelism"] == "dp1"
+    assert dist["comm"]["rccl_ranks"] == 1 and dist["comm"]["backend"] == "nccl"
+    if exchange == "bf16sync":
+        assert dist["comm"]["grad_sync"]["buckets"] >= 5            # 180.9 M parameters in 64 MB bf16 buckets
     # not bit-identical by design: a few reductions use fp32 atomics (LayerNorm dgamma, CLS-token gradients, bias sums), Adam's
     # first steps are sign-like, and bench.py prints the loss rounded to five decimals
     assert abs(dist["loss"] - plain["loss"]) <= 3e-5 + 1e-2 * abs(plain["loss"]), (dist["loss"], plain["loss"])
