@@ -28,7 +28,7 @@ FWD_GFLOP_PER_PAIR = {("base_patch16_224", 4): 187.4, ("base_patch16_224", 16): 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md chip-level table
 
 
-def build_model(arch, model_frames):
+def build_model(arch, model_frames, text_dropout=0.1):
     from egovlp_amd.model.model import FrozenInTime
     from egovlp_amd.synth import synth_state_dict
     m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": arch, "num_frames": model_frames,
@@ -36,6 +36,7 @@ def build_model(arch, model_frames):
                      text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
                      projection="minimal", load_checkpoint="")
     m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=0))
+    m.text_model.set_dropout(text_dropout, text_dropout)
     return m
 
 
@@ -89,7 +90,10 @@ def grad_rel_err(model, loss_fn, data, world, rank, set_precision, mode):
         loss_fn.fused(te, ve, n_, v_).backward()
         return {n: params[n].grad.detach().double().clone() for n in names}
 
+    pd, pa = model.text_model.config.dropout, model.text_model.config.attention_dropout
+    model.text_model.set_dropout(0.0, 0.0)          # two calls draw different masks: compare the deterministic function
     ref, got = grads("bf16x3"), grads(mode)
+    model.text_model.set_dropout(pd, pa)
     set_precision(mode)
     for p_ in model.parameters():
         p_.grad = None
@@ -110,6 +114,8 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("EGOVLP_PRECISION", "mixed"),
                     help="mixed (default: forward bf16x3 = embeddings and loss inside the 1e-3 parity bar, backward "
                          "single-pass bf16) | bf16 (single pass everywhere, fast mode) | bf16x3 (fp32-grade everywhere)")
+    ap.add_argument("--text-dropout", type=float, default=0.1, help="DistilBERT dropout / attention_dropout in the timed step "
+                    "(HF default 0.1 = what the reference trains with; 0 = the deterministic parity configuration)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass bf16 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -152,7 +158,7 @@ def main():
 
     set_precision(args.precision)
     B, T, L = args.batch, args.frames, 32
-    model = build_model(args.arch, 16).cuda().train()
+    model = build_model(args.arch, 16, args.text_dropout).cuda().train()
     net = model
     grad_sync = None
     if use_dist and args.ddp:
@@ -242,7 +248,8 @@ def main():
         "dtype": "bf16", "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
         "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
-                   "parallelism": f"dp{world}", "precision": "/".join(ops.Precision.name())},
+                   "parallelism": f"dp{world}", "precision": "/".join(ops.Precision.name()),
+                   "text_dropout": args.text_dropout},
         "loss": round(loss_val, 5),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
     }

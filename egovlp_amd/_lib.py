@@ -20,6 +20,7 @@ c_p = C.c_void_p
 i32 = C.c_int32
 i64 = C.c_int64
 f32 = C.c_float
+u64 = C.c_uint64
 
 
 class GemmDesc(C.Structure):
@@ -60,8 +61,10 @@ PROTOTYPES = {
     "egv_divided_attn_bwd_work_floats": (i64, [i32, i32, i32, i32]),
     "egv_embed_fwd": (i32, [c_p, c_p, c_p, i32, i32, i32, c_p, c_p]),
     "egv_embed_bwd": (i32, [c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p]),
-    "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, i64, c_p, i32, i32, i32, i32, c_p, c_p, c_p, c_p]),
-    "egv_text_attn_bwd": (i32, [c_p, c_p, c_p, i64, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p, c_p, i64, c_p, c_p]),
+    "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, i64, c_p, i32, i32, i32, i32, f32, u64, c_p, c_p, c_p, c_p]),
+    "egv_text_attn_bwd": (i32, [c_p, c_p, c_p, i64, c_p, c_p, c_p, i32, i32, i32, i32, f32, u64, c_p, c_p, c_p, i64, c_p, c_p]),
+    "egv_zero": (i32, [c_p, i64, c_p]),
+    "egv_dropout": (i32, [c_p, c_p, c_p, i64, f32, u64, c_p]),
     "egv_egonce_fwd_bwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, f32, f32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_egonce_work_floats": (i64, [i32, i32]),
     "egv_sim_matrix_fwd": (i32, [c_p, c_p, i32, i32, i32, f32, c_p, c_p, c_p, c_p, c_p]),

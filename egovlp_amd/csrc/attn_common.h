@@ -166,6 +166,8 @@ struct AttGeom {
   int B, T, n, H, S; // S = tokens per batch item (1+T*n or L)
   int nq, nk;
   const long long* mask;  // MODE_TEXT only
+  EgvDrop drop;           // MODE_TEXT only: attention-probability dropout (thresh == 0: none); element index
+                          // ((b * H + h) * S + query) * S + key
 };
 
 template <int MODE>

@@ -108,6 +108,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    if (MODE == MODE_TEXT && g.drop.thresh != 0u) {
+      // dropout on the attention weights (HF eager attention: softmax -> dropout -> . V): the survivors of P are scaled by
+      // 1 / (1 - p); the normaliser l is the softmax's and does not change
+      const uint64_t rowbase = (((uint64_t)grp.b * g.H + grp.h) * g.S + (uint64_t)min(qi, g.nq - 1)) * g.S;
+#pragma unroll
+      for (int kf = 0; kf < NKF; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kf][r] *= egv_drop_scale(g.drop, rowbase + kf * 16 + 4 * gq + r);
+    }
 
     f32x4_t o[4];
 #pragma unroll
@@ -203,12 +212,13 @@ int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, i
   g.B = B; g.T = T; g.n = n; g.H = H; g.S = 1 + T * n;
   g.nq = n; g.nk = n + 1;
   g.mask = nullptr;
+  g.drop = egv_make_drop(0.f, 0);
   return dispatch_fwd<MODE_SPACE>(g, B * T * H, passes, out_hi, out_lo, HD, lse, cls_ws, s);
 }
 
 extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
-                                 int32_t B, int32_t L, int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo,
-                                 float* lse, void* stream) {
+                                 int32_t B, int32_t L, int32_t H, int32_t passes, float dropout_p, uint64_t seed,
+                                 egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream) {
   if (!q || !k || !v || !out_hi || B <= 0 || L <= 0 || H <= 0) return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   if (passes == 3 && !out_lo) return EGV_ERR_ARG;
@@ -221,5 +231,7 @@ extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v,
   g.nq = L; g.nk = L;
   g.mask = (const long long*)mask;
   if (!mask || ldqkv < HD || ldqkv % 4 != 0) return EGV_ERR_ARG;
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return EGV_ERR_ARG;
+  g.drop = egv_make_drop(dropout_p, seed);
   return dispatch_fwd<MODE_TEXT>(g, B * H, passes, out_hi, out_lo, HD, lse, nullptr, (hipStream_t)stream);
 }

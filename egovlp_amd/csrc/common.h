@@ -86,6 +86,34 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// ---- counter-based dropout mask ------------------------------------------------------------------------
+// keep(seed, idx) is a pure function of a 64-bit seed (one per dropout site and step, chosen by the host) and the element
+// index, so the backward kernels regenerate the mask of the forward instead of storing it (HF DistilBERT, modeling_distilbert.py:
+// embedding / attention-probability / FFN dropout).  Two rounds of a 32-bit avalanche hash over the index words; this is NOT
+// PyTorch's Philox stream -- dropout masks are not part of the parity contract, only their statistics (keep rate 1 - p,
+// survivors scaled by 1 / (1 - p)) and the forward / backward consistency are (tests/test_gpu_dropout.py).
+__device__ __forceinline__ uint32_t egv_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+struct EgvDrop {
+  uint32_t s0, s1, thresh;   // seed words; keep <=> hash >= thresh (thresh = p * 2^32)
+  float scale;               // 1 / (1 - p); 0 threshold and scale 1 when p == 0
+};
+__device__ __forceinline__ float egv_drop_scale(const EgvDrop& d, uint64_t idx) {
+  const uint32_t h = egv_mix32(egv_mix32((uint32_t)idx ^ d.s0) ^ (uint32_t)(idx >> 32) ^ d.s1);
+  return h >= d.thresh ? d.scale : 0.0f;
+}
+static inline EgvDrop egv_make_drop(float p, uint64_t seed) {
+  EgvDrop d;
+  d.s0 = (uint32_t)seed; d.s1 = (uint32_t)(seed >> 32);
+  if (!(p > 0.f)) { d.thresh = 0u; d.scale = 1.0f; return d; }
+  const double t = (double)p * 4294967296.0;
+  d.thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+  d.scale = 1.0f / (1.0f - p);
+  return d;
+}
+
 // XCD-aware, bijective remap of a 1-D block id: blocks that the dispatcher places on one XCD
 // (bid % 8) receive a CONTIGUOUS range of work ids, so neighbouring tiles share that XCD's L2.
 // Speed only -- correctness never depends on placement.

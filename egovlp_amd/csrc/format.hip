@@ -471,3 +471,41 @@ extern "C" int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, in
 }
 
 extern "C" int egv_version(void) { return 1; }
+
+
+// ---- elementwise dropout (DistilBERT embedding / FFN dropout, HF modeling_distilbert.py Embeddings.forward, FFN.ff_chunk) -------
+// out[i] = x[i] * M'(i) + (add ? add[i] : 0), M' = keep ? 1 / (1 - p) : 0 from the counter-based mask of common.h.  The SAME
+// call with x = dy is the backward (the mask is regenerated from (p, seed)); `add` fuses the residual of `LN(ffn(x) + x)`.
+namespace {
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                      float* __restrict__ out, long n, EgvDrop d) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    f32x4_t v = *(const f32x4_t*)(x + i4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= egv_drop_scale(d, (uint64_t)(i4 + e));
+    if (add) v += *(const f32x4_t*)(add + i4);
+    *(f32x4_t*)(out + i4) = v;
+  } else {
+    for (long i = i4; i < n; ++i) out[i] = x[i] * egv_drop_scale(d, (uint64_t)i) + (add ? add[i] : 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int egv_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed, void* stream) {
+  if (!x || !out || n <= 0 || !(p >= 0.f && p < 1.f)) return EGV_ERR_ARG;
+  if ((((size_t)x) | ((size_t)out) | ((size_t)add)) & 15) return EGV_ERR_ARG;
+  const long blocks = (n / 4 + 256) / 256;
+  EGV_LAUNCH(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, add, out, (long)n, egv_make_drop(p, seed));
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+// Zero-fill of a freshly allocated buffer (embedding-gradient tables, the dense CLS-only gradient of the final LayerNorm) as a
+// memset node of the HIP runtime on the caller's stream -- not an ATen fill kernel.
+extern "C" int egv_zero(void* p, int64_t bytes, void* stream) {
+  if (!p || bytes < 0) return EGV_ERR_ARG;
+  if (bytes == 0) return EGV_OK;
+  const hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+  return e == hipSuccess ? EGV_OK : EGV_ERR_LAUNCH + (int)e;
+}

@@ -6,8 +6,11 @@ environment.yml:60; container copy 5.15: Embeddings :82-118, eager attention :12
 DistilBertSelfAttention :150-203, FFN :206-224, TransformerBlock :227-259, post-LN, eps 1e-12,
 exact-erf GELU).  Parameter names/shapes equal HF's, so `text_model.*` checkpoint keys load unchanged.
 
-Deviation (documented in DESIGN.md): dropout / attention_dropout are 0 here; HF's default 0.1 makes the
-reference's train-mode forward stochastic and is not part of the parity contract.
+Dropout: HF's defaults `dropout = attention_dropout = 0.1` are implemented and active in `train()` mode, as in the reference
+(`self.text_model.train()`, model/model.py:36): embedding output, attention probabilities and FFN output, each with a
+counter-based mask that the backward regenerates from (p, seed) instead of storing (csrc/common.h).  The masks are not
+PyTorch's Philox stream -- parity tests run in `eval()` or with `set_dropout(0, 0)`; tests/test_gpu_dropout.py pins the keep
+rate, the 1 / (1 - p) scaling and the forward / backward consistency.
 """
 from __future__ import annotations
 
@@ -24,7 +27,7 @@ from .video_transformer import _lin_bwd
 
 class DistilBertConfig:
     def __init__(self, vocab_size=30522, max_position_embeddings=512, dim=768, n_layers=6, n_heads=12,
-                 hidden_dim=3072, dropout=0.0, attention_dropout=0.0, pad_token_id=0):
+                 hidden_dim=3072, dropout=0.1, attention_dropout=0.1, pad_token_id=0):
         self.vocab_size = vocab_size
         self.max_position_embeddings = max_position_embeddings
         self.dim = dim
@@ -38,25 +41,31 @@ class DistilBertConfig:
 
 
 class _EmbedFn(torch.autograd.Function):
-    """Embeddings.forward: LN(word[ids] + pos[:L]), eps 1e-12."""
+    """Embeddings.forward: dropout(LN(word[ids] + pos[:L])), eps 1e-12."""
 
     @staticmethod
-    def forward(ctx, ids, word, pos, ln_w, ln_b, eps, pad_id):
+    def forward(ctx, ids, word, pos, ln_w, ln_b, eps, pad_id, drop):
         B, L = ids.shape
         D = word.shape[1]
         e = ops.embed_fwd(ids.contiguous(), word, pos, D)
         _, y, mean, rstd, _ = ops.layernorm_fwd(e, ln_w, ln_b, eps, 1, want_f32=True, want_planes=False)
+        if drop[0] > 0:
+            y = ops.dropout(y, drop[0], drop[1])
         ctx.save_for_backward(ids, e, ln_w, mean, rstd)
         ctx.shapes = (word.shape, pos.shape, pad_id)
+        ctx.drop = drop
         return y.view(B, L, D)
 
     @staticmethod
     def backward(ctx, dy):
         ids, e, ln_w, mean, rstd = ctx.saved_tensors
         D = e.shape[1]
-        de, dg, db = ops.layernorm_bwd(dy.contiguous().view(-1, D), e, ln_w, mean, rstd)
+        dy = dy.contiguous().view(-1, D)
+        if ctx.drop[0] > 0:
+            dy = ops.dropout(dy, ctx.drop[0], ctx.drop[1])
+        de, dg, db = ops.layernorm_bwd(dy, e, ln_w, mean, rstd)
         d_word, d_pos = ops.embed_bwd(ids.contiguous(), de, ctx.shapes[0], ctx.shapes[1], ctx.shapes[2])
-        return None, d_word, d_pos, dg, db, None, None
+        return None, d_word, d_pos, dg, db, None, None, None
 
 
 class _TextLayerFn(torch.autograd.Function):
@@ -65,7 +74,7 @@ class _TextLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask, geom, wc: WeightCache,
                 q_w, q_b, k_w, k_b, v_w, v_b, o_w, o_b, ln1_w, ln1_b, f1_w, f1_b, f2_w, f2_b, ln2_w, ln2_b):
-        B, L, H, eps = geom
+        B, L, H, eps, drop = geom          # drop = (attention p, attention seed, ffn p, ffn seed); p = 0 outside train()
         D = x.shape[-1]
         M = B * L
         P = Precision.fwd_passes
@@ -79,10 +88,10 @@ class _TextLayerFn(torch.autograd.Function):
         x_pl, _, _ = ops.split_f32(x2, P)
         # q_lin / k_lin / v_lin as ONE [M, 768] x [2304, 768]^T GEMM (M = B*L = 1024 is latency-bound: three launches -> one)
         qkv = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(x_pl, wc.get_cat((q_w, k_w, v_w), need_t=False)[0], passes=P, bias=torch.cat((q_b, k_b, v_b)),
+        ops.gemm_nt(x_pl, wc.get_cat((q_w, k_w, v_w), need_t=False)[0], passes=P, bias=wc.get_bias_cat((q_b, k_b, v_b)),
                     out_f32=qkv)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-        c_pl, lse = ops.text_attn_fwd(q, k, v, mask, B, L, H, P)
+        c_pl, lse = ops.text_attn_fwd(q, k, v, mask, B, L, H, P, drop[0], drop[1])
         s1 = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(c_pl, W(o_w), passes=P, bias=o_b, residual=x2, out_f32=s1)
         sa_pl, sa, mean1, rstd1, _ = ops.layernorm_fwd(s1, ln1_w, ln1_b, eps, P, want_f32=True)
@@ -91,7 +100,11 @@ class _TextLayerFn(torch.autograd.Function):
         z = torch.empty((M, Hd), dtype=torch.float32, device=dev) if train else None
         ops.gemm_nt(sa_pl, W(f1_w), passes=P, bias=f1_b, act=ACT_GELU, aux_out=z, out_planes=h)
         s2 = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, residual=sa, out_f32=s2)
+        if drop[2] > 0:        # FFN.forward: dropout(lin2(gelu(lin1(x)))), then the block's residual: s2 = drop(y) + sa
+            ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, out_f32=s2)
+            s2 = ops.dropout(s2, drop[2], drop[3], add=sa)
+        else:
+            ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, residual=sa, out_f32=s2)
         _, out, mean2, rstd2, _ = ops.layernorm_fwd(s2, ln2_w, ln2_b, eps, P, want_f32=True, want_planes=False)
         if train:
             ctx.geom, ctx.wc, ctx.P = geom, wc, P
@@ -105,7 +118,7 @@ class _TextLayerFn(torch.autograd.Function):
         (mask, qkv, lse, s1, mean1, rstd1, z, s2, mean2, rstd2,
          q_w, k_w, v_w, o_w, ln1_w, f1_w, f2_w, ln2_w) = ctx.saved_tensors
         x_pl, c_pl, sa_pl, h = ctx.planes
-        B, L, H, eps = ctx.geom
+        B, L, H, eps, drop = ctx.geom
         wc = ctx.wc
         Pb = Precision.bwd_passes
         if Pb > ctx.P:
@@ -117,8 +130,8 @@ class _TextLayerFn(torch.autograd.Function):
             return wc.get(p, need_t=True)[1]
 
         d_s2, d_ln2w, d_ln2b = ops.layernorm_bwd(G, s2, ln2_w, mean2, rstd2)
-        # FFN
-        g_pl = ops.split_f32(d_s2, Pb)[0]
+        # FFN (d_s2 reaches lin2 through the dropout mask of the forward; the residual branch takes it as it is)
+        g_pl = ops.split_f32(ops.dropout(d_s2, drop[2], drop[3]) if drop[2] > 0 else d_s2, Pb)[0]
         Hd = f1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(g_pl, Wt(f2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
@@ -131,7 +144,8 @@ class _TextLayerFn(torch.autograd.Function):
         d_ctx, d_ow, d_ob = _lin_bwd(d_s1, c_pl, Wt(o_w), Pb)
         D3 = 3 * D
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-        _, _, _, dqkv = ops.text_attn_bwd(q, k, v, mask, d_ctx, lse, B, L, H, Pb, fused_out=True)
+        _, _, _, dqkv = ops.text_attn_bwd(q, k, v, mask, d_ctx, lse, B, L, H, Pb, fused_out=True, dropout_p=drop[0],
+                                          seed=drop[1])
         # fused q/k/v projection backward: one wgrad (dW [2304, 768] + bias grads) and one dgrad chained onto d_s1
         dqkv_pl = ops.split_f32(dqkv, Pb)[0]
         _, dW3, db3 = _lin_bwd(dqkv_pl, x_pl, None, Pb, need_dx=False)
@@ -177,10 +191,10 @@ class TransformerBlock(nn.Module):
         self.ffn = FFN(config)
         self.output_layer_norm = nn.LayerNorm(config.dim, eps=1e-12)
 
-    def forward(self, x, mask, wc):
+    def forward(self, x, mask, wc, drop=(0.0, 0, 0.0, 0)):
         B, L, D = x.shape
         a, f = self.attention, self.ffn
-        geom = (B, L, a.n_heads, self.sa_layer_norm.eps)
+        geom = (B, L, a.n_heads, self.sa_layer_norm.eps, drop)
         return _TextLayerFn.apply(
             x, mask, geom, wc,
             a.q_lin.weight, a.q_lin.bias, a.k_lin.weight, a.k_lin.bias, a.v_lin.weight, a.v_lin.bias,
@@ -199,8 +213,10 @@ class DistilBertModel(nn.Module):
     def __init__(self, config=None):
         super().__init__()
         self.config = config or DistilBertConfig()
-        if self.config.dropout != 0.0 or self.config.attention_dropout != 0.0:
-            raise NotImplementedError("dropout is not implemented in the gfx950 text encoder (set to 0)")
+        for pr in (self.config.dropout, self.config.attention_dropout):
+            if not 0.0 <= pr < 1.0:
+                raise ValueError("dropout probabilities must be in [0, 1)")
+        self._drop_calls = 0            # every train-mode forward draws fresh masks: seed = f(torch seed, call #, site)
         self.embeddings = Embeddings(self.config)
         self.transformer = Transformer(self.config)
         self._wc = WeightCache()
@@ -212,6 +228,17 @@ class DistilBertModel(nn.Module):
             elif isinstance(m, nn.Embedding):
                 nn.init.normal_(m.weight, std=0.02)
 
+    def set_dropout(self, dropout, attention_dropout):
+        """Override HF's 0.1 / 0.1 (parity runs against the dropout-free oracle use 0, 0)."""
+        self.config.dropout, self.config.attention_dropout = float(dropout), float(attention_dropout)
+        return self
+
+    def _seed(self, site):
+        # 64-bit seed of one dropout site of one forward call: torch's seed, the call counter and the site id, mixed
+        x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03 + site * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        x ^= x >> 31
+        return (x * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+
     def forward(self, input_ids=None, attention_mask=None, **kw):
         if input_ids is None:
             raise NotImplementedError("inputs_embeds path is not on the EgoClip hot path")
@@ -220,10 +247,15 @@ class DistilBertModel(nn.Module):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         e = self.embeddings
+        pd = self.config.dropout if self.training else 0.0
+        pa = self.config.attention_dropout if self.training else 0.0
+        if pd > 0 or pa > 0:
+            self._drop_calls += 1
         x = _EmbedFn.apply(input_ids, e.word_embeddings.weight, e.position_embeddings.weight,
                            e.LayerNorm.weight, e.LayerNorm.bias, e.LayerNorm.eps,
-                           -1 if e.word_embeddings.padding_idx is None else e.word_embeddings.padding_idx)
+                           -1 if e.word_embeddings.padding_idx is None else e.word_embeddings.padding_idx,
+                           (pd, self._seed(0)))
         mask = attention_mask.to(torch.int64).contiguous()
-        for blk in self.transformer.layer:
-            x = blk(x, mask, self._wc)
+        for li, blk in enumerate(self.transformer.layer):
+            x = blk(x, mask, self._wc, (pa, self._seed(1 + 2 * li), pd, self._seed(2 + 2 * li)))
         return SimpleNamespace(last_hidden_state=x)

@@ -55,15 +55,29 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False):
 
 # Gradient hand-off between consecutive blocks' backward passes: the LayerNorm-backward kernel that produces a block's
 # input gradient d_x also emits it as split-bf16 planes (the format the previous block's GEMMs consume).  autograd only
-# carries the fp32 tensor, so the planes ride along keyed by its storage pointer; a miss (autograd copied or accumulated
-# the gradient) just falls back to one egv_split_f32 pass.
-_GRAD_PLANES = {}
+# carries the fp32 tensor, so the planes ride along ON that tensor object (`_egv_planes`: PyTorch preserves a tensor's Python
+# object, attributes included, across the engine), stamped with the tensor's version counter.  Anything that replaces the
+# tensor (gradient accumulation from a second consumer, hooks that return a new tensor) drops the attribute; anything that
+# modifies it in place bumps the version -- either way the consumer falls back to one egv_split_f32 pass of the real values.
+PLANE_HANDOFF = {"hit": 0, "miss": 0}     # diagnostics / tests
 
 
-def _take_grad_planes(g2d, Pb):
-    ent = _GRAD_PLANES.pop(g2d.data_ptr(), None)
-    if ent is not None and ent[0] == Pb and ent[1].rows == g2d.shape[0] and ent[1].cols == g2d.shape[1]:
-        return ent[1]
+def _attach_grad_planes(g, Pb, planes):
+    g._egv_planes = (Pb, planes, g._version)
+    return g
+
+
+def _take_grad_planes(g_out, g2d, Pb):
+    ent = getattr(g_out, "_egv_planes", None)
+    if ent is not None:
+        try:
+            del g_out._egv_planes
+        except AttributeError:
+            pass
+        if ent[0] == Pb and ent[2] == g_out._version and ent[1].rows == g2d.shape[0] and ent[1].cols == g2d.shape[1]:
+            PLANE_HANDOFF["hit"] += 1
+            return ent[1]
+    PLANE_HANDOFF["miss"] += 1
     return ops.split_f32(g2d, Pb)[0]
 
 
@@ -141,8 +155,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
             return wc.get(p, need_t=True)[1]
 
         # ---- MLP backward.  dZ = (G . W2) * gelu'(z) comes out of the fc2-dgrad epilogue already split.
-        G_pl = _take_grad_planes(G, Pb)
-        _GRAD_PLANES.clear()
+        G_pl = _take_grad_planes(g_out, G, Pb)
         Hd = fc1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
@@ -162,9 +175,8 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
         d_x, d_n3w, d_n3b, d_x_pl = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr,
                                                        planes_passes=Pb)
-        _GRAD_PLANES[d_x.data_ptr()] = (Pb, d_x_pl)
         S = 1 + T * n
-        return (d_x.view(B, S, D), None, None,
+        return (_attach_grad_planes(d_x.view(B, S, D), Pb, d_x_pl), None, None,
                 d_n3w, d_n3b, d_tqkv_w, d_tqkv_b, d_tproj_w, d_tproj_b,
                 d_n1w, d_n1b, d_sqkv_w, d_sqkv_b, d_sproj_w, d_sproj_b,
                 d_n2w, d_n2b, d_fc1_w.view_as(fc1_w), d_fc1_b, d_fc2_w.view_as(fc2_w), d_fc2_b)
@@ -178,7 +190,6 @@ class _PatchTokensFn(torch.autograd.Function):
     def forward(ctx, video, geom, wc, proj_w, proj_b, cls_token, pos_embed, temporal_embed):
         B, T, n, P_, D, T_model = geom[:6]
         Pp = Precision.fwd_passes
-        _GRAD_PLANES.clear()
         mean, std = geom[6] if len(geom) > 6 else (ops.IMAGENET_MEAN, ops.IMAGENET_STD)
         a = ops.patch_gather(video.contiguous(), P_, Pp, mean, std)   # uint8 frames: /255 + Normalize inside the gather
         K = proj_w[0].numel()
@@ -197,7 +208,6 @@ class _PatchTokensFn(torch.autograd.Function):
     def backward(ctx, dx):
         B, T, n, P_, D, T_model = ctx.geom[:6]
         Pb = Precision.bwd_passes
-        _GRAD_PLANES.clear()      # block 0's input-gradient planes have no consumer
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
         _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False)
         K = ctx.wshape[1] * ctx.wshape[2] * ctx.wshape[3]
@@ -222,7 +232,7 @@ class _ClsNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         xc, w, mean, rstd = ctx.saved_tensors
         B, S, D = xc.shape
-        dx = torch.zeros_like(xc)
+        dx = ops.zeros(tuple(xc.shape), device=xc.device)     # only the B CLS rows receive a gradient
         _, dg, db = ops.layernorm_bwd(dy.contiguous(), xc.view(B * S, D), w, mean, rstd, rows=B, ldx=S * D,
                                       dx=dx.view(B * S, D), lddx=S * D)
         return dx, dg, db, None

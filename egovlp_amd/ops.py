@@ -111,10 +111,17 @@ class Planes:
 
 def empty_planes(rows, cols, passes, device, ld=None, zero=False):
     ld = cols if ld is None else ld
-    mk = torch.zeros if zero else torch.empty
+    mk = (lambda shp, dtype, device: zeros(shp, dtype, device)) if zero else torch.empty
     hi = mk((rows, ld), dtype=torch.bfloat16, device=device)
     lo = mk((rows, ld), dtype=torch.bfloat16, device=device) if passes == 3 else None
     return Planes(hi, lo, rows, cols)
+
+
+def zeros(shape, dtype=torch.float32, device="cuda"):
+    """torch.zeros without the ATen fill kernel: caching-allocator memory + one memset node on the current stream."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    check(_lib.lib().egv_zero(_p(t), t.numel() * t.element_size(), _stream()), "egv_zero")
+    return t
 
 
 def pad32(n):
@@ -366,7 +373,7 @@ def assemble_tokens_bwd(dx, B, T, n, D, T_model):
     d_pe = torch.empty((B * T * n, D), dtype=torch.float32, device=dev)
     d_cls = torch.empty((1, 1, D), dtype=torch.float32, device=dev)
     d_pos = torch.empty((1, n + 1, D), dtype=torch.float32, device=dev)
-    d_tmp = torch.zeros((1, T_model, D), dtype=torch.float32, device=dev)
+    d_tmp = zeros((1, T_model, D), device=dev)
     check(_lib.lib().egv_assemble_tokens_bwd(_p(dx), B, T, n, D, T_model, _p(d_pe), _p(d_cls), _p(d_pos), _p(d_tmp),
                                              _stream()), "egv_assemble_tokens_bwd")
     return d_pe, d_cls, d_pos, d_tmp
@@ -397,17 +404,18 @@ def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, m
     return dqkv
 
 
-def text_attn_fwd(q, k, v, mask, B, L, H, passes):
-    """q, k, v: fp32 [B*L, H*64] tensors, or column-block views of one fused [B*L, 3*H*64] projection output."""
+def text_attn_fwd(q, k, v, mask, B, L, H, passes, dropout_p=0.0, seed=0):
+    """q, k, v: fp32 [B*L, H*64] tensors, or column-block views of one fused [B*L, 3*H*64] projection output.
+    dropout_p > 0: attention-probability dropout with the counter-based mask of (dropout_p, seed)."""
     out = empty_planes(B * L, H * 64, passes, q.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
-    check(_lib.lib().egv_text_attn_fwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), B, L, H, passes, _p(out.hi),
-                                       _p(out.lo), _p(lse), _stream()), "egv_text_attn_fwd")
+    check(_lib.lib().egv_text_attn_fwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), B, L, H, passes, float(dropout_p),
+                                       int(seed), _p(out.hi), _p(out.lo), _p(lse), _stream()), "egv_text_attn_fwd")
     return out, lse
 
 
-def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False):
+def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False, dropout_p=0.0, seed=0):
     """-> (dq, dk, dv); with fused_out they are the column blocks of ONE [B*L, 3*H*64] tensor (returned 4th)."""
     HD = H * 64
     if fused_out:
@@ -418,8 +426,18 @@ def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     work = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     check(_lib.lib().egv_text_attn_bwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), _p(d_out), _p(lse), B, L, H, passes,
-                                       _p(dq), _p(dk), _p(dv), dq.stride(0), _p(work), _stream()), "egv_text_attn_bwd")
+                                       float(dropout_p), int(seed), _p(dq), _p(dk), _p(dv), dq.stride(0), _p(work),
+                                       _stream()), "egv_text_attn_bwd")
     return (dq, dk, dv, dqkv) if fused_out else (dq, dk, dv)
+
+
+def dropout(x, p, seed, add=None):
+    """out = x * M'(p, seed) + add (elementwise, contiguous fp32); with x = dy the same call is the backward."""
+    _need_cuda(x, add)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().egv_dropout(_p(x), _p(add), _p(out), x.numel(), float(p), int(seed), _stream()), "egv_dropout")
+    return out
 
 
 def embed_fwd(ids, word, pos, D):
@@ -432,8 +450,8 @@ def embed_fwd(ids, word, pos, D):
 def embed_bwd(ids, d_e, word_shape, pos_shape, pad_id=-1):
     B, L = ids.shape
     D = word_shape[1]
-    d_word = torch.zeros(word_shape, dtype=torch.float32, device=d_e.device)
-    d_pos = torch.zeros(pos_shape, dtype=torch.float32, device=d_e.device)
+    d_word = zeros(tuple(word_shape), device=d_e.device)
+    d_pos = zeros(tuple(pos_shape), device=d_e.device)
     check(_lib.lib().egv_embed_bwd(_p(ids), _p(d_e), B, L, D, int(pad_id), _p(d_word), _p(d_pos), _stream()),
           "egv_embed_bwd")
     return d_word, d_pos

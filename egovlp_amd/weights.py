@@ -39,6 +39,7 @@ class _Entry:
 class WeightCache:
     def __init__(self):
         self._c = {}
+        self._c_bias = {}
 
     # -- one launch for every stale entry that already owns its planes
     def _refresh_all(self):
@@ -95,5 +96,17 @@ class WeightCache:
         [3*768, 768] GEMM) -> (Planes [sum N_i, K], Planes [K, sum N_i] | None)."""
         return self._get(tuple(params), need_t)
 
+    def get_bias_cat(self, biases):
+        """The concatenation of several bias vectors (DistilBERT's fused q/k/v projection), rebuilt only when one of them
+        changed -- not one torch.cat per layer per step."""
+        key = ("bias",) + tuple(id(b) for b in biases)
+        ent = self._c_bias.get(key)
+        ver = tuple((b._version, EPOCH, b.data_ptr()) for b in biases)
+        if ent is None or ent[0] != ver:
+            ent = (ver, torch.cat([b.detach() for b in biases]))
+            self._c_bias[key] = ent
+        return ent[1]
+
     def clear(self):
         self._c.clear()
+        self._c_bias.clear()

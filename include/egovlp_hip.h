@@ -163,14 +163,21 @@ int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, int32_t L, in
  * mask [B, L] int64 (0 = padded key -> -inf).  Output split planes [B, L, H*64]; probs are recomputed
  * in backward from lse [B,H,L].                                                                     */
 int egv_text_attn_fwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask, int32_t B,
-                      int32_t L, int32_t H, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse,
-                      void* stream);
+                      int32_t L, int32_t H, int32_t passes, float dropout_p, uint64_t seed, egv_bf16* out_hi,
+                      egv_bf16* out_lo, float* lse, void* stream);
 /* q, k, v (and dq, dk, dv) rows are ldqkv (lddqkv) floats apart: H*64 for separate tensors, 3*H*64 when they are the
- * three column blocks of one fused [B*L, 3*H*64] projection output (one GEMM instead of three).                      */
+ * three column blocks of one fused [B*L, 3*H*64] projection output (one GEMM instead of three).
+ * dropout_p > 0: HF's attention dropout (softmax -> dropout -> . V, modeling_distilbert.py eager attention) with the
+ * counter-based mask keep(seed, ((b*H + h)*L + query)*L + key); the backward regenerates it from the same (dropout_p, seed). */
 int egv_text_attn_bwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
                       const float* d_out, const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
-                      float* dq, float* dk, float* dv, int64_t lddqkv, float* delta_work /* B*H*L floats */,
-                      void* stream);
+                      float dropout_p, uint64_t seed, float* dq, float* dk, float* dv, int64_t lddqkv,
+                      float* delta_work /* B*H*L floats */, void* stream);
+/* Zero-fill (hipMemsetAsync on `stream`) of a buffer the caller has just allocated.                                    */
+int egv_zero(void* p, int64_t bytes, void* stream);
+/* Elementwise dropout of DistilBERT (embedding output, FFN output): out[i] = x[i] * M'(i) + (add ? add[i] : 0) with
+ * M'(i) = keep(seed, i) ? 1 / (1 - p) : 0.  The same call with x = dy is its backward.  16-byte aligned pointers.      */
+int egv_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed, void* stream);
 
 /* ---- contrastive head ---------------------------------------------------------------------------------
  * sim_matrix x3 + EgoNCE/NormSoftmaxLoss forward AND backward in one launch

