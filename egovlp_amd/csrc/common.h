@@ -33,12 +33,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 // ---- bf16 <-> f32 -----------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even (inputs are finite in this path; NaN propagates as a quiet NaN)
-__device__ __forceinline__ bf16_t f32_to_bf16(float x) {
-  uint32_t u = __float_as_uint(x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, on the CDNA4 conversion instruction v_cvt_pk_bf16_f32 (two values per issue; the
+// integer-add emulation of older targets costs ~4 VALU ops per value and showed up in every plane-writing epilogue).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float a, float b) {       // a -> bits 0..15, b -> bits 16..31
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float x) { return (bf16_t)(f32x2_to_bf16x2(x, 0.f) & 0xffffu); }
 
 // "split-bf16": x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi); |x - hi - lo| <= 2^-17 |x|.
 // Three bf16 MFMA passes (hi*hi + hi*lo + lo*hi) on such pairs reproduce an fp32 product to ~2^-16
@@ -46,6 +48,11 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float x) {
 __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   hi = f32_to_bf16(x);
   lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+// the same for a pair, packed (a in the low half): 2 conversions + 2 subtractions + 2 unpack ops for two values
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = f32x2_to_bf16x2(a, b);
+  lo = f32x2_to_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
 __device__ __forceinline__ uint32_t pack2(bf16_t a, bf16_t b) { return (uint32_t)a | ((uint32_t)b << 16); }

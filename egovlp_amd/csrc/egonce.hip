@@ -393,3 +393,61 @@ extern "C" int egv_egonce_from_sim(const float* x, const float* sim_v, const flo
   }
   return EGV_OK;
 }
+
+// ---- max-margin ranking losses (model/loss.py:55-133; the EPIC-MIR / Charades fine-tuning heads on the same similarity
+// matrix) ----------------------------------------------------------------------------------------------------------------
+//   loss = mean over the kept (i, j) of  relu(w_i m - x_ii + x_ij) + relu(w_i m - x_ii + x_ji)
+// (w_i = 1: MaxMarginRankingLoss; w_i = weight[i]: AdaptiveMaxMarginRankingLoss); fix_norm drops the diagonal pairs, so the
+// mean runs over 2 n (n - 1) terms instead of 2 n^2.  The gradient is local in x:
+//   d x_ab (a != b) = ( [w_a m - x_aa + x_ab > 0] + [w_b m - x_bb + x_ab > 0] ) / count
+//   d x_aa          = - sum_{j != a} ( [w_a m - x_aa + x_aj > 0] + [w_a m - x_aa + x_ja > 0] ) / count
+// One workgroup per row a; the loss is accumulated with one atomicAdd per row into a zeroed scalar.
+namespace {
+__global__ __launch_bounds__(256) void maxmargin_kernel(const float* __restrict__ x, const float* __restrict__ w, int n,
+                                                        float margin, int fix_norm, float inv_count,
+                                                        float* __restrict__ loss, float* __restrict__ dx) {
+  const int a = blockIdx.x;
+  const float xaa = x[(long)a * n + a];
+  const float ma = (w ? w[a] : 1.0f) * margin;
+  float lsum = 0.f, dsum = 0.f;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const float xaj = x[(long)a * n + j], xja = x[(long)j * n + a];
+    const float t1 = ma - xaa + xaj, t2 = ma - xaa + xja;
+    if (j != a) {
+      lsum += fmaxf(t1, 0.f) + fmaxf(t2, 0.f);
+      const float i1 = t1 > 0.f ? 1.f : 0.f, i2 = t2 > 0.f ? 1.f : 0.f;
+      dsum += i1 + i2;
+      if (dx) {
+        const float mj = (w ? w[j] : 1.0f) * margin;
+        const float t3 = mj - x[(long)j * n + j] + xaj;        // the column-direction term of row j that contains x_aj
+        dx[(long)a * n + j] = (i1 + (t3 > 0.f ? 1.f : 0.f)) * inv_count;
+      }
+    } else if (!fix_norm) {
+      lsum += 2.f * fmaxf(ma, 0.f);                             // x_aa cancels: constant terms, no gradient
+    }
+  }
+  __shared__ float red[2][4];
+  lsum = wave_sum(lsum);
+  dsum = wave_sum(dsum);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = lsum;
+    red[1][threadIdx.x >> 6] = dsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(loss, (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_count);
+    if (dx) dx[(long)a * n + a] = -(red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_count;
+  }
+}
+}  // namespace
+
+extern "C" int egv_maxmargin_fwd_bwd(const float* x, const float* weight, int32_t n, float margin, int32_t fix_norm,
+                                     float* loss, float* dx, void* stream) {
+  if (!x || !loss || n <= 0 || n > 4096 || (fix_norm && n < 2)) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return EGV_ERR_LAUNCH;
+  const double count = fix_norm ? 2.0 * n * (n - 1.0) : 2.0 * n * (double)n;
+  EGV_LAUNCH(maxmargin_kernel, dim3(n), dim3(256), 0, s, x, weight, n, margin, fix_norm, (float)(1.0 / count), loss, dx);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}

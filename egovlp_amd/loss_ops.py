@@ -48,3 +48,20 @@ def egonce_from_sim(x, sim_v, sim_n, temperature, use_noun, use_verb, want_grad=
     check(_lib.lib().egv_egonce_from_sim(_p(x), _p(sv), _p(sn), n, float(temperature), int(use_noun), int(use_verb),
                                          _p(loss), _p(dx), _p(work), _stream()), "egv_egonce_from_sim")
     return loss, dx
+
+
+def maxmargin(x, weight, margin, fix_norm, want_grad=True):
+    """MaxMarginRankingLoss (weight None) / AdaptiveMaxMarginRankingLoss on a square similarity matrix -> (loss[1], dx)."""
+    ops._need_cuda(x, weight)
+    x = x.contiguous().float()
+    n = x.shape[0]
+    if x.dim() != 2 or x.shape[1] != n:
+        raise ValueError("the ranking losses need a square similarity matrix")
+    w = None if weight is None else weight.contiguous().float()
+    if w is not None and w.numel() != n:
+        raise ValueError("weight must have one entry per row")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if want_grad else None
+    check(_lib.lib().egv_maxmargin_fwd_bwd(_p(x), _p(w), n, float(margin), int(bool(fix_norm)), _p(loss), _p(dx), _stream()),
+          "egv_maxmargin_fwd_bwd")
+    return loss, dx

@@ -5,8 +5,9 @@ Two ways in, same kernels underneath (egovlp_amd/csrc/egonce.hip):
     trainer/trainer_egoclip.py:130-137): `forward` below, an autograd node over egv_egonce_from_sim;
   * the fused hot path  `loss.fused(text, video, noun, verb)`: ONE call computes the three similarity
     matrices, the mask, the loss and the gradients w.r.t. both embeddings (egv_egonce_fwd_bwd).
-The other losses of model/loss.py (MaxMarginRankingLoss :55-90, AdaptiveMaxMarginRankingLoss :92-133,
-CrossEntropy :135-141) belong to fine-tuning paths and are out of scope.
+MaxMarginRankingLoss (:55-90) and AdaptiveMaxMarginRankingLoss (:92-133), the EPIC-MIR / Charades fine-tuning heads over the
+same similarity matrix, run on egv_maxmargin_fwd_bwd.  CrossEntropy (:135-141) is a plain nn.CrossEntropyLoss
+wrapper of the classification fine-tunes and stays out of scope.
 """
 import torch
 from torch import nn
@@ -70,3 +71,42 @@ class EgoNCE(nn.Module):
     def fused(self, text_embeds, video_embeds, noun_vec, verb_vec):
         return _FusedHeadFn.apply(text_embeds, video_embeds, noun_vec, verb_vec, self.temperature, self.noun,
                                   self.verb or not self.noun)
+
+
+class _MaxMarginFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, margin, fix_norm):
+        loss, dx = loss_ops.maxmargin(x, weight, margin, fix_norm, want_grad=True)
+        ctx.save_for_backward(dx)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None, None, None
+
+
+class MaxMarginRankingLoss(nn.Module):
+    """model/loss.py:55-90 (same constructor; `weight` is accepted and ignored, as in the reference)."""
+
+    def __init__(self, margin=0.2, fix_norm=True):
+        super().__init__()
+        self.fix_norm = fix_norm
+        self.margin = margin
+
+    def forward(self, x, weight=None):
+        return _MaxMarginFn.apply(x, None, self.margin, self.fix_norm)
+
+
+class AdaptiveMaxMarginRankingLoss(nn.Module):
+    """model/loss.py:92-133: the margin of row i is weight[i] * margin."""
+
+    def __init__(self, margin=0.4, fix_norm=True):
+        super().__init__()
+        self.fix_norm = fix_norm
+        self.margin = margin
+
+    def forward(self, x, weight=None):
+        if weight is None:
+            raise TypeError("AdaptiveMaxMarginRankingLoss needs the per-row weight (model/loss.py:109)")
+        return _MaxMarginFn.apply(x, weight, self.margin, self.fix_norm)

@@ -70,7 +70,6 @@ int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
  * so that the RCCL kernels of the overlapped gradient all-reduce find free CUs.  Multiples of 8 in [8, 256] are accepted;
  * returns the previous value (process-wide, read at every launch).                                                    */
 int egv_gemm_set_grid(int32_t workgroups);
-
 /* ---- format kernels (HBM-bound) -----------------------------------------------------------------
  * fp32 [rows, cols] -> split planes, optionally also the TRANSPOSED planes t_*[cols, ldt] (ldt >= rows,
  * columns rows..ldt-1 are zero-filled so a following GEMM can contract over a K padded to 32) and the
@@ -202,6 +201,13 @@ int egv_sim_matrix_bwd(const float* g, const float* an, const float* bn, const f
 int egv_egonce_from_sim(const float* x, const float* sim_v, const float* sim_n, int32_t n, float temperature,
                         int32_t use_noun, int32_t use_verb, float* loss, float* dx,
                         float* work /* n*n + 6n floats */, void* stream);
+
+/* Max-margin ranking losses of the fine-tuning heads (model/loss.py:55-133) on a square similarity matrix x [n, n]:
+ *   loss = mean_{kept (i,j)} relu(w_i m - x_ii + x_ij) + relu(w_i m - x_ii + x_ji),   w = NULL: MaxMarginRankingLoss (w_i = 1),
+ *   w = weight [n]: AdaptiveMaxMarginRankingLoss; fix_norm != 0 drops the diagonal pairs (mean over 2 n (n - 1) terms).
+ * dx (optional) receives d loss / d x.  n <= 4096.                                                                       */
+int egv_maxmargin_fwd_bwd(const float* x, const float* weight, int32_t n, float margin, int32_t fix_norm,
+                          float* loss, float* dx, void* stream);
 
 /* ---- gradient exchange (data parallel) ------------------------------------------------------------------
  * Replaces the fp32 bucket copies of DistributedDataParallel (base/base_trainer.py:258): `count` fp32 gradient tensors

@@ -292,3 +292,21 @@ def adamw_step(p, g, m, v, step, lr=3e-5, beta1=0.9, beta2=0.999, eps=1e-6, weig
     if weight_decay > 0.0:
         p.add_(p, alpha=-lr * weight_decay)
     return p
+
+
+# ----------------------------------------------------------------------------- fine-tune ranking losses
+
+def max_margin_ranking_loss(x, margin=0.2, fix_norm=True, weight=None):
+    """MaxMarginRankingLoss.forward (model/loss.py:63-89) and, with `weight`, AdaptiveMaxMarginRankingLoss.forward
+    (:100-132), restated without the index_select gymnastics: the two halves of the reference's concatenation are the
+    row-direction terms relu(w_i m - (x_ii - x_ij)) and the column-direction terms relu(w_i m - (x_ii - x_ji)); fix_norm
+    removes the diagonal pairs before the mean (:77-87, :119-130)."""
+    n = x.shape[0]
+    d = torch.diag(x).unsqueeze(1)                                              # x1: x_ii expanded along j (:66-69)
+    m = margin if weight is None else weight.unsqueeze(1) * margin             # w1 (:106-109)
+    rows = F.relu(m - (d - x))                                                  # x2 = x.view(-1)          (:71)
+    cols = F.relu(m - (d - x.t()))                                              # x3 = x.t().view(-1)      (:72)
+    if fix_norm:
+        keep = 1.0 - torch.eye(n, dtype=x.dtype)
+        return ((rows + cols) * keep).sum() / (2 * n * (n - 1))
+    return (rows + cols).sum() / (2 * n * n)

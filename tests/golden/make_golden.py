@@ -174,9 +174,32 @@ def make_gather():
     print("gather_w2: loss", out["loss0"], out["loss1"])
 
 
+def make_losses(ml):
+    """The reference's own MaxMarginRankingLoss / AdaptiveMaxMarginRankingLoss (model/loss.py:55-133) on seeded similarity
+    matrices: loss values and d loss / d x from torch autograd."""
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    for n in (5, 48, 200):
+        x = (torch.rand(n, n, generator=g) * 2 - 1).requires_grad_(True)
+        w = torch.rand(n, generator=g) * 1.5 + 0.1
+        for fix in (True, False):
+            for name, loss, args in (("mm", ml.MaxMarginRankingLoss(margin=0.2, fix_norm=fix), ()),
+                                     ("amm", ml.AdaptiveMaxMarginRankingLoss(margin=0.4, fix_norm=fix), (w,))):
+                x.grad = None
+                v = loss(x, *args)
+                v.backward()
+                key = f"{name}_n{n}_fix{int(fix)}"
+                out["loss_" + key] = np32(v)
+                out["grad_" + key] = np32(x.grad)
+        out[f"x_n{n}"] = np32(x)
+        out[f"w_n{n}"] = np32(w)
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    print("losses:", {k: float(v) for k, v in out.items() if k.startswith("loss_") and "n48" in k})
+
+
 if __name__ == "__main__":
     assert ref_import.available(), "needs /root/reference (build container only)"
-    which = sys.argv[1:] or ["tiny", "gather", "full"]
+    which = sys.argv[1:] or ["tiny", "gather", "full", "losses"]
     if "gather" in which:
         make_gather()
     mm, ml, te, mv = ref_import.load_reference()
@@ -184,3 +207,5 @@ if __name__ == "__main__":
         make_tiny(mv)
     if "full" in which:
         make_full(mm, ml)
+    if "losses" in which:
+        make_losses(ml)

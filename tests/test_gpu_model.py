@@ -210,8 +210,9 @@ def test_train_step_matches_oracle(full, mode):
         assert abs(float(loss) - float(ref)) < PARITY * abs(float(ref))
         new = dict(m.named_parameters())
         # Adam's first update is lr * g / (|g| + eps): sign-like, so an element whose gradient is within the backward's error of
-        # zero flips by 2 lr.  bf16x3 backward (gradients at 1e-4): 2e-2 of the update norm; single-pass backward (1e-2): 1e-1.
-        bound = 2e-2 if mode == "bf16x3" else 1e-1
+        # zero flips by 2 lr.  bf16x3 backward (gradients at 1e-4): measured < 1e-3 of the update norm, bound 2e-2; single-pass
+        # backward (gradients at 1e-2): measured 4e-2 .. 8e-2, bound 1.5e-1.
+        bound = 2e-2 if mode == "bf16x3" else 1.5e-1
         for name in watch:
             p = sdo[name].detach().clone()
             O.adamw_step(p, sdo[name].grad, torch.zeros_like(p), torch.zeros_like(p), 1, lr=3e-5)

@@ -6,6 +6,7 @@ Tolerances: "bf16x3" (split-bf16, 3 MFMA passes) is the parity mode -- rel-L2 <=
 inside the 1e-3 end-to-end bar; "bf16" (1 pass) is the fast mode -- rel-L2 <= 1e-2 per op.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -385,3 +386,23 @@ def test_weight_cache_multi_tensor_refresh(ops):
     cat = torch.cat([q.detach(), k_.detach(), v.detach()], 0)
     rp, rt, _ = ops.split_f32(cat, 3, want_rowmajor=True, want_transposed=True)
     assert torch.equal(pl.hi, rp.hi) and torch.equal(pl.lo, rp.lo) and torch.equal(tp.hi, rt.hi) and torch.equal(tp.lo, rt.lo)
+
+
+@pytest.mark.parametrize("n", [5, 48, 200])
+def test_max_margin_ranking_losses_match_reference_golden(golden_dir, n):
+    """MaxMarginRankingLoss / AdaptiveMaxMarginRankingLoss (model/loss.py:55-133) on egv_maxmargin_fwd_bwd vs the golden vectors
+    produced by the reference's own classes (tests/golden/losses.npz): loss and d loss / d x."""
+    import numpy as np
+    from egovlp_amd.model.loss import AdaptiveMaxMarginRankingLoss, MaxMarginRankingLoss
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    for fix in (1, 0):
+        for name in ("mm", "amm"):
+            x = torch.from_numpy(g[f"x_n{n}"]).cuda().requires_grad_(True)
+            w = torch.from_numpy(g[f"w_n{n}"]).cuda()
+            loss = MaxMarginRankingLoss(0.2, bool(fix)) if name == "mm" else AdaptiveMaxMarginRankingLoss(0.4, bool(fix))
+            v = loss(x) if name == "mm" else loss(x, w)
+            (v * 3.0).backward()
+            key = f"{name}_n{n}_fix{fix}"
+            want = float(g["loss_" + key])
+            assert abs(float(v) - want) < 2e-6 * max(1.0, abs(want)), (key, float(v), want)
+            assert torch.allclose(x.grad.cpu() / 3.0, torch.from_numpy(g["grad_" + key]), rtol=1e-5, atol=1e-8), key

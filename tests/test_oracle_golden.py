@@ -110,3 +110,19 @@ def test_adamw_restatement_matches_published_algorithm():
     m1 = 0.1 * g; v1 = 0.001 * g * g
     ref = p0 - 1e-2 * (1 - 0.999) ** 0.5 / (1 - 0.9) * m1 / (v1.sqrt() + 1e-6)
     assert torch.allclose(p, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_ranking_losses_match_the_reference(golden_dir):
+    """oracle.max_margin_ranking_loss vs the reference's MaxMarginRankingLoss / AdaptiveMaxMarginRankingLoss (model/loss.py:
+    55-133): loss values and gradients, with and without fix_norm."""
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    for n in (5, 48, 200):
+        for fix in (1, 0):
+            for name, margin in (("mm", 0.2), ("amm", 0.4)):
+                x = torch.from_numpy(g[f"x_n{n}"]).clone().requires_grad_(True)
+                w = torch.from_numpy(g[f"w_n{n}"]) if name == "amm" else None
+                v = O.max_margin_ranking_loss(x, margin, bool(fix), w)
+                v.backward()
+                key = f"{name}_n{n}_fix{fix}"
+                assert abs(float(v) - float(g["loss_" + key])) < 1e-6 * max(1.0, abs(float(g["loss_" + key]))), key
+                assert torch.allclose(x.grad, torch.from_numpy(g["grad_" + key]), rtol=1e-5, atol=1e-8), key
