@@ -53,6 +53,7 @@ PROTOTYPES = {
     "egv_layernorm_bwd": (i32, [c_p, c_p, c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_patch_gather": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, i64, c_p]),
     "egv_patch_gather_u8": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p]),
+    "egv_patch_gather_u8_aug": (i32, [c_p, i32, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "egv_assemble_tokens": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, c_p, c_p]),
     "egv_assemble_tokens_bwd": (i32, [c_p, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),
     "egv_divided_attn_fwd": (i32, [c_p, c_p, i32, i32, i32, i32, i32, i32, c_p, c_p, c_p, c_p, c_p]),

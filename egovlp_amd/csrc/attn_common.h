@@ -85,17 +85,14 @@ __device__ __forceinline__ bf16x8_t att_frag_rows(const char* plane, int r0, int
 #endif
 }
 
-// 8 fp32 -> split bf16x8 pair
+// 8 fp32 -> split bf16x8 pair (four v_cvt_pk_bf16_f32 per plane)
 __device__ __forceinline__ void att_split8(const float* v, bf16x8_t& hi, bf16x8_t& lo) {
-  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
-  u16x8_t h, l;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    bf16_t a, b;
-    split_bf16(v[e], a, b);
-    h[e] = a;
-    l[e] = b;
-  }
+  u32x4_t h, l;
+  uint32_t a, b;
+  split_bf16x2(v[0], v[1], a, b); h[0] = a; l[0] = b;
+  split_bf16x2(v[2], v[3], a, b); h[1] = a; l[1] = b;
+  split_bf16x2(v[4], v[5], a, b); h[2] = a; l[2] = b;
+  split_bf16x2(v[6], v[7], a, b); h[3] = a; l[3] = b;
   hi = __builtin_bit_cast(bf16x8_t, h);
   lo = __builtin_bit_cast(bf16x8_t, l);
 }

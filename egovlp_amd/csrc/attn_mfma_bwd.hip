@@ -34,11 +34,11 @@ struct AttGrad {
 };
 
 __device__ __forceinline__ void store_planes4(bf16_t* hi, bf16_t* lo, long off, f32x4_t v) {
-  bf16_t h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
-  *(u32x2_t*)(hi + off) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
-  if (lo) *(u32x2_t*)(lo + off) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+  uint32_t h0, h1, l0, l1;
+  split_bf16x2(v[0], v[1], h0, l0);
+  split_bf16x2(v[2], v[3], h1, l1);
+  *(u32x2_t*)(hi + off) = (u32x2_t){h0, h1};
+  if (lo) *(u32x2_t*)(lo + off) = (u32x2_t){l0, l1};
 }
 
 // ------------------------------------------------------------------------------------------------ dQ

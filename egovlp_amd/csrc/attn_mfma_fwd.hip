@@ -151,12 +151,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
       bf16_t* ol = out_lo ? out_lo + tok * out_stride + hoff : nullptr;
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        bf16_t h[4], lo4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) split_bf16(o[df][r] * inv, h[r], lo4[r]);
+        uint32_t h0, h1, l0, l1;
+        split_bf16x2(o[df][0] * inv, o[df][1] * inv, h0, l0);
+        split_bf16x2(o[df][2] * inv, o[df][3] * inv, h1, l1);
         const int d = df * 16 + 4 * gq;
-        *(u32x2_t*)(oh + d) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
-        if (ol) *(u32x2_t*)(ol + d) = (u32x2_t){pack2(lo4[0], lo4[1]), pack2(lo4[2], lo4[3])};
+        *(u32x2_t*)(oh + d) = (u32x2_t){h0, h1};
+        if (ol) *(u32x2_t*)(ol + d) = (u32x2_t){l0, l1};
       }
       if (gq == 0 && lse) {
         const long srow = tok - grp.tok0;

@@ -73,13 +73,18 @@ __device__ __forceinline__ void ldp(const bf16_t* __restrict__ ph, const bf16_t*
 
 template <int CPL>
 __device__ __forceinline__ void stp(bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long off, const float (&x)[CPL]) {
+  if (CPL == 4) {
+    uint32_t h0, h1, l0, l1;
+    split_bf16x2(x[0], x[1], h0, l0);
+    split_bf16x2(x[CPL > 2 ? 2 : 0], x[CPL > 3 ? 3 : 0], h1, l1);
+    *(u32x2_t*)(ph + off) = (u32x2_t){h0, h1};
+    if (pl) *(u32x2_t*)(pl + off) = (u32x2_t){l0, l1};
+    return;
+  }
   bf16_t h[CPL], l[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) split_bf16(x[c], h[c], l[c]);
-  if (CPL == 4) {
-    *(u32x2_t*)(ph + off) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
-    if (pl) *(u32x2_t*)(pl + off) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
-  } else if (CPL == 2) {
+  if (CPL == 2) {
     *(uint32_t*)(ph + off) = pack2(h[0], h[1]);
     if (pl) *(uint32_t*)(pl + off) = pack2(l[0], l[1]);
   } else {

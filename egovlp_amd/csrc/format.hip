@@ -509,3 +509,110 @@ extern "C" int egv_zero(void* p, int64_t bytes, void* stream) {
   const hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
   return e == hipSuccess ? EGV_OK : EGV_ERR_LAUNCH + (int)e;
 }
+
+// ---- train-time augmentation fused into the patch gather (data_loader/transforms.py:14-19: RandomResizedCrop(
+// input_res, scale) -> RandomHorizontalFlip -> ColorJitter(0, 0, 0) = identity -> Normalize) -----------------------------------
+// The loader hands over the DECODED uint8 clip [B*T, C, Hs, Ws] and five ints per clip -- the crop box (top, left, h, w) and a
+// flip flag, the random draws of the host transform (one box per clip: the reference applies the transform to the [T, C, H, W]
+// tensor as a whole).  Every output pixel of the R x R frame is sampled here: x / 255 first (the reference resizes float frames),
+// bilinear with align_corners = False semantics (source index (o + 0.5) * size / R - 0.5 clamped at 0, right / bottom neighbour
+// clamped to the box), mirrored when flipped, normalised, split and written straight into the im2col planes of the patch-embed
+// GEMM.  No resized fp32 clip ever exists in HBM (the host transform writes 4 x 3 x 224 x 224 floats per clip and the H2D
+// copy carries them).
+namespace {
+struct AugBox { int top, left, h, w, flip; };
+__global__ __launch_bounds__(256) void patch_gather_aug_kernel(const unsigned char* __restrict__ video, int BT, int T, int C,
+                                                               int Hs, int Ws, int R, int P, const int* __restrict__ boxes,
+                                                               bf16_t* __restrict__ ahi, bf16_t* __restrict__ alo, long lda,
+                                                               const PatchNorm nrm) {
+  // thread -> (image bt, channel c, output row y, 4-pixel group xg)
+  const int WG = R / 4;
+  const long total = (long)BT * C * R * WG;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int xg = (int)(i % WG);
+  long t = i / WG;
+  const int y = (int)(t % R);
+  t /= R;
+  const int c = (int)(t % C);
+  const int bt = (int)(t / C);
+  const int* bx = boxes + (long)(bt / T) * 5;
+  const int top = bx[0], left = bx[1], bh = bx[2], bw = bx[3], flip = bx[4];
+  const unsigned char* src = video + ((long)bt * C + c) * Hs * Ws;
+  const float sy = (float)bh / (float)R, sx = (float)bw / (float)R;
+  float fy = ((float)y + 0.5f) * sy - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  const int y0 = (int)fy;
+  const int y1 = y0 + (y0 < bh - 1 ? 1 : 0);
+  const float ly = fy - (float)y0;
+  const unsigned char* r0 = src + (long)(top + y0) * Ws + left;
+  const unsigned char* r1 = src + (long)(top + y1) * Ws + left;
+  const float mu = nrm.mean[c], sd = nrm.std[c];
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ox = xg * 4 + e;
+    const int sxi = flip ? R - 1 - ox : ox;               // RandomHorizontalFlip acts on the resized crop
+    float fx = ((float)sxi + 0.5f) * sx - 0.5f;
+    fx = fx < 0.f ? 0.f : fx;
+    const int x0 = (int)fx;
+    const int x1 = x0 + (x0 < bw - 1 ? 1 : 0);
+    const float lx = fx - (float)x0;
+    const float p00 = (float)r0[x0] / 255.0f, p01 = (float)r0[x1] / 255.0f;
+    const float p10 = (float)r1[x0] / 255.0f, p11 = (float)r1[x1] / 255.0f;
+    const float val = (1.0f - ly) * ((1.0f - lx) * p00 + lx * p01) + ly * ((1.0f - lx) * p10 + lx * p11);
+    v[e] = (val - mu) / sd;
+  }
+  const int gw = R / P;
+  const int py = y / P, iy = y % P;
+  const int x = xg * 4;
+  const int px = x / P, ix = x % P;             // P % 4 == 0 is checked by the launcher... (P = 16); P = 14 takes the 2-pixel path below
+  const long row = ((long)bt * gw + py) * gw + px;
+  const int col = (c * P + iy) * P + ix;
+  if (ix + 3 < P) {
+    uint32_t h0, h1, l0, l1;
+    split_bf16x2(v[0], v[1], h0, l0);
+    split_bf16x2(v[2], v[3], h1, l1);
+    if (((row * lda + col) & 3) == 0) {
+      *(u32x2_t*)(ahi + row * lda + col) = (u32x2_t){h0, h1};
+      if (alo) *(u32x2_t*)(alo + row * lda + col) = (u32x2_t){l0, l1};
+    } else {
+      *(uint32_t*)(ahi + row * lda + col) = h0;
+      *(uint32_t*)(ahi + row * lda + col + 2) = h1;
+      if (alo) {
+        *(uint32_t*)(alo + row * lda + col) = l0;
+        *(uint32_t*)(alo + row * lda + col + 2) = l1;
+      }
+    }
+  } else {
+    // the 4-pixel group straddles two patches (P = 14): element-wise
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int xe = x + e;
+      const long rw = ((long)bt * gw + py) * gw + xe / P;
+      const int cl = (c * P + iy) * P + xe % P;
+      bf16_t h, l;
+      split_bf16(v[e], h, l);
+      ahi[rw * lda + cl] = h;
+      if (alo) alo[rw * lda + cl] = l;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int egv_patch_gather_u8_aug(const uint8_t* video, int32_t BT, int32_t T, int32_t C, int32_t Hs, int32_t Ws,
+                                       int32_t R, int32_t P, const int32_t* boxes, const float* mean, const float* std,
+                                       egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream) {
+  if (!video || !boxes || !a_hi || !mean || !std || BT <= 0 || T <= 0 || BT % T != 0 || C <= 0 || C > 4) return EGV_ERR_ARG;
+  if (Hs <= 0 || Ws <= 0 || R <= 0 || P <= 0 || R % P != 0 || R % 4 != 0 || P % 2 != 0 || lda % 2 != 0) return EGV_ERR_ARG;
+  PatchNorm nrm{};
+  for (int c = 0; c < C; ++c) {
+    nrm.mean[c] = mean[c];
+    nrm.std[c] = std[c];
+  }
+  const long total = (long)BT * C * R * (R / 4);
+  EGV_LAUNCH(patch_gather_aug_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, video, BT, T, C, Hs,
+             Ws, R, P, boxes, a_hi, a_lo, (long)lda, nrm);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}

@@ -191,7 +191,9 @@ class _PatchTokensFn(torch.autograd.Function):
         B, T, n, P_, D, T_model = geom[:6]
         Pp = Precision.fwd_passes
         mean, std = geom[6] if len(geom) > 6 else (ops.IMAGENET_MEAN, ops.IMAGENET_STD)
-        a = ops.patch_gather(video.contiguous(), P_, Pp, mean, std)   # uint8 frames: /255 + Normalize inside the gather
+        aug = geom[7] if len(geom) > 7 else None
+        # uint8 frames: /255 + Normalize (and, with `aug`, the train transform's crop / resize / flip) inside the gather
+        a = ops.patch_gather(video.contiguous(), P_, Pp, mean, std, aug=aug)
         K = proj_w[0].numel()
         if a.cols == K:
             w_pl = wc.get(proj_w, need_t=False)[0]
@@ -376,16 +378,31 @@ class SpaceTimeTransformer(nn.Module):
     def no_weight_decay(self):
         return {'pos_embed', 'cls_token'}
 
+    def set_input_augmentation(self, boxes, out_res=None):
+        """Fuse the loader's train transform into the NEXT forward: `boxes` int32 [B, 5] (top, left, h, w, flip; see
+        egovlp_amd.data_loader.transforms.train_transform_params) select, per clip, the region of the decoded uint8 frames
+        that is resized to `out_res` (default: the model's img_size), flipped and normalised inside the patch gather.
+        One-shot: consumed by the next forward_features call."""
+        self._input_aug = (boxes.to(device=self.cls_token.device, dtype=torch.int32).contiguous(),
+                           int(out_res or self.patch_embed.img_size[0]))
+
     def forward_features(self, x):
         b, curr_frames, channels, Hh, Ww = x.shape
         assert curr_frames <= self.num_frames                                  # :74
         P_ = self.patch_embed.patch_size[0]
+        aug = getattr(self, "_input_aug", None)
+        self._input_aug = None
+        if aug is not None:
+            if x.dtype != torch.uint8:
+                raise ValueError("set_input_augmentation expects decoded uint8 frames")
+            Hh = Ww = aug[1]                                                   # the resized crop is what gets patched
         n = (Hh // P_) * (Ww // P_)
         if n != self.patches_per_frame:
             raise NotImplementedError("input resolution must match the positional embedding")
         # `input_norm` = (mean, std) of the loader's Normalize (data_loader/transforms.py:34-39); only used when the frames
         # arrive as decoded uint8 (then x / 255 and the normalisation are fused into the patch gather on the device)
-        geom = (b, curr_frames, n, P_, self.embed_dim, self.num_frames, getattr(self, "input_norm", (ops.IMAGENET_MEAN, ops.IMAGENET_STD)))
+        geom = (b, curr_frames, n, P_, self.embed_dim, self.num_frames,
+                getattr(self, "input_norm", (ops.IMAGENET_MEAN, ops.IMAGENET_STD)), aug)
         x = _PatchTokensFn.apply(x, geom, self._wc, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
                                  self.cls_token, self.pos_embed, self.temporal_embed)
         for blk in self.blocks:                                                # :325-328

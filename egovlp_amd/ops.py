@@ -340,11 +340,20 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)    # data_loader/transforms.py:34-35 defaults
 
 
-def patch_gather(video5d, P, passes, norm_mean=IMAGENET_MEAN, norm_std=IMAGENET_STD) -> Planes:
+def patch_gather(video5d, P, passes, norm_mean=IMAGENET_MEAN, norm_std=IMAGENET_STD, aug=None) -> Planes:
     """im2col planes [B*T*patches, K = C*P*P]; K is padded with zero columns to a multiple of 64 (the GEMM k-tile;
     588 -> 640 for ViT-L/14), `cols` of the returned planes is the PADDED width.  A uint8 `video5d` (decoded frames) is
-    scaled and normalised in the kernel (x / 255, then (x - mean) / std per channel) -- the loader's host transform."""
+    scaled and normalised in the kernel (x / 255, then (x - mean) / std per channel) -- the loader's host transform.
+    aug = (boxes int32 [B, 5] on the device: top, left, h, w, flip; out_res): the train transform (RandomResizedCrop +
+    RandomHorizontalFlip, data_loader/transforms.py:14-19) runs inside the gather on the decoded uint8 clip."""
     B, T, Cc, H, W = video5d.shape
+    if aug is not None:
+        boxes, R = aug
+        if video5d.dtype != torch.uint8:
+            raise ValueError("the fused train transform takes decoded uint8 frames")
+        if boxes.dtype != torch.int32 or tuple(boxes.shape) != (B, 5) or not boxes.is_cuda or not boxes.is_contiguous():
+            raise ValueError("aug boxes: contiguous int32 [B, 5] on the device (top, left, h, w, flip)")
+        H = W = int(R)
     rows = B * T * (H // P) * (W // P)
     K = Cc * P * P
     Kp = (K + 63) // 64 * 64
@@ -353,6 +362,11 @@ def patch_gather(video5d, P, passes, norm_mean=IMAGENET_MEAN, norm_std=IMAGENET_
         if len(norm_mean) != Cc or len(norm_std) != Cc:
             raise ValueError("patch_gather: one mean / std per channel")
         mean, std = (C.c_float * Cc)(*norm_mean), (C.c_float * Cc)(*norm_std)
+        if aug is not None:
+            check(_lib.lib().egv_patch_gather_u8_aug(_p(video5d), B * T, T, Cc, video5d.shape[3], video5d.shape[4], H, P,
+                                                     _p(aug[0]), mean, std, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
+                  "egv_patch_gather_u8_aug")
+            return pl
         check(_lib.lib().egv_patch_gather_u8(_p(video5d), B * T, Cc, H, W, P, mean, std, _p(pl.hi), _p(pl.lo), pl.ld,
                                              _stream()), "egv_patch_gather_u8")
         return pl

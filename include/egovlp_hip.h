@@ -119,6 +119,13 @@ int egv_patch_gather(const float* video, int32_t BT, int32_t C, int32_t H, int32
  * applied in the kernel, fp32, same operation order = bit-identical planes; `mean` / `std` are HOST arrays of C <= 4 floats. */
 int egv_patch_gather_u8(const uint8_t* video, int32_t BT, int32_t C, int32_t H, int32_t W, int32_t P,
                         const float* mean, const float* std, egv_bf16* a_hi, egv_bf16* a_lo, int64_t lda, void* stream);
+/* The same gather with the TRAIN transform of the loader fused in (data_loader/transforms.py:14-19): per clip a crop box
+ * (top, left, h, w) and a flip flag -- boxes[B][5] int32 on the DEVICE, the host's random draws -- select the region of the
+ * decoded uint8 clip [B*T, C, Hs, Ws] that is resized (bilinear, align_corners = False semantics, on x / 255) to R x R,
+ * mirrored when flip != 0, normalised and written as patch planes (R % P == 0, R % 4 == 0).  The box must lie inside the frame. */
+int egv_patch_gather_u8_aug(const uint8_t* video, int32_t BT, int32_t T, int32_t C, int32_t Hs, int32_t Ws, int32_t R,
+                            int32_t P, const int32_t* boxes, const float* mean, const float* std, egv_bf16* a_hi,
+                            egv_bf16* a_lo, int64_t lda, void* stream);
 /* x[b,0,:] = cls + pos[0]; x[b,1+f*n+i,:] = pe[(b*T+f)*n+i,:] + pos[1+i] + temporal[f]
  * (model/video_transformer.py:305-320; pos tiling by the MODEL's num_frames, sliced to T).          */
 int egv_assemble_tokens(const float* pe, const float* cls, const float* pos, const float* temporal,
