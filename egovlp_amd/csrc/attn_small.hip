@@ -214,6 +214,160 @@ __global__ __launch_bounds__(256) void attn_time_fwd_kernel(const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------- time fwd, 16-byte lanes
+// The same computation with a lane holding EIGHT channels: one wave = two neighbouring locations x four heads (8 lanes per
+// head), so every load / store moves 16 B per lane (1 KiB per wave instruction, two 512-B runs) and a head's dot product is
+// reduced with three DPP steps (quad xor 1, xor 2, row_half_mirror).  PMC on the 8-byte version: HBM traffic = algorithmic,
+// 80 % of wave cycles in s_waitcnt at 2.9 TB/s (profiles/r02_i_pmc_attention.txt) -- half as many, twice as wide requests.
+__device__ __forceinline__ float row8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+__device__ __forceinline__ void ldp8(const bf16_t* __restrict__ ph, const bf16_t* __restrict__ pl, long off, float (&x)[8]) {
+  const u32x4_t a = *(const u32x4_t*)(ph + off);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x[2 * e] = __uint_as_float(a[e] << 16);
+    x[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+  }
+  if (pl) {
+    const u32x4_t b = *(const u32x4_t*)(pl + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[2 * e] += __uint_as_float(b[e] << 16);
+      x[2 * e + 1] += __uint_as_float(b[e] & 0xffff0000u);
+    }
+  }
+}
+__device__ __forceinline__ void stp8(bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long off, const float (&x)[8]) {
+  uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+  split_bf16x2(x[0], x[1], h0, l0);
+  split_bf16x2(x[2], x[3], h1, l1);
+  split_bf16x2(x[4], x[5], h2, l2);
+  split_bf16x2(x[6], x[7], h3, l3);
+  *(u32x4_t*)(ph + off) = (u32x4_t){h0, h1, h2, h3};
+  if (pl) *(u32x4_t*)(pl + off) = (u32x4_t){l0, l1, l2, l3};
+}
+
+template <int TMAX>
+__global__ __launch_bounds__(256) void attn_time_fwd8_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
+                                                             int B, int T, int n, int H, bf16_t* __restrict__ out_hi,
+                                                             bf16_t* __restrict__ out_lo, float* __restrict__ lse,
+                                                             float* __restrict__ cls_ws) {
+  constexpr int CPL = 8;
+  const int lane = threadIdx.x & 63;
+  const int HQ = H / 4;
+  const int NPAIR = (n + 1) / 2;
+  const long gid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gid >= (long)B * NPAIR * HQ) return;
+  const int hq = (int)(gid % HQ);
+  const long r = gid / HQ;
+  const int ip = (int)(r % NPAIR);
+  const int b = (int)(r / NPAIR);
+  const int i_raw = 2 * ip + (lane >> 5);
+  const bool live = i_raw < n;                 // odd n: the second half of the last pair repeats location n - 1, stores off
+  const int i = live ? i_raw : n - 1;
+  const int head = hq * 4 + ((lane & 31) >> 3);
+  const int ch = (lane & 7) * CPL;
+  const long S = 1 + (long)T * n;
+  const long HD = (long)H * D;
+  const long ts = 3 * HD;
+  const long base = (long)b * S * ts + (long)head * D + ch;   // token 0, q part
+  float qc[CPL], kc[CPL], vc[CPL];
+  ldp8(qh, ql, base, qc);
+  ldp8(qh, ql, base + HD, kc);
+  ldp8(qh, ql, base + 2 * HD, vc);
+  float q[TMAX][CPL], k[TMAX][CPL], v[TMAX][CPL];
+#pragma unroll
+  for (int f = 0; f < TMAX; ++f) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) q[f][c] = k[f][c] = v[f][c] = 0.f;
+    if (f < T) {
+      const long p = base + (1 + (long)f * n + i) * ts;
+      ldp8(qh, ql, p, q[f]);
+      ldp8(qh, ql, p + HD, k[f]);
+      ldp8(qh, ql, p + 2 * HD, v[f]);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < TMAX; ++f) {
+    if (f < T) {
+      float s[TMAX + 1];
+      s[0] = row8_sum(dotc<CPL>(q[f], kc)) * 0.125f;
+      float m = s[0];
+#pragma unroll
+      for (int j = 0; j < TMAX; ++j) {
+        s[j + 1] = -3e38f;
+        if (j < T) {
+          s[j + 1] = row8_sum(dotc<CPL>(q[f], k[j])) * 0.125f;
+          m = fmaxf(m, s[j + 1]);
+        }
+      }
+      const float p0 = __expf(s[0] - m);
+      float l = p0;
+      float o[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) o[c] = p0 * vc[c];
+#pragma unroll
+      for (int j = 0; j < TMAX; ++j) {
+        if (j < T) {
+          const float pj = __expf(s[j + 1] - m);
+          l += pj;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) o[c] += pj * v[j][c];
+        }
+      }
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) o[c] *= inv;
+      const long tok = (long)b * S + 1 + (long)f * n + i;
+      if (live) {
+        stp8(out_hi, out_lo, tok * HD + (long)head * D + ch, o);
+        if ((lane & 7) == 0 && lse) lse[((long)b * H + head) * S + 1 + (long)f * n + i] = m + __logf(l);
+      }
+    }
+  }
+  // the clip's CLS query against this location's T keys (+ the CLS key, counted in location-group 0 only)
+  {
+    float s[TMAX + 1];
+    s[0] = (i == 0) ? row8_sum(dotc<CPL>(qc, kc)) * 0.125f : -1e30f;
+    float m = s[0];
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+      s[j + 1] = -3e38f;
+      if (j < T) {
+        s[j + 1] = row8_sum(dotc<CPL>(qc, k[j])) * 0.125f;
+        m = fmaxf(m, s[j + 1]);
+      }
+    }
+    const float p0 = (i == 0) ? __expf(s[0] - m) : 0.f;
+    float l = p0;
+    float o[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) o[c] = p0 * vc[c];
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+      if (j < T) {
+        const float pj = __expf(s[j + 1] - m);
+        l += pj;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) o[c] += pj * v[j][c];
+      }
+    }
+    if (live) {
+      float* w = cls_ws + (((long)b * H + head) * n + i) * 68;
+      *(f32x4_t*)(w + ch) = (f32x4_t){o[0], o[1], o[2], o[3]};
+      *(f32x4_t*)(w + ch + 4) = (f32x4_t){o[4], o[5], o[6], o[7]};
+      if ((lane & 7) == 0) {
+        w[64] = m;
+        w[65] = l;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------- time bwd
 // one workgroup = (b, head group, 16 consecutive locations); each wave walks 4 locations.  Per location the T keys /
 // values and their gradient accumulators live in registers and ONE rolled loop walks the T patch queries plus, as
@@ -446,7 +600,17 @@ __global__ __launch_bounds__(64) void attn_cls_finish_kernel(const float* __rest
 template <int TMAX>
 int launch_time_fwd(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
                     float* ws, hipStream_t s) {
-  if (H % 4 == 0 && TMAX <= 4) {   // 4 heads per wave while the per-lane q/k/v arrays still fit the register file
+  bool done = false;
+  if constexpr (TMAX <= 4) {   // 2 locations x 4 heads per wave, 16 B per lane (the per-lane q/k/v arrays fit up to T = 4)
+    if (H % 4 == 0) {
+      const long ngroups = (long)B * ((n + 1) / 2) * (H / 4);
+      EGV_LAUNCH((attn_time_fwd8_kernel<TMAX>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H, oh,
+                 ol, lse, ws);
+      done = true;
+    }
+  }
+  if (done) {
+  } else if (H % 4 == 0 && TMAX <= 4) {
     const long ngroups = (long)B * n * (H / 4);
     EGV_LAUNCH((attn_time_fwd_kernel<TMAX, 4>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
                oh, ol, lse, ws);

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egovlp_amd import ops
 B, T, n, H = 32, 4, 196, 12
 S = 1 + T * n
