@@ -75,8 +75,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // per GEMM with the matrix pipe idle, and the SAME exponential e^{-x^2/2} serves the Gaussian pdf of the derivative.
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
   const float ax = fabsf(x);
-  const float e = __expf(-0.5f * x * x);                      // e^{-u^2}, u = x / sqrt(2)
-  const float t = __frcp_rn(1.0f + 0.3275911f * 0.70710678118654752f * ax);
+  // raw v_exp_f32 / v_rcp_f32 (1 ulp): __expf adds a denormal-range rescue (compare + two selects) and __frcp_rn expands to
+  // the IEEE division sequence (~10 VALU ops) -- together a third of the GELU epilogue's instructions, for accuracy the
+  // 1.5e-7 approximation cannot use
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);      // e^{-x^2/2} = e^{-u^2}, u = x / sqrt(2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float half = 0.5f * poly * e;                         // 0.5 * erfc(|u|): no cancellation in the negative tail
   cdf = (x < 0.f) ? half : 1.0f - half;

@@ -138,15 +138,20 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
   if (EPI == EPI_GENERIC && p.alpha != 1.0f) v *= p.alpha;
   if (EPI != EPI_GELU_BWD && p.bias) v += *(const f32x4_t*)(p.bias + n);
   if (EPI == EPI_GELU || (EPI == EPI_GENERIC && p.act == EGV_ACT_GELU)) {
+    f32x4_t s = v;                    // what is saved for backward: the pre-activation, or (aux_bf16 == 2) gelu'(it)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float cdf, pdf;
+      gelu_parts(v[e], cdf, pdf);
+      if (p.aux_bf16 == 2) s[e] = cdf + v[e] * pdf;
+      v[e] *= cdf;
+    }
     if (p.aux_out) {
       if (p.aux_bf16)
-        *(u32x2_t*)((bf16_t*)p.aux_out + (long)m * p.ldaux + n) =
-            (u32x2_t){pack2(f32_to_bf16(v[0]), f32_to_bf16(v[1])), pack2(f32_to_bf16(v[2]), f32_to_bf16(v[3]))};
+        *(u32x2_t*)((bf16_t*)p.aux_out + (long)m * p.ldaux + n) = (u32x2_t){f32x2_to_bf16x2(s[0], s[1]), f32x2_to_bf16x2(s[2], s[3])};
       else
-        *(f32x4_t*)(p.aux_out + (long)m * p.ldaux + n) = v;
+        *(f32x4_t*)(p.aux_out + (long)m * p.ldaux + n) = s;
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
   } else if (EPI == EPI_GELU_BWD || (EPI == EPI_GENERIC && p.act == EGV_ACT_GELU_BWD)) {
     f32x4_t zv;
     if (p.aux_bf16) {
@@ -157,7 +162,7 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
       zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(zv[e]);
+    for (int e = 0; e < 4; ++e) v[e] *= (p.aux_bf16 == 2) ? zv[e] : gelu_grad_f(zv[e]);
   } else if (EPI == EPI_GENERIC && p.act == EGV_ACT_RELU_BWD) {
     const f32x4_t zv = *(const f32x4_t*)(p.aux_in + (long)m * p.ldaux + n);
 #pragma unroll
@@ -956,25 +961,46 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         bf16_t* dz = nullptr;
         if (EPI == EPI_GELU && p.aux_out) dz = (bf16_t*)p.aux_out + (long)(mw + rs16) * p.ldaux + n;
         const long ldz4 = 4 * p.ldaux;
+        const bool saved_grad = p.aux_bf16 == 2;
         auto row16 = [&](const int it, const f32x4_t zin) {
           const unsigned a0 = (r16 + it * 2048) ^ ((it & 1) << 6);
           f32x4_t v0 = *(const f32x4_t*)(smem + a0) + b0, v1 = *(const f32x4_t*)(smem + (a0 ^ 16u)) + b1;
           if constexpr (EPI == EPI_GELU) {
+            // one evaluation of (Phi, phi) gives both the activation and -- saved in place of the pre-activation when the
+            // caller asks for it (aux_bf16 == 2) -- its derivative, so that the fc2-dgrad epilogue is a plain multiply
+            f32x4_t s0 = v0, s1 = v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float c0, p0, c1, p1;
+              gelu_parts(v0[e], c0, p0);
+              gelu_parts(v1[e], c1, p1);
+              if (saved_grad) { s0[e] = c0 + v0[e] * p0; s1[e] = c1 + v1[e] * p1; }
+              v0[e] *= c0;
+              v1[e] *= c1;
+            }
             if (dz) {
-              *(u32x4_t*)dz = (u32x4_t){f32x2_to_bf16x2(v0[0], v0[1]), f32x2_to_bf16x2(v0[2], v0[3]),
-                                        f32x2_to_bf16x2(v1[0], v1[1]), f32x2_to_bf16x2(v1[2], v1[3])};
+              *(u32x4_t*)dz = (u32x4_t){f32x2_to_bf16x2(s0[0], s0[1]), f32x2_to_bf16x2(s0[2], s0[3]),
+                                        f32x2_to_bf16x2(s1[0], s1[1]), f32x2_to_bf16x2(s1[2], s1[3])};
               dz += ldz4;
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = gelu_f(v0[e]); v1[e] = gelu_f(v1[e]); }
           } else if constexpr (EPI == EPI_GELU_BWD) {
             const u32x4_t zb = __builtin_bit_cast(u32x4_t, zin);
+            if (saved_grad) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              v0[2 * e] *= gelu_grad_f(__uint_as_float(zb[e] << 16));
-              v0[2 * e + 1] *= gelu_grad_f(__uint_as_float(zb[e] & 0xffff0000u));
-              v1[2 * e] *= gelu_grad_f(__uint_as_float(zb[2 + e] << 16));
-              v1[2 * e + 1] *= gelu_grad_f(__uint_as_float(zb[2 + e] & 0xffff0000u));
+              for (int e = 0; e < 2; ++e) {
+                v0[2 * e] *= __uint_as_float(zb[e] << 16);
+                v0[2 * e + 1] *= __uint_as_float(zb[e] & 0xffff0000u);
+                v1[2 * e] *= __uint_as_float(zb[2 + e] << 16);
+                v1[2 * e + 1] *= __uint_as_float(zb[2 + e] & 0xffff0000u);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                v0[2 * e] *= gelu_grad_f(__uint_as_float(zb[e] << 16));
+                v0[2 * e + 1] *= gelu_grad_f(__uint_as_float(zb[e] & 0xffff0000u));
+                v1[2 * e] *= gelu_grad_f(__uint_as_float(zb[2 + e] << 16));
+                v1[2 * e + 1] *= gelu_grad_f(__uint_as_float(zb[2 + e] & 0xffff0000u));
+              }
             }
           }
           uint32_t h0, h1, h2, h3, l0, l1, l2, l3;

@@ -123,11 +123,13 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P)
         Hd = fc1_w.shape[0]
         h = ops.empty_planes(M, Hd, P, dev)
-        # pre-activation saved for GELU' in backward: bf16 when backward runs single-pass bf16 anyway (half the bytes of
-        # fc1's epilogue write and of fc2-dgrad's epilogue read); fp32 in the all-bf16x3 parity mode
+        # saved for backward: the fp32 pre-activation z in the all-bf16x3 parity mode; when backward runs single-pass bf16
+        # anyway, gelu'(z) itself as bf16 -- the epilogue has Phi(z) and phi(z) in registers, the buffer is half the bytes,
+        # and the fc2-dgrad epilogue becomes one multiply instead of a second erf evaluation over 77 M elements
         z_dtype = torch.bfloat16 if (Precision.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D)) else torch.float32
         z = torch.empty((M, Hd), dtype=z_dtype, device=dev) if train else None
-        ops.gemm_nt(n2, W(fc1_w), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h)
+        ops.gemm_nt(n2, W(fc1_w), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
+                    aux_is_grad=z is not None and z_dtype == torch.bfloat16)
         out = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(h, W(fc2_w), passes=P, bias=fc2_b, residual=sr, out_f32=out)
 
@@ -158,7 +160,8 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         G_pl = _take_grad_planes(g_out, G, Pb)
         Hd = fc1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
-        ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
+        ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D,
+                    aux_is_grad=z.dtype == torch.bfloat16)
         _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False)
         d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, dx_planes=_LN_DY_PLANES)   # LayerNorm backward reads planes
         # d_sr = G + LN2'(d_n2)

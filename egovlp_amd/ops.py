@@ -130,8 +130,9 @@ def pad32(n):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_NONE, aux_in=None, aux_out=None,
-            out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=None, K=None):
-    """C[M,N] = A[M,K] . B[N,K]^T with the fused epilogue of egv_gemm_nt.  A.rows = M, B.rows = N."""
+            out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=None, K=None, aux_is_grad=False):
+    """C[M,N] = A[M,K] . B[N,K]^T with the fused epilogue of egv_gemm_nt.  A.rows = M, B.rows = N.
+    `aux_is_grad` (bf16 aux only): the GELU epilogue saves gelu'(z) instead of z and the GELU' epilogue multiplies by it."""
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
     if ksplit is None:
@@ -146,6 +147,10 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     aux = aux_in if aux_in is not None else aux_out
     d.aux_in, d.aux_out, d.ldaux = _p(aux_in), _p(aux_out), (aux.stride(0) if aux is not None else 0)
     d.aux_bf16 = int(aux is not None and aux.dtype == torch.bfloat16)
+    if aux_is_grad:
+        if not d.aux_bf16:
+            raise ValueError("aux_is_grad needs a bf16 aux buffer")
+        d.aux_bf16 = 2
     d.out_f32, d.ldo = _p(out_f32), (out_f32.stride(0) if out_f32 is not None else 0)
     if out_planes is not None:
         d.out_hi, d.out_lo, d.ldoh = _p(out_planes.hi), _p(out_planes.lo), out_planes.ld

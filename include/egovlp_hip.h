@@ -58,6 +58,8 @@ typedef struct egv_gemm_desc {
   int32_t trans;    /* (see below) */
   int32_t aux_bf16; /* != 0: aux_in / aux_out are bf16 [M, ldaux] instead of fp32 (the GELU pre-activation saved by fc1 for
                        fc2's dgrad: half the bytes when backward runs single-pass bf16 anyway).  Big-tile kernel only.
+                       2: the bf16 buffer holds gelu'(pre-activation) itself -- EGV_ACT_GELU stores the derivative (it has
+                       Phi and phi in registers) and EGV_ACT_GELU_BWD multiplies by the stored value, no second erf.
                        trans = 0: A[M,K], B[N,K] (contraction index contiguous).  1 ("TN", wgrad): A is stored [K, lda] with
                        its M rows as COLUMNS and B is stored [K, ldb] with N columns, C[m,n] = sum_k A[k,m] B[k,n] --
                        no transposed copy of either operand is ever made (CDNA4 transpose-read from LDS).  Requires

@@ -184,6 +184,20 @@ def test_gemm_big_gelu_epilogues_bf16_aux(ops):
         zd = z.float().double().cpu().requires_grad_(True)
         F.gelu(zd).sum().backward()
         assert rel(out, (ref - bias) * zd.grad) < 5e-6
+    # the benchmarked flavour: fc1 saves gelu'(z) as bf16 (aux_is_grad), fc2-dgrad multiplies by the saved value; plane outputs
+    gp = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    h = ops.empty_planes(M, N, 3, "cuda")
+    ops.gemm_nt(A, Bm, passes=1, bias=bias.cuda(), act=ops.ACT_GELU, aux_out=gp, out_planes=h, aux_is_grad=True)
+    zd = ref.clone().requires_grad_(True)
+    F.gelu(zd).sum().backward()
+    assert rel(h.float(), F.gelu(ref)) < 5e-6
+    assert rel(gp.float(), zd.grad) < 3e-3                                         # bf16 rounding of gelu'
+    dz = ops.empty_planes(M, N, 1, "cuda")
+    ops.gemm_nt(A, Bm, passes=1, act=ops.ACT_GELU_BWD, aux_in=gp, out_planes=dz, aux_is_grad=True)
+    assert rel(dz.float(), (ref - bias) * gp.float().double().cpu()) < 3e-3      # = product * saved value, rounded to the bf16 plane
+    out = torch.empty(M, N, device="cuda")                                          # slow path (fp32 output) agrees
+    ops.gemm_nt(A, Bm, passes=1, act=ops.ACT_GELU_BWD, aux_in=gp, out_f32=out, aux_is_grad=True)
+    assert rel(out, (ref - bias) * gp.float().double().cpu()) < 5e-6
 
 
 @pytest.mark.parametrize("passes", [3, 1])

@@ -55,9 +55,9 @@ def cases(P, Pb):
     dx_pl = ops.empty_planes(M, D, Pb, dev)
     nt("qkv   fwd", M, H3, D, P, kw=lambda bias: dict(bias=bias, out_planes=qkv_pl))
     nt("proj  fwd", M, D, D, P, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
-    nt("fc1   fwd", M, HD, D, P, kw=lambda bias: dict(bias=bias, act=ops.ACT_GELU, aux_out=z, out_planes=h_pl))
+    nt("fc1   fwd", M, HD, D, P, kw=lambda bias: dict(bias=bias, act=ops.ACT_GELU, aux_out=z, out_planes=h_pl, aux_is_grad=Pb == 1))
     nt("fc2   fwd", M, D, HD, P, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
-    nt("fc2 dgrad", M, HD, D, Pb, kw=lambda bias: dict(act=ops.ACT_GELU_BWD, aux_in=zin, out_planes=dz_pl))
+    nt("fc2 dgrad", M, HD, D, Pb, kw=lambda bias: dict(act=ops.ACT_GELU_BWD, aux_in=zin, out_planes=dz_pl, aux_is_grad=Pb == 1))
     nt("fc1 dgrad", M, D, HD, Pb, kw=lambda bias: dict(out_f32=o32))
     nt("proj dgrad", M, D, D, Pb, kw=lambda bias: dict(out_planes=dx_pl))
     nt("qkv dgrad", M, D, H3, Pb, kw=lambda bias: dict(out_f32=o32))
