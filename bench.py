@@ -123,6 +123,10 @@ def main():
                     "egovlp_amd.dist.Bf16GradSync (A/B of the gradient exchange)")
     ap.add_argument("--gemm-grid", type=int, default=0, help="persistent workgroups of the big GEMM (default: 256 at N=1, "
                     "248 at N>1 so that the overlapped RCCL kernels find free CUs)")
+    ap.add_argument("--wgrad-side", type=int, default=int(os.environ.get("EGV_WGRAD_SIDE", "0")),
+                    help="1: weight-gradient GEMMs on a second HIP stream (egovlp_amd.ops.side_stream)")
+    ap.add_argument("--text-side", type=int, default=int(os.environ.get("EGV_TEXT_SIDE", "1")),
+                    help="1 (default): the DistilBERT tower on a second HIP stream under the video tower; 0: one stream")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL process group, DDP wrapper and the fused all-gather even at world size 1 "
                          "(smoke test of the N>1 code path on a 1-GPU box)")
@@ -171,6 +175,8 @@ def main():
     from egovlp_amd import _lib
     grid = args.gemm_grid or (248 if world > 1 else 256)
     _lib.lib().egv_gemm_set_grid(grid)
+    ops.WGRAD_SIDE_STREAM = bool(args.wgrad_side)
+    ops.TEXT_SIDE_STREAM = bool(args.text_side)
     opt = AdamW(model.parameters(), lr=3e-5)
     loss_fn = EgoNCE()
     batch = synth_batch(B, T=T, L=L, seed=1234, rank=rank)
@@ -205,11 +211,14 @@ def main():
     roof = None
     if not args.no_kernel_timing:
         ops.KERNEL_TIMER = ops.KernelTimer()
+        side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False    # per-launch durations: one kernel at a time
+        tside, ops.TEXT_SIDE_STREAM = ops.TEXT_SIDE_STREAM, False
         for _ in range(2):
             egoclip_step(net, loss_fn, opt, data, world, rank, grad_sync=grad_sync)
         torch.cuda.synchronize()
         kt = ops.KERNEL_TIMER.summary()
         ops.KERNEL_TIMER = None
+        ops.WGRAD_SIDE_STREAM, ops.TEXT_SIDE_STREAM = side, tside
         g = kt["egv_gemm_nt"]
         ach = g["flops"] / g["seconds"] / 1e12
         shapes = sorted(g["shapes"].items(), key=lambda kv: -kv[1]["seconds"])
@@ -250,7 +259,8 @@ def main():
         "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
                    "parallelism": f"dp{world}", "precision": "/".join(ops.Precision.name()),
-                   "text_dropout": args.text_dropout},
+                   "text_dropout": args.text_dropout,
+                   "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side)}},
         "loss": round(loss_val, 5),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
     }

@@ -126,6 +126,9 @@ class Bf16GradSync:
             self._launch(b)
 
     def _launch(self, b: _Bucket):
+        if self.pack_fn is _hip_pack:
+            from . import ops
+            ops.join_streams_for_gradient_hook()      # gradients are produced on up to three streams (ops.side_stream, text tower)
         grads = [p.grad for p in b.params]
         for g in grads:
             if g is None or g.dtype != torch.float32 or not g.is_contiguous():

@@ -143,8 +143,23 @@ class FrozenInTime(BaseModel):
     def forward(self, data, video_only=False, return_embeds=True):
         if video_only:
             return self.compute_video(data['video'])
-        text_embeddings = self.compute_text(data['text'])
-        video_embeddings = self.compute_video(data['video'])
+        if ops.TEXT_SIDE_STREAM and data['video'].is_cuda:
+            # the two towers are independent until the loss: DistilBERT (M = B*L = 1024 token rows, latency-bound launches
+            # that fill a fraction of the chip) runs on a second HIP stream under the video tower.  autograd replays each
+            # tower's backward on the stream its forward ran on and orders them against the loss by itself.
+            self._wc.refresh()
+            main, side = torch.cuda.current_stream(), ops.text_stream()
+            side.wait_stream(main)
+            for t in data['text'].values():
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                text_embeddings = self.compute_text(data['text'])
+            video_embeddings = self.compute_video(data['video'])
+            main.wait_stream(side)
+            text_embeddings.record_stream(main)
+        else:
+            text_embeddings = self.compute_text(data['text'])
+            video_embeddings = self.compute_video(data['video'])
         if return_embeds:
             return text_embeddings, video_embeddings
         return sim_matrix(text_embeddings, video_embeddings)

@@ -41,8 +41,15 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False):
     M, K = x_pl.rows, x_pl.cols
     N = dy.cols
     dev = x_pl.hi.device
-    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-    db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True)
+    # off the critical path: fills the CUs the dgrad chain leaves idle (ops.side_stream); the text tower's own backward is
+    # already off the video tower's stream (ops.TEXT_SIDE_STREAM) and keeps its small wgrads where they are
+    if ops.WGRAD_SIDE_STREAM and not ops.on_text_stream():
+        with ops.side_stream(dy.hi, dy.lo, x_pl.hi, x_pl.lo):
+            dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True)
+    else:
+        dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+        db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True)
     dx = None
     if need_dx and dx_planes:      # dx feeds a kernel that consumes planes (attention backward): no fp32 copy at all
         dx = ops.empty_planes(M, K, Pb, dev)

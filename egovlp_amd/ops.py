@@ -45,6 +45,87 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- side stream for work that is OFF the critical path of backward (the weight gradients) --------------------------------
+# dW = dY^T X is needed only by the optimizer, while the dgrad chain of backward waits for nothing but dX.  With
+# WGRAD_SIDE_STREAM on, every wgrad GEMM (and its split-K reduce) is enqueued on a second HIP stream behind an event of the
+# main stream: its persistent workgroups fill the CUs that the main stream's kernels leave idle (last partial round of a
+# tile grid, drain tails, the launch gaps of the small kernels).  The main stream re-joins at the end of backward (an autograd
+# engine callback queued by the first wgrad of the pass) and before any gradient hook reads a wgrad (`join_side_stream`).
+WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "0") == "1"
+_SIDE = {"stream": None, "main": None, "dirty": False, "queued": False}
+
+
+# The text tower on its own stream under the video tower (model/model.py FrozenInTime.forward).
+TEXT_SIDE_STREAM = os.environ.get("EGV_TEXT_SIDE", "1") == "1"
+_TEXT = {"stream": None}
+
+
+def text_stream():
+    if _TEXT["stream"] is None:
+        _TEXT["stream"] = torch.cuda.Stream()
+    return _TEXT["stream"]
+
+
+def on_text_stream():
+    return _TEXT["stream"] is not None and torch.cuda.current_stream() == _TEXT["stream"]
+
+
+class side_stream:
+    """`with side_stream(*inputs):` -- enqueue the body on the side stream, ordered after everything already enqueued on the
+    current stream; `inputs` are the tensors the body reads (kept alive for the side stream by the caching allocator)."""
+
+    def __init__(self, *inputs):
+        self.inputs = [t for t in inputs if t is not None]
+
+    def __enter__(self):
+        main = torch.cuda.current_stream()
+        if _SIDE["stream"] is None:
+            _SIDE["stream"] = torch.cuda.Stream()
+        side = _SIDE["stream"]
+        side.wait_stream(main)
+        for t in self.inputs:
+            t.record_stream(side)
+        _SIDE["main"], _SIDE["dirty"] = main, True
+        if not _SIDE["queued"]:
+            try:   # inside a backward pass: join when the pass ends, whoever called backward()
+                torch.autograd.Variable._execution_engine.queue_callback(_join_callback)
+                _SIDE["queued"] = True
+            except RuntimeError:
+                pass
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return side
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def _join_callback():
+    _SIDE["queued"] = False
+    join_side_stream()
+
+
+def join_side_stream():
+    """Make the main stream (the one the side work was forked from) wait for everything enqueued on the side stream."""
+    if _SIDE["dirty"]:
+        _SIDE["main"].wait_stream(_SIDE["stream"])
+        cur = torch.cuda.current_stream()
+        if cur != _SIDE["main"]:
+            cur.wait_stream(_SIDE["stream"])
+        _SIDE["dirty"] = False
+
+
+def join_streams_for_gradient_hook():
+    """Gradient hooks run when a gradient has been ENQUEUED, on the stream of the node that produced it; a hook that reads
+    gradients of several parameters (a bucket of the data-parallel exchange) must first order its stream behind the other
+    streams gradients are produced on: the wgrad side stream and the text tower's stream."""
+    join_side_stream()
+    if _TEXT["stream"] is not None:
+        cur = torch.cuda.current_stream()
+        if cur != _TEXT["stream"]:
+            cur.wait_stream(_TEXT["stream"])
+
+
 class KernelTimer:
     """Opt-in HIP-event timing of individual C-ABI calls (bench.py's roofline leg).  Events are recorded on
     the stream the kernel is launched on, immediately before and after the enqueue; `key` groups the launches of one

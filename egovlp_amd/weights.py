@@ -69,6 +69,12 @@ class WeightCache:
         for ent, ver in done:
             ent.ver = ver
 
+    def refresh(self):
+        """Bring every cached plane set up to date NOW, on the current stream (callers that are about to fork work onto a
+        second stream do this first, so that no stream finds a stale entry and refreshes the cache under the other one)."""
+        if any(ent.pl is not None and ent.ver != ent.version() and ent.shapes_ok() for ent in self._c.values()):
+            self._refresh_all()
+
     def _get(self, params, need_t: bool):
         key = tuple(id(p) for p in params)
         ent = self._c.get(key)

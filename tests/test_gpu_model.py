@@ -435,3 +435,37 @@ def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T
         r = rel(params[w].grad, sdo[w].grad)
         print("  %s grad %-45s rel %.2e" % (name, w, r))
         assert r < 3 * PARITY, (w, r)
+
+
+@pytest.mark.parametrize("which", ["wgrad", "text", "both"])
+def test_weight_gradients_on_the_side_stream_are_the_same_gradients(full, which):
+    """ops.WGRAD_SIDE_STREAM: every wgrad GEMM runs on a second HIP stream behind an event of the main stream and the main
+    stream re-joins at the end of backward (autograd engine callback).  Same kernels, same inputs -> the same gradients up to
+    the run-to-run noise of the few fp32-atomic reductions upstream (LayerNorm dgamma, CLS-token gradients: ~1e-6); a missing
+    join or a recycled input buffer would show up as an O(1) error."""
+    from egovlp_amd import ops
+    m, _ = full
+    m.train()
+    batch = to_dev(synth_batch(4, T=4, L=32, seed=77))
+    from egovlp_amd.model.loss import EgoNCE
+    lossf = EgoNCE()
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        te, ve = m(batch)
+        lossf.fused(te, ve, batch["noun_vec"], batch["verb_vec"]).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    try:
+        ref = grads()
+        ops.WGRAD_SIDE_STREAM = which in ("wgrad", "both")
+        ops.TEXT_SIDE_STREAM = which in ("text", "both")      # DistilBERT tower on its own stream under the video tower
+        for _ in range(3):                       # repeated: a missing join shows up as a stale / half-written gradient
+            got = grads()
+            worst = max((rel(got[k], ref[k]), k) for k in ref)
+            print("side streams (%s): worst gradient rel %.2e (%s)" % ((which,) + worst))
+            assert worst[0] < 1e-4, worst
+    finally:
+        ops.WGRAD_SIDE_STREAM = ops.TEXT_SIDE_STREAM = False
+        m.eval()
