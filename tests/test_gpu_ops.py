@@ -449,7 +449,13 @@ def test_fused_train_transform_matches_the_host_transform(P, R):
     want = ops.patch_gather(host.cuda(), P, 3).float().cpu()
     got = ops.patch_gather(u8.cuda(), P, 3, aug=(boxes.cuda(), R)).float().cpu()
     assert got.shape == want.shape
-    assert float((got - want).abs().max()) < 2e-5, float((got - want).abs().max())
+    err = (got - want).abs()
+    # the two pixel pipelines agree to ~2e-6 before the split into bf16 planes; after it an element whose value sits on a
+    # rounding boundary of the hi plane can come out one lo-plane step apart (2^-16 .. 2^-14 at |x| <= 2.64), and WHICH elements
+    # do depends on the host CPU's bilinear kernel (F.interpolate is the reference here): bound the bulk tightly, the tail loosely
+    n_loose = int((err > 2e-5).sum())
+    print("fused train transform P=%d: max abs err %.2e, %d of %d elements above 2e-5" % (P, float(err.max()), n_loose, err.numel()))
+    assert float(err.max()) < 1.3e-4 and n_loose <= err.numel() // 10000, (float(err.max()), n_loose)
     # hi-only planes equal bf16 rounding of the same values
     got1 = ops.patch_gather(u8.cuda(), P, 1, aug=(boxes.cuda(), R))
     assert got1.lo is None and float((got1.float().cpu() - want).abs().max()) < 2e-2
