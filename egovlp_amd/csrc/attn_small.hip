@@ -251,7 +251,8 @@ __device__ __forceinline__ void stp8(bf16_t* __restrict__ ph, bf16_t* __restrict
   if (pl) *(u32x4_t*)(pl + off) = (u32x4_t){l0, l1, l2, l3};
 }
 
-template <int TMAX>
+// DBG (diagnostics build only): 1 = everything but the output stores, 2 = the loads alone
+template <int TMAX, int DBG = 0>
 __global__ __launch_bounds__(256) void attn_time_fwd8_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
                                                              int B, int T, int n, int H, bf16_t* __restrict__ out_hi,
                                                              bf16_t* __restrict__ out_lo, float* __restrict__ lse,
@@ -291,6 +292,16 @@ __global__ __launch_bounds__(256) void attn_time_fwd8_kernel(const bf16_t* __res
       ldp8(qh, ql, p + 2 * HD, v[f]);
     }
   }
+  if (DBG == 2) {
+#pragma unroll
+    for (int f = 0; f < TMAX; ++f)
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) asm volatile("" ::"v"(q[f][c]), "v"(k[f][c]), "v"(v[f][c]));
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) asm volatile("" ::"v"(qc[c]), "v"(kc[c]), "v"(vc[c]));
+    return;
+  }
+  const bool store_on = (DBG != 1) || B < 0;
 #pragma unroll
   for (int f = 0; f < TMAX; ++f) {
     if (f < T) {
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_time_fwd8_kernel(const bf16_t* __res
 #pragma unroll
       for (int c = 0; c < CPL; ++c) o[c] *= inv;
       const long tok = (long)b * S + 1 + (long)f * n + i;
-      if (live) {
+      if (live && store_on) {
         stp8(out_hi, out_lo, tok * HD + (long)head * D + ch, o);
         if ((lane & 7) == 0 && lse) lse[((long)b * H + head) * S + 1 + (long)f * n + i] = m + __logf(l);
       }
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256) void attn_time_fwd8_kernel(const bf16_t* __res
         for (int c = 0; c < CPL; ++c) o[c] += pj * v[j][c];
       }
     }
-    if (live) {
+    if (live && store_on) {
       float* w = cls_ws + (((long)b * H + head) * n + i) * 68;
       *(f32x4_t*)(w + ch) = (f32x4_t){o[0], o[1], o[2], o[3]};
       *(f32x4_t*)(w + ch + 4) = (f32x4_t){o[4], o[5], o[6], o[7]};
@@ -604,6 +615,16 @@ int launch_time_fwd(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int
   if constexpr (TMAX <= 4) {   // 2 locations x 4 heads per wave, 16 B per lane (the per-lane q/k/v arrays fit up to T = 4)
     if (H % 4 == 0) {
       const long ngroups = (long)B * ((n + 1) / 2) * (H / 4);
+#ifdef EGV_DIAG
+      static const int dbg = getenv("EGV_TIME_DBG") ? atoi(getenv("EGV_TIME_DBG")) : 0;
+      if (dbg == 1)
+        EGV_LAUNCH((attn_time_fwd8_kernel<TMAX, 1>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
+                   oh, ol, lse, ws);
+      else if (dbg == 2)
+        EGV_LAUNCH((attn_time_fwd8_kernel<TMAX, 2>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
+                   oh, ol, lse, ws);
+      else
+#endif
       EGV_LAUNCH((attn_time_fwd8_kernel<TMAX>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H, oh,
                  ol, lse, ws);
       done = true;

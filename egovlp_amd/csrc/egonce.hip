@@ -441,6 +441,56 @@ __global__ __launch_bounds__(256) void maxmargin_kernel(const float* __restrict_
 }
 }  // namespace
 
+// ---- dual-softmax re-scaling of a retrieval similarity matrix (run/test_epic.py:137-143) ------------------------------------
+//   y = softmax(x / temp, dim = 1) * x        (row-wise prior: one wave per row, the row is streamed three times from L2)
+//   z = softmax(y, dim = 0)                   (column-wise: a workgroup owns 64 columns; lanes walk the rows coalesced)
+namespace {
+__global__ __launch_bounds__(256) void dual_softmax_rows_kernel(const float* __restrict__ x, int n, int m, float inv_temp,
+                                                                float* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* xr = x + (long)row * m;
+  float mx = -3.0e38f;
+  for (int j = lane; j < m; j += 64) mx = fmaxf(mx, xr[j] * inv_temp);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < m; j += 64) sum += __expf(xr[j] * inv_temp - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float* yr = y + (long)row * m;
+  for (int j = lane; j < m; j += 64) yr[j] = __expf(xr[j] * inv_temp - mx) * inv * xr[j];
+}
+
+__global__ __launch_bounds__(256) void dual_softmax_cols_kernel(const float* __restrict__ y, int n, int m, float* __restrict__ z) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const bool live = col < m;
+  float mx = -3.0e38f;
+  for (int i = part; i < n; i += 4) if (live) mx = fmaxf(mx, y[(long)i * m + col]);
+  red[part][threadIdx.x & 63] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0][threadIdx.x & 63], red[1][threadIdx.x & 63]), fmaxf(red[2][threadIdx.x & 63], red[3][threadIdx.x & 63]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = part; i < n; i += 4) if (live) sum += __expf(y[(long)i * m + col] - mx);
+  red[part][threadIdx.x & 63] = sum;
+  __syncthreads();
+  sum = red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63];
+  const float inv = 1.0f / sum;
+  for (int i = part; i < n; i += 4) if (live) z[(long)i * m + col] = __expf(y[(long)i * m + col] - mx) * inv;
+}
+}  // namespace
+
+extern "C" int egv_dual_softmax(const float* x, int32_t n, int32_t m, float temp, float* work, float* out, void* stream) {
+  if (!x || !work || !out || n <= 0 || m <= 0 || !(temp > 0.f)) return EGV_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  EGV_LAUNCH(dual_softmax_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, n, m, 1.0f / temp, work);
+  EGV_CHECK_LAUNCH();
+  EGV_LAUNCH(dual_softmax_cols_kernel, dim3((m + 63) / 64), dim3(256), 0, s, work, n, m, out);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
 extern "C" int egv_maxmargin_fwd_bwd(const float* x, const float* weight, int32_t n, float margin, int32_t fix_norm,
                                      float* loss, float* dx, void* stream) {
   if (!x || !loss || n <= 0 || n > 4096 || (fix_norm && n < 2)) return EGV_ERR_ARG;

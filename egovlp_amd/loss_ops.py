@@ -65,3 +65,16 @@ def maxmargin(x, weight, margin, fix_norm, want_grad=True):
     check(_lib.lib().egv_maxmargin_fwd_bwd(_p(x), _p(w), n, float(margin), int(bool(fix_norm)), _p(loss), _p(dx), _stream()),
           "egv_maxmargin_fwd_bwd")
     return loss, dx
+
+
+def dual_softmax(x, temp=500.0):
+    """softmax(softmax(x / temp, dim=1) * x, dim=0) of a [texts, videos] similarity matrix (run/test_epic.py:137-143)."""
+    ops._need_cuda(x)
+    x = x.contiguous().float()
+    if x.dim() != 2:
+        raise ValueError("dual_softmax needs a [texts, videos] matrix")
+    n, m = x.shape
+    work = torch.empty_like(x)
+    out = torch.empty_like(x)
+    check(_lib.lib().egv_dual_softmax(_p(x), n, m, float(temp), _p(work), _p(out), _stream()), "egv_dual_softmax")
+    return out

@@ -240,3 +240,25 @@ class _SimMatrixFn(torch.autograd.Function):
 def sim_matrix(a, b, eps=1e-8):
     """added eps for numerical stability (model/model.py:189-197)."""
     return _SimMatrixFn.apply(a, b, eps)
+
+
+def sim_matrix_mm(a, b):
+    """Plain inner-product similarity a @ b^T (run/test_epic.py:31-33), fp32-grade on the bf16x3 GEMM."""
+    ops._need_cuda(a, b)
+    n, m = a.shape[0], b.shape[0]
+    m4 = (m + 3) // 4 * 4                     # the GEMM writes 4-column pieces: pad the video rows with zeros
+    b = b.detach().contiguous().float()
+    if m4 != m:
+        b = torch.cat([b, b.new_zeros(m4 - m, b.shape[1])])
+    out = torch.empty((n, m4), dtype=torch.float32, device=a.device)
+    a_pl = ops.split_f32(a.detach().contiguous().float(), 3)[0]
+    b_pl = ops.split_f32(b, 3)[0]
+    ops.gemm_nt(a_pl, b_pl, passes=3, out_f32=out)
+    return out[:, :m]
+
+
+def dual_softmax_similarity(text_embeds, vid_embeds, temp=500.0):
+    """The `--dual_softmax` retrieval similarity of run/test_epic.py:137-143: sim = text @ video^T (un-normalised),
+    sim = softmax(sim / 500, dim=1) * sim, sim = softmax(sim, dim=0); [texts, videos] on the device."""
+    from ..loss_ops import dual_softmax
+    return dual_softmax(sim_matrix_mm(text_embeds, vid_embeds), temp)

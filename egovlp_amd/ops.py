@@ -245,7 +245,8 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * K,
                           lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"), passes,
-                          key=f"NT M={M} N={N} K={K} x{passes}")
+                          key=("gemm_big " if ksplit <= 1 and uses_big_gemm(M, N, K) else "gemm_nt(128x128) ")
+                          + f"NT M={M} N={N} K={K} x{passes}")
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
 
@@ -302,7 +303,7 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * Kd,
                           lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"), passes,
-                          key=f"TN M={M} N={N} K={Kd} x{passes}")
+                          key=f"gemm_big TN M={M} N={N} K={Kd} x{passes}")
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)")
     return cs

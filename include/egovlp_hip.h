@@ -218,6 +218,10 @@ int egv_egonce_from_sim(const float* x, const float* sim_v, const float* sim_n, 
 int egv_maxmargin_fwd_bwd(const float* x, const float* weight, int32_t n, float margin, int32_t fix_norm,
                           float* loss, float* dx, void* stream);
 
+/* Dual-softmax re-scaling of a retrieval similarity matrix x [n texts, m videos] (run/test_epic.py:137-143, --dual_softmax):
+ *   y = softmax(x / temp, dim 1) * x;  out = softmax(y, dim 0).  work: n*m floats.  temp = 500 in the reference.        */
+int egv_dual_softmax(const float* x, int32_t n, int32_t m, float temp, float* work, float* out, void* stream);
+
 /* ---- gradient exchange (data parallel) ------------------------------------------------------------------
  * Replaces the fp32 bucket copies of DistributedDataParallel (base/base_trainer.py:258): `count` fp32 gradient tensors
  * (HOST arrays of device pointers / sizes) are scaled by `scale` (= 1 / world size), rounded to bf16 (RNE) and written to

@@ -310,3 +310,18 @@ def max_margin_ranking_loss(x, margin=0.2, fix_norm=True, weight=None):
         keep = 1.0 - torch.eye(n, dtype=x.dtype)
         return ((rows + cols) * keep).sum() / (2 * n * (n - 1))
     return (rows + cols).sum() / (2 * n * n)
+
+
+def dual_softmax_similarity(text_embeds, vid_embeds, temp=500.0):
+    """run/test_epic.py:31-38,137-143 (`--dual_softmax`): sim = text @ video^T; sim = softmax(sim / 500, dim=1) * sim;
+    sim = softmax(sim, dim=0).  [texts, videos]."""
+    sim = torch.mm(text_embeds, vid_embeds.transpose(0, 1))
+    sim = F.softmax(sim / temp, dim=1) * sim
+    return F.softmax(sim, dim=0)
+
+
+def text_token_embeds(input_ids, attention_mask, sd, cfg: "TextCfg"):
+    """FrozenInTime.compute_text_tokens, model/model.py:128-138: txt_proj (ReLU -> Linear) applied to EVERY token of
+    DistilBERT's last hidden state -> [B, L, 256] (the NLQ / MQ feature dumps, run/test_nlq.py:107-110)."""
+    hidden = distilbert(input_ids, attention_mask, sd, cfg)
+    return F.linear(F.relu(hidden), sd["txt_proj.1.weight"], sd["txt_proj.1.bias"])

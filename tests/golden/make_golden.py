@@ -197,9 +197,51 @@ def make_losses(ml):
     print("losses:", {k: float(v) for k, v in out.items() if k.startswith("loss_") and "n48" in k})
 
 
+def make_retrieval(mm):
+    """(a) the `--dual_softmax` similarity of run/test_epic.py (the script cannot be imported -- it pulls the data loaders -- so
+    its three helper functions `sim_matrix_mm`, `softmax_numpy` are EXECUTED from the reference's own source text and the
+    expression of :140-143 is applied to them); (b) FrozenInTime.compute_text_tokens of the reference model on the seeded
+    B = 4 ragged batch (sub-sampled rows)."""
+    import ast
+    import torch.nn.functional as F
+    src = open("/root/reference/run/test_epic.py").read()
+    tree = ast.parse(src)
+    want = {"sim_matrix_mm", "softmax_numpy"}
+    ns = {"torch": torch, "F": F, "np": np}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in want:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "run/test_epic.py", "exec"), ns)
+    out = {}
+    g = torch.Generator().manual_seed(99)
+    for nt, nv in ((7, 5), (150, 96), (300, 410)):
+        t = torch.randn(nt, 256, generator=g) * 2.0
+        v = torch.randn(nv, 256, generator=g) * 2.0
+        sim = ns["sim_matrix_mm"](t, v)                                  # run/test_epic.py:141
+        sim = ns["softmax_numpy"](sim / 500, dim=1) * sim                # :142
+        sim = ns["softmax_numpy"](sim, dim=0)                            # :143
+        out[f"text_{nt}x{nv}"], out[f"video_{nt}x{nv}"], out[f"dual_{nt}x{nv}"] = np32(t), np32(v), np.asarray(sim, np.float32)
+    torch.manual_seed(0)
+    net = mm.FrozenInTime(
+        video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 16,
+                      "pretrained": True, "time_init": "zeros"},
+        text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+        projection="minimal", load_checkpoint="")
+    net.text_model.config._attn_implementation = "eager"
+    net.load_state_dict(synth_state_dict({k: v.shape for k, v in net.state_dict().items()}, seed=0), strict=True)
+    net.eval()
+    batch = synth_batch(4, T=4, L=32, seed=1234, ragged=True)
+    with torch.no_grad():
+        tok = net.compute_text_tokens(batch["text"])                    # [4, 32, 256]
+        vid = net(batch, video_only=True)                               # model/model.py:100-103
+    out["text_tokens"] = np32(tok)
+    out["video_only"] = np32(vid)
+    np.savez_compressed(os.path.join(HERE, "retrieval.npz"), **out)
+    print("retrieval:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     assert ref_import.available(), "needs /root/reference (build container only)"
-    which = sys.argv[1:] or ["tiny", "gather", "full", "losses"]
+    which = sys.argv[1:] or ["tiny", "gather", "full", "losses", "retrieval"]
     if "gather" in which:
         make_gather()
     mm, ml, te, mv = ref_import.load_reference()
@@ -209,3 +251,5 @@ if __name__ == "__main__":
         make_full(mm, ml)
     if "losses" in which:
         make_losses(ml)
+    if "retrieval" in which:
+        make_retrieval(mm)

@@ -469,3 +469,26 @@ def test_weight_gradients_on_the_side_stream_are_the_same_gradients(full, which)
     finally:
         ops.WGRAD_SIDE_STREAM = ops.TEXT_SIDE_STREAM = False
         m.eval()
+
+
+def test_retrieval_heads_match_the_reference_golden(full, golden_dir):
+    """§8(f4) consumers of the encoders: compute_text_tokens (NLQ / MQ feature dumps), forward(video_only=True) (OSCC / PNR
+    heads, feature dumps) and the dual-softmax retrieval similarity of run/test_epic.py, against outputs of the reference."""
+    from egovlp_amd.model.model import dual_softmax_similarity, sim_matrix_mm
+    g = np.load(os.path.join(golden_dir, "retrieval.npz"))
+    m, _ = full
+    m.eval()
+    batch = to_dev(synth_batch(4, T=4, L=32, seed=1234, ragged=True))
+    with torch.no_grad():
+        tok = m.compute_text_tokens(batch["text"])
+        vid = m(batch, video_only=True)
+    assert tok.shape == (4, 32, 256)
+    print("text tokens rel %.2e, video_only rel %.2e" % (rel(tok, g["text_tokens"]), rel(vid, g["video_only"])))
+    assert rel(tok, g["text_tokens"]) < PARITY and rel(vid, g["video_only"]) < PARITY
+    for shape in ("7x5", "150x96", "300x410"):
+        t, v = torch.from_numpy(g["text_" + shape]).cuda(), torch.from_numpy(g["video_" + shape]).cuda()
+        assert rel(sim_matrix_mm(t, v), t.double().cpu() @ v.double().cpu().t()) < 2e-5
+        got = dual_softmax_similarity(t, v)
+        r = rel(got, g["dual_" + shape])
+        print("dual softmax %s rel %.2e" % (shape, r))
+        assert r < 1e-4, shape                               # exp() of O(100) logits amplifies the GEMM's 1e-5

@@ -126,3 +126,18 @@ def test_ranking_losses_match_the_reference(golden_dir):
                 key = f"{name}_n{n}_fix{fix}"
                 assert abs(float(v) - float(g["loss_" + key])) < 1e-6 * max(1.0, abs(float(g["loss_" + key]))), key
                 assert torch.allclose(x.grad, torch.from_numpy(g["grad_" + key]), rtol=1e-5, atol=1e-8), key
+
+
+def test_retrieval_heads_match_the_reference(golden_dir, full):
+    """§8(f4): the `--dual_softmax` similarity (run/test_epic.py:137-143, golden computed by the reference's own helper
+    functions), FrozenInTime.compute_text_tokens (model/model.py:128-138) and forward(video_only=True) (:100-103)."""
+    g = np.load(os.path.join(golden_dir, "retrieval.npz"))
+    for shape in ("7x5", "150x96", "300x410"):
+        got = O.dual_softmax_similarity(torch.from_numpy(g["text_" + shape]), torch.from_numpy(g["video_" + shape]))
+        assert rel(got, g["dual_" + shape]) < 1e-5, shape
+    _, sd, batch, te, ve, _ = full
+    with torch.no_grad():
+        tok = O.text_token_embeds(batch["text"]["input_ids"], batch["text"]["attention_mask"], sd, O.TextCfg())
+    assert rel(tok, g["text_tokens"]) < 2e-5
+    assert rel(tok[:, 0], te) < 1e-6                    # token 0 is the sentence embedding of compute_text
+    assert rel(ve, g["video_only"]) < 2e-5
