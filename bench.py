@@ -127,6 +127,9 @@ def main():
                     help="1: weight-gradient GEMMs on a second HIP stream (egovlp_amd.ops.side_stream)")
     ap.add_argument("--text-side", type=int, default=int(os.environ.get("EGV_TEXT_SIDE", "1")),
                     help="1 (default): the DistilBERT tower on a second HIP stream under the video tower; 0: one stream")
+    ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("EGV_ADAMW_OVERLAP", "0")),
+                    help="1: AdamW updates enqueued from grad-ready hooks on a side stream under the rest of backward "
+                         "(single GPU only; bit-identical results)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL process group, DDP wrapper and the fused all-gather even at world size 1 "
                          "(smoke test of the N>1 code path on a 1-GPU box)")
@@ -178,6 +181,8 @@ def main():
     ops.WGRAD_SIDE_STREAM = bool(args.wgrad_side)
     ops.TEXT_SIDE_STREAM = bool(args.text_side)
     opt = AdamW(model.parameters(), lr=3e-5)
+    if args.adamw_overlap and grad_sync is None and not args.ddp:
+        opt.overlap_backward()
     loss_fn = EgoNCE()
     batch = synth_batch(B, T=T, L=L, seed=1234, rank=rank)
     data = {"video": batch["video"].cuda(), "text": {k: v.cuda() for k, v in batch["text"].items()},
@@ -269,7 +274,8 @@ def main():
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
                    "parallelism": f"dp{world}", "precision": "/".join(ops.Precision.name()),
                    "text_dropout": args.text_dropout,
-                   "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side)}},
+                   "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
+                               "adamw_overlapped_with_backward": bool(args.adamw_overlap and grad_sync is None and not args.ddp)}},
         "loss": round(loss_val, 5),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
     }
