@@ -34,6 +34,15 @@ def _gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
     return out
 
 
+def _pad_tokens(text, multiple):
+    """Right-pad input_ids (0 = [PAD]) and attention_mask (0 = masked) to a multiple of `multiple` tokens."""
+    L = text['input_ids'].shape[1]
+    Lp = (L + multiple - 1) // multiple * multiple
+    if Lp == L:
+        return text
+    return {k: torch.nn.functional.pad(v, (0, Lp - L), value=0) for k, v in text.items()}
+
+
 class AllGather_multi(torch.autograd.Function):
     """An autograd function that performs allgather on a tensor (reference signature kept:
     `AllGather_multi.apply(tensor, n_gpu, args)` with args.world_size / args.rank)."""
@@ -187,6 +196,14 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
         and scored by the configured metrics (model/metric.py:218-234).  Differences: the gathers are one collective each
         (`all_gather_into_tensor`) and are skipped without a process group; results stay on the device until the end."""
         self.model.eval()
+        # one query + five clips per question is ~330 launches for ~3 ms of GPU work: with `args.graph_eval` the forward is
+        # captured once per input shape into a HIP graph and replayed (egovlp_amd/graph.py); queries are padded to a multiple
+        # of 8 tokens (masked keys contribute exact zeros) so that a handful of graphs covers every caption length
+        fwd = None
+        if getattr(self.args, 'graph_eval', False):
+            from ..graph import GraphedForward
+            fwd = GraphedForward(self.model)
+            self.last_graphed_forward = fwd
         n_loaders = len(self.valid_data_loader)
         gt_arr = {x: [] for x in range(n_loaders)}
         pred_arr = {x: [] for x in range(n_loaders)}
@@ -200,7 +217,12 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
                         data['text'] = self.tokenizer(data['text'], return_tensors='pt', padding=True, truncation=True)
                     data['text'] = {key: val.to(self.device) for key, val in data['text'].items()}
                     data['video'] = data['video'].to(self.device)
-                    text_embed, vid_embed = self.model(data, return_embeds=True)       # :211
+                    if fwd is not None:
+                        data['text'] = _pad_tokens(data['text'], 8)
+                        text_embed, vid_embed = fwd(data)
+                        text_embed, vid_embed = text_embed.clone(), vid_embed.clone()  # the graph's static outputs
+                    else:
+                        text_embed, vid_embed = self.model(data, return_embeds=True)   # :211
                     data_gt = data['correct'][0].to(self.device).unsqueeze(0)
                     data_pred = sim_matrix(text_embed, vid_embed)                        # :214
                     data_type = data['type'][0].to(self.device).unsqueeze(0)

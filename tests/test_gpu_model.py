@@ -305,6 +305,17 @@ def test_egomcq_validation_epoch_matches_oracle(full):
     assert rel(pred, ref) < PARITY
     want = egomcq_accuracy_metrics(ref, torch.cat([q["correct"] for q in questions]), torch.cat([q["type"] for q in questions]))
     assert res["nested_val_metrics"][0]["egomcq_accuracy_metrics"] == want
+    # the same epoch through HIP-graph replay (args.graph_eval): one capture for the one input shape, same predictions
+    args.graph_eval = True
+    tr.valid_data_loader = [Loader([dict(q) for q in questions])]
+    res_g = tr._valid_epoch(1)
+    pred_g = tr.last_val_predictions[0]
+    fwd = tr.last_graphed_forward
+    print("graphed EgoMCQ epoch: %d captures, %d replays, max |pred - eager| %.2e"
+          % (fwd.stats["captures"], fwd.stats["replays"], float((pred_g - pred).abs().max())))
+    assert fwd.stats == {"captures": 1, "replays": 6}
+    assert float((pred_g - pred).abs().max()) < 1e-6
+    assert res_g["nested_val_metrics"][0]["egomcq_accuracy_metrics"] == want
     m.train()
 
 
