@@ -166,11 +166,139 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
   }
 }
 
+// ---- streaming variant for the three-pass space mode ---------------------------------------------------------------------
+// The kernel above keeps the scores of ALL keys of a query tile in registers (56 fp32 + their split bf16 images: 256 VGPRs
+// in three-pass mode, i.e. two waves per SIMD), and a wave runs QK^T (matrix pipe) -> softmax (VALU) -> P.V (matrix pipe)
+// strictly one after the other: PMC shows VALU 25 %, MFMA 16 %, LDS 20 % of the launch, added up rather than overlapped
+// (profiles/r02_i_pmc_attention.txt).  Here a wave walks the keys in chunks of 32 with the running-max / running-sum
+// recurrence (m, l, O rescaled by exp(m_old - m_new) per chunk), so only one chunk of scores is live: <= 128 VGPRs, SIXTEEN
+// waves per workgroup (four per SIMD) whose phases interleave, and the 13 query tiles of a ViT-B group run in one round.
+// Measured 137 -> 130 us (profiles/r02_z_attention_streaming.txt): staging a group's K / V (one workgroup per CU, 115 KiB) is still
+// not overlapped with the previous group's tiles -- that needs the K / V chunks themselves streamed through a small LDS ring.
+template <int NKF>
+__global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
+                                                                bf16_t* __restrict__ out_lo, long out_stride,
+                                                                float* __restrict__ lse, float* __restrict__ cls_ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKP = NKF * 16;
+  constexpr int PLANE = NKP * ATT_ROW_BYTES;
+  char* k_hi = smem;
+  char* v_hi = smem + PLANE;
+  char* k_lo = smem + 2 * PLANE;
+  char* v_lo = smem + 3 * PLANE;
+  float* kbias = (float*)(smem + 4 * PLANE);
+
+  const AttGroup<MODE_SPACE> grp(g, blockIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long hoff = (long)grp.h * ATT_D;
+  const long HD = (long)g.H * ATT_D;
+
+  att_stage_planes(k_hi, k_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + HD + hoff; });
+  att_stage_planes(v_hi, v_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + 2 * HD + hoff; });
+  for (int j = threadIdx.x; j < NKP; j += blockDim.x) kbias[j] = (j < g.nk) ? 0.f : -1e30f;
+  __syncthreads();
+
+  const int gq = lane >> 4;
+  const int nq_all = g.nq + 1;                       // + the CLS query row (see attn_fwd_kernel)
+  const int ntiles = (nq_all + 15) / 16;
+  for (int qt = wave; qt < ntiles; qt += (int)(blockDim.x >> 6)) {
+    const int qi = qt * 16 + (lane & 15);
+    const bool is_cls = qi >= g.nq;
+    const long qtok = is_cls ? grp.tok0 : grp.q_tok(g, min(qi, g.nq - 1));
+    bf16x8_t qh[2], ql[2];
+    att_gfrag_planes(g.ph, g.pl, qtok * g.tok_stride + hoff, 0, lane, qh[0], ql[0]);
+    att_gfrag_planes(g.ph, g.pl, qtok * g.tok_stride + hoff, 1, lane, qh[1], ql[1]);
+    float m = -3e38f, l = 0.f;                       // m: uniform over the four lane groups of a query; l: this lane group's part
+    f32x4_t o[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < NKF / 2; ++c) {
+      f32x4_t s[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kf = 2 * c + h;
+        s[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
+          const bf16x8_t al = att_frag_cols(k_lo, kf * 16, ks, lane);
+          s[h] = att_mma<3>(ah, al, qh[ks], ql[ks], s[h]);
+        }
+        const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
+        s[h] = s[h] * 0.125f + kb;                   // q *= 64^-0.5 (video_transformer.py:106), applied to the scores
+      }
+      if (c == 0 && is_cls && grp.f > 0 && gq == 0) s[0][0] = -1e30f;   // CLS key x CLS query: group 0 only
+      float cm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      const float mn = fmaxf(m, cm);
+      const float alpha = __expf(m - mn);            // first chunk: exp(-3e38 - mn) = 0 and l, o are 0 anyway
+      m = mn;
+      float pv[8];
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = __expf(s[0][r] - mn);
+        pv[4 + r] = __expf(s[1][r] - mn);
+        ps += pv[r] + pv[4 + r];
+      }
+      l = l * alpha + ps;
+      bf16x8_t ph, pl;
+      att_split8(pv, ph, pl);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8_t vh = att_frag_rows(v_hi, 32 * c, df * 16, lane);
+        const bf16x8_t vl = att_frag_rows(v_lo, 32 * c, df * 16, lane);
+        o[df] = att_mma<3>(vh, vl, ph, pl, o[df] * alpha);
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qi == g.nq) {
+      // CLS query x this frame's keys: un-normalised partial for egv_attn_cls_combine
+      float* w = cls_ws + (((long)grp.b * g.H + grp.h) * g.T + grp.f) * 68;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) *(f32x4_t*)(w + df * 16 + 4 * gq) = o[df];
+      if (gq == 0) {
+        w[64] = m;
+        w[65] = l;
+      }
+    } else if (qi < g.nq) {
+      const float inv = 1.0f / l;
+      bf16_t* oh = out_hi + qtok * out_stride + hoff;
+      bf16_t* ol = out_lo + qtok * out_stride + hoff;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        uint32_t h0, h1, l0, l1;
+        split_bf16x2(o[df][0] * inv, o[df][1] * inv, h0, l0);
+        split_bf16x2(o[df][2] * inv, o[df][3] * inv, h1, l1);
+        const int d = df * 16 + 4 * gq;
+        *(u32x2_t*)(oh + d) = (u32x2_t){h0, h1};
+        *(u32x2_t*)(ol + d) = (u32x2_t){l0, l1};
+      }
+      if (gq == 0 && lse) lse[((long)grp.b * g.H + grp.h) * g.S + (qtok - grp.tok0)] = m + __logf(l);
+    }
+  }
+}
+
 template <int MODE, int NKF>
 int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol, long ostride, float* lse,
                float* cls_ws, hipStream_t s) {
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NKF * 16 * ATT_ROW_BYTES + NKF * 16 * sizeof(float);
+  if constexpr (MODE == MODE_SPACE && NKF == 14) {   // measured on ViT-B/16 (13 query tiles on 16 waves): 137 -> 130 us
+    static const int stream_on = getenv("EGV_ATTN_STREAM") ? atoi(getenv("EGV_ATTN_STREAM")) : 1;   // A/B: 0 = the all-keys kernel
+    if (passes == 3 && ol != nullptr && stream_on) {
+      auto kern = attn_fwd_stream3_kernel<NKF>;
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EGV_LAUNCH(kern, dim3(ngroups), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws);
+      EGV_CHECK_LAUNCH();
+      return EGV_OK;
+    }
+  }
   if (passes == 3) {
     auto kern = attn_fwd_kernel<MODE, NKF, 3>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
