@@ -27,6 +27,8 @@ struct AttGrad {
   const bf16_t* doh;   // MODE_SPACE: d_out planes
   const bf16_t* dol;
   long do_stride;
+  const bf16_t* oh;    // MODE_SPACE: the forward's attention output planes (delta = rowsum(dO o O) in the streaming dQ kernel)
+  const bf16_t* ol;
   const float* lse;    // [B, H, S]
   float* delta;        // [B, H, S] workspace (written by dQ kernel, read by dKV kernel; slot 0 = the CLS row's delta,
                        //  precomputed by egv_attn_cls_delta in MODE_SPACE)
@@ -175,6 +177,125 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const
 #pragma unroll
         for (int df = 0; df < 4; ++df) *(f32x4_t*)(out + df * 16 + 4 * gq) = dq[df] * 0.125f;
       }
+      if (gq == 0) gr.delta[lrow] = delta;
+    }
+  }
+}
+
+// ---- streaming dQ for the space mode ------------------------------------------------------------------------------------------
+// The kernel above needs delta = sum_k P dP before it can form dS, so it keeps P and dP of ALL keys in registers (112 fp32,
+// 171 VGPRs single-pass: two waves per SIMD, one workgroup per CU).  delta is also rowsum(dO o O) -- one dot product of the
+// query's dO row with the forward's output row -- so here it is computed up front from the O planes and the keys are walked
+// in 32-key chunks with nothing but the dQ accumulators live: under 128 VGPRs, i.e. two 8-wave workgroups per CU in
+// single-pass mode (the staging of one hides under the tiles of the other) and 16 waves per workgroup in three-pass mode.
+__device__ __forceinline__ float frag_dot8(bf16x8_t ah, bf16x8_t al, bool a_lo, bf16x8_t bh, bf16x8_t bl, bool b_lo) {
+  const u32x4_t a0 = __builtin_bit_cast(u32x4_t, ah), a1 = __builtin_bit_cast(u32x4_t, al);
+  const u32x4_t b0 = __builtin_bit_cast(u32x4_t, bh), b1 = __builtin_bit_cast(u32x4_t, bl);
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float ax = __uint_as_float(a0[e] << 16), ay = __uint_as_float(a0[e] & 0xffff0000u);
+    float bx = __uint_as_float(b0[e] << 16), by = __uint_as_float(b0[e] & 0xffff0000u);
+    if (a_lo) { ax += __uint_as_float(a1[e] << 16); ay += __uint_as_float(a1[e] & 0xffff0000u); }
+    if (b_lo) { bx += __uint_as_float(b1[e] << 16); by += __uint_as_float(b1[e] & 0xffff0000u); }
+    acc += ax * bx + ay * by;
+  }
+  return acc;
+}
+
+template <int NKF, int PASSES>
+__global__ __launch_bounds__(PASSES == 3 ? 1024 : 512) void attn_bwd_dq_stream_kernel(const AttGeom g, const AttGrad gr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKP = NKF * 16;
+  constexpr int PLANE = NKP * ATT_ROW_BYTES;
+  char* k_hi = smem;
+  char* v_hi = smem + PLANE;
+  char* k_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
+  char* v_lo = (PASSES == 3) ? smem + 3 * PLANE : nullptr;
+  float* kbias = (float*)(smem + ((PASSES == 3) ? 4 : 2) * PLANE);
+
+  const AttGroup<MODE_SPACE> grp(g, blockIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long hoff = (long)grp.h * ATT_D;
+  const long HD = (long)g.H * ATT_D;
+  att_stage_planes(k_hi, k_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + HD + hoff; });
+  att_stage_planes(v_hi, v_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + 2 * HD + hoff; });
+  for (int j = threadIdx.x; j < NKP; j += blockDim.x) kbias[j] = (j < g.nk) ? 0.f : -1e30f;
+  __syncthreads();
+
+  const int gq = lane >> 4;
+  const int nq_all = g.nq + 1;
+  const int ntiles = (nq_all + 15) / 16;
+  for (int qt = wave; qt < ntiles; qt += (int)(blockDim.x >> 6)) {
+    const int qi = qt * 16 + (lane & 15);
+    const bool is_cls = qi >= g.nq;
+    const long tok = is_cls ? grp.tok0 : grp.q_tok(g, min(qi, g.nq - 1));
+    bf16x8_t qh[2], ql[2], gh[2], gl[2], oh[2], ol[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      att_gfrag_planes(g.ph, g.pl, tok * g.tok_stride + hoff, ks, lane, qh[ks], ql[ks]);
+      att_gfrag_planes(gr.doh, gr.dol, tok * gr.do_stride + hoff, ks, lane, gh[ks], gl[ks]);
+      att_gfrag_planes(gr.oh, gr.ol, tok * gr.do_stride + hoff, ks, lane, oh[ks], ol[ks]);
+    }
+    const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (tok - grp.tok0);
+    const float L = gr.lse[lrow];
+    float delta = frag_dot8(gh[0], gl[0], gr.dol != nullptr, oh[0], ol[0], gr.ol != nullptr) +
+                  frag_dot8(gh[1], gl[1], gr.dol != nullptr, oh[1], ol[1], gr.ol != nullptr);
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    if (is_cls) delta = gr.delta[lrow];             // the CLS row's delta spans all frame groups: precomputed
+
+    f32x4_t dq[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) dq[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < NKF / 2; ++c) {
+      float dsv[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kf = 2 * c + h;
+        f32x4_t sc = {0.f, 0.f, 0.f, 0.f};
+        f32x4_t d = sc;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
+          bf16x8_t al = ah;
+          if (PASSES == 3) al = att_frag_cols(k_lo, kf * 16, ks, lane);
+          sc = att_mma<PASSES>(ah, al, qh[ks], ql[ks], sc);
+          const bf16x8_t bh = att_frag_cols(v_hi, kf * 16, ks, lane);
+          bf16x8_t bl = bh;
+          if (PASSES == 3) bl = att_frag_cols(v_lo, kf * 16, ks, lane);
+          d = att_mma<PASSES>(bh, bl, gh[ks], gl[ks], d);
+        }
+        const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pr = __expf(sc[r] * 0.125f + kb[r] - L);
+          if (kf == 0 && r == 0 && is_cls && grp.f > 0 && gq == 0) pr = 0.f;   // CLS key x CLS query: group 0 only
+          dsv[4 * h + r] = pr * (d[r] - delta);
+        }
+      }
+      bf16x8_t sh, sl;
+      att_split8(dsv, sh, sl);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8_t kh = att_frag_rows(k_hi, 32 * c, df * 16, lane);
+        bf16x8_t kl = kh;
+        if (PASSES == 3) kl = att_frag_rows(k_lo, 32 * c, df * 16, lane);
+        dq[df] = att_mma<PASSES>(kh, kl, sh, sl, dq[df]);
+      }
+    }
+    if (qi == g.nq) {
+      float* a = gr.dcls + ((long)grp.b * g.H + grp.h) * 192;
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(a + df * 16 + 4 * gq + r, dq[df][r]);
+    } else if (qi < g.nq) {
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+        store_planes4(gr.gh, gr.gl, tok * gr.tok_stride + hoff + df * 16 + 4 * gq, dq[df] * 0.125f);
       if (gq == 0) gr.delta[lrow] = delta;
     }
   }
@@ -334,6 +455,31 @@ template <int MODE, int NF>
 int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hipStream_t s) {
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NF * 16 * ATT_ROW_BYTES + 2 * NF * 16 * sizeof(float);
+  if constexpr (MODE == MODE_SPACE && NF == 14) {     // ViT-B/16: streaming dQ kernel (measured), then the dK/dV kernel
+    static const int stream_on = getenv("EGV_ATTN_STREAM") ? atoi(getenv("EGV_ATTN_STREAM")) : 1;   // A/B: 0 = all-keys dQ kernel
+    if (stream_on && gr.oh != nullptr) {
+      const size_t lds1 = (size_t)planes * NF * 16 * ATT_ROW_BYTES + NF * 16 * sizeof(float);
+      if (passes == 3) {
+        auto k1 = attn_bwd_dq_stream_kernel<NF, 3>;
+        auto k2 = attn_bwd_dkv_kernel<MODE, NF, 3>;
+        (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        EGV_LAUNCH(k1, dim3(ngroups), dim3(1024), lds1, s, g, gr);
+        EGV_CHECK_LAUNCH();
+        EGV_LAUNCH(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+      } else {
+        auto k1 = attn_bwd_dq_stream_kernel<NF, 1>;
+        auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
+        (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        EGV_LAUNCH(k1, dim3(ngroups), dim3(512), lds1, s, g, gr);
+        EGV_CHECK_LAUNCH();
+        EGV_LAUNCH(k2, dim3(ngroups), dim3(512), lds, s, g, gr);
+      }
+      EGV_CHECK_LAUNCH();
+      return EGV_OK;
+    }
+  }
   if (passes == 3) {
     auto k1 = attn_bwd_dq_kernel<MODE, NF, 3>;
     auto k2 = attn_bwd_dkv_kernel<MODE, NF, 3>;
@@ -369,7 +515,8 @@ int dispatch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, h
 
 }  // namespace
 
-int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* do_hi, const bf16_t* do_lo,
+int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* out_hi, const bf16_t* out_lo,
+                            const bf16_t* do_hi, const bf16_t* do_lo,
                             const float* lse, float* delta, float* dcls, int B, int T, int n, int H, int passes,
                             bf16_t* dqkv_hi, bf16_t* dqkv_lo, hipStream_t s) {
   AttGeom g;
@@ -391,6 +538,7 @@ int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf
   gr.doh = do_hi;
   gr.dol = (passes == 3) ? do_lo : nullptr;
   gr.do_stride = HD;
+  gr.oh = out_hi; gr.ol = out_lo;                   // [B*S, H*64] planes, same row stride as d_out
   gr.lse = lse; gr.delta = delta; gr.dcls = dcls;
   return dispatch_bwd<MODE_SPACE>(g, gr, B * T * H, passes, s);
 }
@@ -417,6 +565,7 @@ extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v,
   gr.gh = gr.gl = nullptr;
   gr.tok_stride = lddqkv;
   gr.d_out = d_out; gr.doh = gr.dol = nullptr; gr.do_stride = HD;
+  gr.oh = gr.ol = nullptr;
   gr.lse = lse; gr.delta = delta_work; gr.dcls = nullptr;
   return dispatch_bwd<MODE_TEXT>(g, gr, B * H, passes, (hipStream_t)stream);
 }

@@ -6,7 +6,8 @@
 
 int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, int T, int n, int H, int passes,
                             bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, hipStream_t s);
-int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* do_hi, const bf16_t* do_lo,
+int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* out_hi, const bf16_t* out_lo,
+                            const bf16_t* do_hi, const bf16_t* do_lo,
                             const float* lse, float* delta, float* dcls, int B, int T, int n, int H, int passes,
                             bf16_t* dqkv_hi, bf16_t* dqkv_lo, hipStream_t s);
 int egv_attn_time_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol,
@@ -55,7 +56,9 @@ extern "C" int egv_divided_attn_bwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_
     return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   if (passes == 3 && (!qkv_lo || !out_lo || !dout_lo || !dqkv_lo)) return EGV_ERR_ARG;
-  if (passes == 1) { qkv_lo = nullptr; out_lo = nullptr; dout_lo = nullptr; dqkv_lo = nullptr; }
+  // single-pass: hi planes only -- except the forward's output, whose lo plane (if the caller has one: the benchmarked mode
+  // runs a three-pass forward) makes delta = rowsum(dO o O) exact in O at no cost
+  if (passes == 1) { qkv_lo = nullptr; dout_lo = nullptr; dqkv_lo = nullptr; }
   hipStream_t s = (hipStream_t)stream;
   const int S = 1 + T * n;
   float* delta = work;                          // [B, H, S]
@@ -64,8 +67,8 @@ extern "C" int egv_divided_attn_bwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_
   int rc = egv_attn_cls_delta_impl(out_hi, out_lo, dout_hi, dout_lo, B, S, H, delta, s);
   if (rc) return rc;
   if (mode == 0)
-    rc = egv_attn_space_bwd_impl(qkv_hi, qkv_lo, dout_hi, dout_lo, lse, delta, dcls, B, T, n, H, passes, dqkv_hi,
-                                 dqkv_lo, s);
+    rc = egv_attn_space_bwd_impl(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dcls, B, T, n, H, passes,
+                                 dqkv_hi, dqkv_lo, s);
   else if (mode == 1)
     rc = egv_attn_time_bwd_impl(qkv_hi, qkv_lo, dout_hi, dout_lo, lse, delta, B, T, n, H, dqkv_hi, dqkv_lo, dcls, s);
   else
