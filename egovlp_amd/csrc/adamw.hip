@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t, float lr,
                    (!wh || (((size_t)wh) & 7) == 0) && (!wl || (((size_t)wl) & 7) == 0);
   if (vec) {
     for (long i = base + threadIdx.x * 4; i < end; i += 256 * 4) {
-      f32x4_t pv = *(f32x4_t*)(p + i), gv = *(const f32x4_t*)(g + i), mv = *(f32x4_t*)(m + i), vv = *(f32x4_t*)(v + i);
+      f32x4_t pv = egv_load<EGV_NT_ADAMW_LD, f32x4_t>(p + i), gv = egv_load<EGV_NT_ADAMW_LD, f32x4_t>(g + i),
+               mv = egv_load<EGV_NT_ADAMW_LD, f32x4_t>(m + i), vv = egv_load<EGV_NT_ADAMW_LD, f32x4_t>(v + i);
       bf16_t h[4], l[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -54,9 +55,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t, float lr,
         if (wd > 0.f) pv[e] = pv[e] - lr * wd * pv[e];
         split_bf16(pv[e], h[e], l[e]);
       }
-      *(f32x4_t*)(p + i) = pv;
-      *(f32x4_t*)(m + i) = mv;
-      *(f32x4_t*)(v + i) = vv;
+      egv_store<EGV_NT_ADAMW_ST>(p + i, pv);
+      egv_store<EGV_NT_ADAMW_ST>(m + i, mv);
+      egv_store<EGV_NT_ADAMW_ST>(v + i, vv);
       if (wh) *(u32x2_t*)(wh + i) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
       if (wl) *(u32x2_t*)(wl + i) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
     }

@@ -39,8 +39,8 @@ __device__ __forceinline__ void store_planes4(bf16_t* hi, bf16_t* lo, long off, 
   uint32_t h0, h1, l0, l1;
   split_bf16x2(v[0], v[1], h0, l0);
   split_bf16x2(v[2], v[3], h1, l1);
-  *(u32x2_t*)(hi + off) = (u32x2_t){h0, h1};
-  if (lo) *(u32x2_t*)(lo + off) = (u32x2_t){l0, l1};
+  egv_store<EGV_NT_SPACE_ATTN>(hi + off, (u32x2_t){h0, h1});
+  if (lo) egv_store<EGV_NT_SPACE_ATTN>(lo + off, (u32x2_t){l0, l1});
 }
 
 // ------------------------------------------------------------------------------------------------ dQ

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
         split_bf16x2(o[df][0] * inv, o[df][1] * inv, h0, l0);
         split_bf16x2(o[df][2] * inv, o[df][3] * inv, h1, l1);
         const int d = df * 16 + 4 * gq;
-        *(u32x2_t*)(oh + d) = (u32x2_t){h0, h1};
-        if (ol) *(u32x2_t*)(ol + d) = (u32x2_t){l0, l1};
+        egv_store<EGV_NT_SPACE_ATTN>(oh + d, (u32x2_t){h0, h1});
+        if (ol) egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
       }
       if (gq == 0 && lse) {
         const long srow = tok - grp.tok0;
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         split_bf16x2(o[df][0] * inv, o[df][1] * inv, h0, l0);
         split_bf16x2(o[df][2] * inv, o[df][3] * inv, h1, l1);
         const int d = df * 16 + 4 * gq;
-        *(u32x2_t*)(oh + d) = (u32x2_t){h0, h1};
-        *(u32x2_t*)(ol + d) = (u32x2_t){l0, l1};
+        egv_store<EGV_NT_SPACE_ATTN>(oh + d, (u32x2_t){h0, h1});
+        egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
       }
       if (gq == 0 && lse) lse[((long)grp.b * g.H + grp.h) * g.S + (qtok - grp.tok0)] = m + __logf(l);
     }

@@ -71,14 +71,14 @@ __device__ __forceinline__ void ldp(const bf16_t* __restrict__ ph, const bf16_t*
   }
 }
 
-template <int CPL>
+template <int CPL, int SITE = 0>
 __device__ __forceinline__ void stp(bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long off, const float (&x)[CPL]) {
   if (CPL == 4) {
     uint32_t h0, h1, l0, l1;
     split_bf16x2(x[0], x[1], h0, l0);
     split_bf16x2(x[CPL > 2 ? 2 : 0], x[CPL > 3 ? 3 : 0], h1, l1);
-    *(u32x2_t*)(ph + off) = (u32x2_t){h0, h1};
-    if (pl) *(u32x2_t*)(pl + off) = (u32x2_t){l0, l1};
+    egv_store<SITE>(ph + off, (u32x2_t){h0, h1});
+    if (pl) egv_store<SITE>(pl + off, (u32x2_t){l0, l1});
     return;
   }
   bf16_t h[CPL], l[CPL];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_time_fwd_kernel(const bf16_t* __rest
 #pragma unroll
       for (int c = 0; c < CPL; ++c) o[c] *= inv;
       const long tok = (long)b * S + 1 + (long)f * n + i;
-      stp<CPL>(out_hi, out_lo, tok * HD + (long)head * D + ch, o);
+      stp<CPL, EGV_NT_ATTN_OUT>(out_hi, out_lo, tok * HD + (long)head * D + ch, o);
       if (lane % LPH == 0 && lse) lse[((long)b * H + head) * S + 1 + (long)f * n + i] = m + __logf(l);
     }
   }
@@ -247,8 +247,8 @@ __device__ __forceinline__ void stp8(bf16_t* __restrict__ ph, bf16_t* __restrict
   split_bf16x2(x[2], x[3], h1, l1);
   split_bf16x2(x[4], x[5], h2, l2);
   split_bf16x2(x[6], x[7], h3, l3);
-  *(u32x4_t*)(ph + off) = (u32x4_t){h0, h1, h2, h3};
-  if (pl) *(u32x4_t*)(pl + off) = (u32x4_t){l0, l1, l2, l3};
+  egv_store16<EGV_NT_ATTN_OUT>(ph + off, (u32x4_t){h0, h1, h2, h3});
+  if (pl) egv_store16<EGV_NT_ATTN_OUT>(pl + off, (u32x4_t){l0, l1, l2, l3});
 }
 
 // DBG (diagnostics build only): 1 = everything but the output stores, 2 = the loads alone
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void at
       } else {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) dq[c] *= 0.125f;
-        stp<CPL>(gb, gbl, (unsigned)(tok * ts) + hc, dq);
+        stp<CPL, EGV_NT_TIME_BWD>(gb, gbl, (unsigned)(tok * ts) + hc, dq);
       }
     }
 #pragma unroll
@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void at
         const unsigned to = (unsigned)((1 + j * n + i) * ts) + hc;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) dk[j][c] *= 0.125f;
-        stp<CPL>(gb, gbl, to + HD, dk[j]);
-        stp<CPL>(gb, gbl, to + 2 * HD, dv[j]);
+        stp<CPL, EGV_NT_TIME_BWD>(gb, gbl, to + HD, dk[j]);
+        stp<CPL, EGV_NT_TIME_BWD>(gb, gbl, to + 2 * HD, dv[j]);
       }
     }
   }

@@ -30,6 +30,31 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     if (e__ != hipSuccess) return EGV_ERR_LAUNCH + (int)e__; \
   } while (0)
 
+// Global store / load, optionally non-temporal (streaming: `global_store ... nt`).  Which streams use it is a per-site
+// compile-time choice (EGV_NT_MASK bits; Makefile `nt` target builds A/B libraries):
+//   1 what fc1 saves for backward (read a whole forward later)   2 time-attention forward output planes
+//   4 plane outputs of the GEMM epilogues                         8 fp32 GEMM outputs
+//  16 LayerNorm outputs (fwd planes / fp32, bwd dx + planes)      32 AdamW stores (p, m, v)      64 AdamW loads (g, m, v, p)
+// 128 reduced weight gradients (split-K reduce output)           256 space-attention outputs (fwd / bwd, 8-byte pieces)
+// 512 time-attention backward outputs
+#ifndef EGV_NT_MASK
+#define EGV_NT_MASK 7
+#endif
+enum { EGV_NT_SAVED = 1, EGV_NT_ATTN_OUT = 2, EGV_NT_GEMM_PLANES = 4, EGV_NT_GEMM_F32 = 8, EGV_NT_LN = 16, EGV_NT_ADAMW_ST = 32,
+       EGV_NT_ADAMW_LD = 64, EGV_NT_WGRAD = 128, EGV_NT_SPACE_ATTN = 256, EGV_NT_TIME_BWD = 512 };
+template <int SITE, typename V>
+__device__ __forceinline__ void egv_store(void* p, V v) {
+  if constexpr ((EGV_NT_MASK & SITE) != 0) __builtin_nontemporal_store(v, (V*)p);
+  else *(V*)p = v;
+}
+template <int SITE, typename V>
+__device__ __forceinline__ void egv_store16(void* p, V v) { egv_store<SITE, V>(p, v); }
+template <int SITE, typename V>
+__device__ __forceinline__ V egv_load(const void* p) {
+  if constexpr ((EGV_NT_MASK & SITE) != 0) return __builtin_nontemporal_load((const V*)p);
+  else return *(const V*)p;
+}
+
 // ---- bf16 <-> f32 -----------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

@@ -913,7 +913,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             static_for<0, 8>([&](auto Tc) {
               constexpr int it = decltype(Tc)::value;
               const f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5))) + bias4 + pre[it < NPF ? it : 0];
-              *(f32x4_t*)d = val;
+              egv_store16<EGV_NT_GEMM_F32>(d, val);
               d += ld2;
             });
           }
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
               f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5)));
               if (EPI == EPI_LINEAR) val += bias4;
-              *(f32x4_t*)d = val;
+              egv_store16<EGV_NT_GEMM_F32>(d, val);
               d += ld2;
             }
           }
@@ -979,8 +979,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
               v1[e] *= c1;
             }
             if (dz) {
-              *(u32x4_t*)dz = (u32x4_t){f32x2_to_bf16x2(s0[0], s0[1]), f32x2_to_bf16x2(s0[2], s0[3]),
-                                        f32x2_to_bf16x2(s1[0], s1[1]), f32x2_to_bf16x2(s1[2], s1[3])};
+              egv_store16<EGV_NT_SAVED>(dz, (u32x4_t){f32x2_to_bf16x2(s0[0], s0[1]), f32x2_to_bf16x2(s0[2], s0[3]),
+                                        f32x2_to_bf16x2(s1[0], s1[1]), f32x2_to_bf16x2(s1[2], s1[3])});
               dz += ldz4;
             }
           } else if constexpr (EPI == EPI_GELU_BWD) {
@@ -1008,8 +1008,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           split_bf16x2(v0[2], v0[3], h1, l1);
           split_bf16x2(v1[0], v1[1], h2, l2);
           split_bf16x2(v1[2], v1[3], h3, l3);
-          *(u32x4_t*)dh = (u32x4_t){h0, h1, h2, h3};
-          if (dlo) *(u32x4_t*)(dh + dlo) = (u32x4_t){l0, l1, l2, l3};
+          egv_store16<EGV_NT_GEMM_PLANES>(dh, (u32x4_t){h0, h1, h2, h3});
+          if (dlo) egv_store16<EGV_NT_GEMM_PLANES>(dh + dlo, (u32x4_t){l0, l1, l2, l3});
           dh += ld4;
         };
 #pragma unroll 1

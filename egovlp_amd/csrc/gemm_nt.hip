@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   f32x4_t s = *(const f32x4_t*)(partial + i4);
   for (int z = 1; z < ksplit; ++z) s += *(const f32x4_t*)(partial + (long)z * mn + i4);
   if (accumulate) s += *(const f32x4_t*)(out + i4);
-  *(f32x4_t*)(out + i4) = s;
+  egv_store<EGV_NT_WGRAD>(out + i4, s);
 }
 
 }  // namespace

@@ -59,13 +59,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
       f32x4_t y;
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-      if (yf) *(f32x4_t*)(yf + (long)row * ldy + c4 * 4) = y;
+      if (yf) egv_store<EGV_NT_LN>(yf + (long)row * ldy + c4 * 4, y);
       if (yhi) {
         bf16_t h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) split_bf16(y[e], h[e], l[e]);
-        *(u32x2_t*)(yhi + (long)row * ldy + c4 * 4) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
-        if (ylo) *(u32x2_t*)(ylo + (long)row * ldy + c4 * 4) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+        egv_store<EGV_NT_LN>(yhi + (long)row * ldy + c4 * 4, (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])});
+        if (ylo) egv_store<EGV_NT_LN>(ylo + (long)row * ldy + c4 * 4, (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])});
       }
     }
   }
@@ -145,13 +145,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
         if (add1) o += *(const f32x4_t*)(add1 + (long)row * lddx + c4 * 4);
         if (add2) o += *(const f32x4_t*)(add2 + (long)row * lddx + c4 * 4);
-        *(f32x4_t*)(dx + (long)row * lddx + c4 * 4) = o;
+        egv_store<EGV_NT_LN>(dx + (long)row * lddx + c4 * 4, o);
         if (dxh) {   // the same gradient as the next GEMM's operand (row-major split-bf16 planes, ld = cols)
           bf16_t h[4], l[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) split_bf16(o[e], h[e], l[e]);
-          *(u32x2_t*)(dxh + (long)row * cols + c4 * 4) = (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])};
-          if (dxl) *(u32x2_t*)(dxl + (long)row * cols + c4 * 4) = (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])};
+          egv_store<EGV_NT_LN>(dxh + (long)row * cols + c4 * 4, (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])});
+          if (dxl) egv_store<EGV_NT_LN>(dxl + (long)row * cols + c4 * 4, (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])});
         }
       }
     }
