@@ -226,14 +226,14 @@ __device__ __forceinline__ float row8_sum(float v) {
   return v;
 }
 __device__ __forceinline__ void ldp8(const bf16_t* __restrict__ ph, const bf16_t* __restrict__ pl, long off, float (&x)[8]) {
-  const u32x4_t a = *(const u32x4_t*)(ph + off);
+  const u32x4_t a = egv_load<EGV_NT_TIME_LD, u32x4_t>(ph + off);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     x[2 * e] = __uint_as_float(a[e] << 16);
     x[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
   }
   if (pl) {
-    const u32x4_t b = *(const u32x4_t*)(pl + off);
+    const u32x4_t b = egv_load<EGV_NT_TIME_LD, u32x4_t>(pl + off);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       x[2 * e] += __uint_as_float(b[e] << 16);

@@ -870,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       }
     }
     auto pf_issue = [&]() {
-      static_for<0, NPF>([&](auto Tc) { pre[decltype(Tc)::value] = *(const f32x4_t*)pf_ptr; pf_ptr += pf_ld; });
+      static_for<0, NPF>([&](auto Tc) { pre[decltype(Tc)::value] = egv_load<EGV_NT_EPI_LD, f32x4_t>(pf_ptr); pf_ptr += pf_ld; });
     };
     __builtin_amdgcn_sched_barrier(0);
     if (has_next) {

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
   const long i4 = ((long)((int)blockIdx.x >= blocks1 ? (int)blockIdx.x - blocks1 : (int)blockIdx.x) * blockDim.x + threadIdx.x) * 4;
   if (i4 >= mn) return;
-  f32x4_t s = *(const f32x4_t*)(partial + i4);
-  for (int z = 1; z < ksplit; ++z) s += *(const f32x4_t*)(partial + (long)z * mn + i4);
+  f32x4_t s = egv_load<EGV_NT_REDUCE_LD, f32x4_t>(partial + i4);
+  for (int z = 1; z < ksplit; ++z) s += egv_load<EGV_NT_REDUCE_LD, f32x4_t>(partial + (long)z * mn + i4);
   if (accumulate) s += *(const f32x4_t*)(out + i4);
   egv_store<EGV_NT_WGRAD>(out + i4, s);
 }
