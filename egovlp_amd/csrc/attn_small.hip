@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void at
       } else {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) dq[c] *= 0.125f;
-        stp<CPL, EGV_NT_TIME_BWD>(gb, gbl, (unsigned)(tok * ts) + hc, dq);
+        stp<CPL, (CPL >= 4 ? EGV_NT_TIME_BWD : 0)>(gb, gbl, (unsigned)(tok * ts) + hc, dq);
       }
     }
 #pragma unroll
@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void at
         const unsigned to = (unsigned)((1 + j * n + i) * ts) + hc;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) dk[j][c] *= 0.125f;
-        stp<CPL, EGV_NT_TIME_BWD>(gb, gbl, to + HD, dk[j]);
-        stp<CPL, EGV_NT_TIME_BWD>(gb, gbl, to + 2 * HD, dv[j]);
+        stp<CPL, (CPL >= 4 ? EGV_NT_TIME_BWD : 0)>(gb, gbl, to + HD, dk[j]);
+        stp<CPL, (CPL >= 4 ? EGV_NT_TIME_BWD : 0)>(gb, gbl, to + 2 * HD, dv[j]);
       }
     }
   }
@@ -648,7 +648,10 @@ template <int TMAX>
 int launch_time_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
                     const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s) {
   const int chunks = (n + 15) / 16;
-  static const int want4 = getenv("EGV_TIME_HPW") ? atoi(getenv("EGV_TIME_HPW")) == 4 : 0;   // A/B diagnostics
+  // four heads per wave = 8-byte lanes, one full 128-B line per head and store instruction (which is what lets the outputs
+  // stream, csrc/common.h EGV_NT_TIME_BWD): 128 -> 99 us per call at B=32 (profiles/r02_tb_time_attention_bwd.txt);
+  // EGV_TIME_HPW=2 selects the 4-byte-lane kernel for A/B
+  static const int want4 = getenv("EGV_TIME_HPW") ? atoi(getenv("EGV_TIME_HPW")) == 4 : 1;
   if (H % 4 == 0 && TMAX <= 4 && want4) {
     EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
                lse, delta, B, T, n, H, gh, gl, dcls);

@@ -36,10 +36,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 //   4 plane outputs of the GEMM epilogues                         8 fp32 GEMM outputs
 //  16 LayerNorm outputs (fwd planes / fp32, bwd dx + planes)      32 AdamW stores (p, m, v)      64 AdamW loads (g, m, v, p)
 // 128 reduced weight gradients (split-K reduce output)           256 space-attention outputs (fwd / bwd, 8-byte pieces)
-// 512 time-attention backward outputs   1024 LOADS of the GEMM epilogue (residual / saved gelu')   2048 LOADS of time attention fwd
+// 512 time-attention backward outputs (8-byte-lane kernel only)   1024 LOADS of the GEMM epilogue (residual / saved gelu')   2048 LOADS of time attention fwd
 // 4096 LOADS of the split-K reduce
 #ifndef EGV_NT_MASK
-#define EGV_NT_MASK 7
+#define EGV_NT_MASK 519
 #endif
 enum { EGV_NT_SAVED = 1, EGV_NT_ATTN_OUT = 2, EGV_NT_GEMM_PLANES = 4, EGV_NT_GEMM_F32 = 8, EGV_NT_LN = 16, EGV_NT_ADAMW_ST = 32,
        EGV_NT_ADAMW_LD = 64, EGV_NT_WGRAD = 128, EGV_NT_SPACE_ATTN = 256, EGV_NT_TIME_BWD = 512,
