@@ -33,17 +33,19 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 // Global store / load, optionally non-temporal (streaming: `global_store ... nt`).  Which streams use it is a per-site
 // compile-time choice (EGV_NT_MASK bits; Makefile `nt` target builds A/B libraries):
 //   1 what fc1 saves for backward (read a whole forward later)   2 time-attention forward output planes
-//   4 plane outputs of the GEMM epilogues                         8 fp32 GEMM outputs
+//   4 plane outputs of the plain GEMM epilogue (qkv, dgrad dX)  8 fp32 GEMM outputs   8192 h planes of the GELU epilogue
+// 16384 dZ planes of the GELU' epilogue
 //  16 LayerNorm outputs (fwd planes / fp32, bwd dx + planes)      32 AdamW stores (p, m, v)      64 AdamW loads (g, m, v, p)
 // 128 reduced weight gradients (split-K reduce output)           256 space-attention outputs (fwd / bwd, 8-byte pieces)
 // 512 time-attention backward outputs (8-byte-lane kernel only)   1024 LOADS of the GEMM epilogue (residual / saved gelu')   2048 LOADS of time attention fwd
 // 4096 LOADS of the split-K reduce
 #ifndef EGV_NT_MASK
-#define EGV_NT_MASK 519
+#define EGV_NT_MASK (519 + 8192 + 16384)
 #endif
 enum { EGV_NT_SAVED = 1, EGV_NT_ATTN_OUT = 2, EGV_NT_GEMM_PLANES = 4, EGV_NT_GEMM_F32 = 8, EGV_NT_LN = 16, EGV_NT_ADAMW_ST = 32,
        EGV_NT_ADAMW_LD = 64, EGV_NT_WGRAD = 128, EGV_NT_SPACE_ATTN = 256, EGV_NT_TIME_BWD = 512,
-       EGV_NT_EPI_LD = 1024, EGV_NT_TIME_LD = 2048, EGV_NT_REDUCE_LD = 4096 };
+       EGV_NT_EPI_LD = 1024, EGV_NT_TIME_LD = 2048, EGV_NT_REDUCE_LD = 4096,
+       EGV_NT_GELU_PLANES = 8192, EGV_NT_GELUBWD_PLANES = 16384 };
 template <int SITE, typename V>
 __device__ __forceinline__ void egv_store(void* p, V v) {
   if constexpr ((EGV_NT_MASK & SITE) != 0) __builtin_nontemporal_store(v, (V*)p);

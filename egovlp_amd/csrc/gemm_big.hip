@@ -1008,8 +1008,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           split_bf16x2(v0[2], v0[3], h1, l1);
           split_bf16x2(v1[0], v1[1], h2, l2);
           split_bf16x2(v1[2], v1[3], h3, l3);
-          egv_store16<EGV_NT_GEMM_PLANES>(dh, (u32x4_t){h0, h1, h2, h3});
-          if (dlo) egv_store16<EGV_NT_GEMM_PLANES>(dh + dlo, (u32x4_t){l0, l1, l2, l3});
+          constexpr int PSITE = (EPI == EPI_GELU) ? EGV_NT_GELU_PLANES : ((EPI == EPI_GELU_BWD) ? EGV_NT_GELUBWD_PLANES : EGV_NT_GEMM_PLANES);
+          egv_store16<PSITE>(dh, (u32x4_t){h0, h1, h2, h3});
+          if (dlo) egv_store16<PSITE>(dh + dlo, (u32x4_t){l0, l1, l2, l3});
           dh += ld4;
         };
 #pragma unroll 1
