@@ -117,3 +117,18 @@ def test_checkpoint_with_unimportable_config_object_and_module_prefix(tmp_path):
     m4 = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
                       load_checkpoint=path)
     assert torch.equal(m4.video_model.temporal_embed, vals16["video_model.temporal_embed"][:, :4])
+
+
+def test_eval_token_padding_for_graph_replay():
+    """`_pad_tokens` (EgoMCQ validation with args.graph_eval): captions are right-padded to a multiple of 8 tokens with [PAD]
+    ids and masked positions, so a handful of captured graphs covers every caption length; shorter-than-multiple inputs keep
+    their content, exact multiples are returned untouched."""
+    import torch
+    from egovlp_amd.trainer.trainer_egoclip import _pad_tokens
+    t = {"input_ids": torch.arange(1, 12).view(1, 11), "attention_mask": torch.ones(1, 11, dtype=torch.long)}
+    p = _pad_tokens(t, 8)
+    assert p["input_ids"].shape == (1, 16) and p["attention_mask"].shape == (1, 16)
+    assert torch.equal(p["input_ids"][:, :11], t["input_ids"]) and int(p["input_ids"][:, 11:].abs().sum()) == 0
+    assert int(p["attention_mask"].sum()) == 11
+    t16 = {"input_ids": torch.ones(2, 16, dtype=torch.long), "attention_mask": torch.ones(2, 16, dtype=torch.long)}
+    assert _pad_tokens(t16, 8) is t16
