@@ -579,9 +579,13 @@ __global__ __launch_bounds__(256) void attn_cls_combine_kernel(const float* __re
 __global__ __launch_bounds__(64) void attn_cls_delta_kernel(const bf16_t* __restrict__ oh, const bf16_t* __restrict__ ol,
                                                             const bf16_t* __restrict__ doh,
                                                             const bf16_t* __restrict__ dol, int S, int H,
-                                                            float* __restrict__ delta) {
+                                                            float* __restrict__ delta, float* __restrict__ dcls) {
   const int lane = threadIdx.x;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
+  if (dcls) {   // this (clip, head)'s raw dq / dk / dv accumulators start at zero: saves a memset node per attention backward
+    float* a = dcls + (long)blockIdx.x * 192;
+    a[lane] = 0.f; a[64 + lane] = 0.f; a[128 + lane] = 0.f;
+  }
   const long off = (long)b * S * H * D + (long)h * D + lane;
   float o = bf16_to_f32(oh[off]), g = bf16_to_f32(doh[off]);
   if (ol) o += bf16_to_f32(ol[off]);
@@ -693,8 +697,8 @@ int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_
 }
 
 int egv_attn_cls_delta_impl(const bf16_t* oh, const bf16_t* ol, const bf16_t* doh, const bf16_t* dol, int B, int S, int H,
-                            float* delta, hipStream_t s) {
-  EGV_LAUNCH(attn_cls_delta_kernel, dim3(B * H), dim3(64), 0, s, oh, ol, doh, dol, S, H, delta);
+                            float* delta, float* dcls, hipStream_t s) {
+  EGV_LAUNCH(attn_cls_delta_kernel, dim3(B * H), dim3(64), 0, s, oh, ol, doh, dol, S, H, delta, dcls);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

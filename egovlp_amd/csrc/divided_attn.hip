@@ -18,7 +18,7 @@ int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh
 int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse,
                               hipStream_t s);
 int egv_attn_cls_delta_impl(const bf16_t* oh, const bf16_t* ol, const bf16_t* doh, const bf16_t* dol, int B, int S, int H,
-                            float* delta, hipStream_t s);
+                            float* delta, float* dcls, hipStream_t s);
 int egv_attn_cls_finish_impl(const float* dcls, int B, int S, int H, bf16_t* gh, bf16_t* gl, hipStream_t s);
 
 extern "C" int64_t egv_divided_attn_fwd_work_floats(int32_t B, int32_t T, int32_t n, int32_t H, int32_t mode) {
@@ -63,8 +63,7 @@ extern "C" int egv_divided_attn_bwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_
   const int S = 1 + T * n;
   float* delta = work;                          // [B, H, S]
   float* dcls = work + (long)B * H * S;         // [B, H, 3, 64] raw fp32 accumulators of the CLS token
-  if (hipMemsetAsync(dcls, 0, sizeof(float) * (size_t)B * H * 192, s) != hipSuccess) return EGV_ERR_LAUNCH;
-  int rc = egv_attn_cls_delta_impl(out_hi, out_lo, dout_hi, dout_lo, B, S, H, delta, s);
+  int rc = egv_attn_cls_delta_impl(out_hi, out_lo, dout_hi, dout_lo, B, S, H, delta, dcls, s);   // also zeroes dcls
   if (rc) return rc;
   if (mode == 0)
     rc = egv_attn_space_bwd_impl(qkv_hi, qkv_lo, out_hi, out_lo, dout_hi, dout_lo, lse, delta, dcls, B, T, n, H, passes,
