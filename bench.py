@@ -266,7 +266,9 @@ def main():
         step_frac = pairs / world * FWD_GFLOP_PER_PAIR[key] * 3 * 1e9 / (PEAK_BF16_TFLOPS * 1e12)
 
     out = {
-        "metric": "clip-pairs/sec (whole node), 4f/224^2 ViT-B + 32-tok text, B=32/GPU, train step (fwd+gather+EgoNCE+bwd+AdamW)",
+        "metric": "clip-pairs/sec (whole node), 4f/224^2 ViT-B + 32-tok text, B=32/GPU, train step (fwd+gather+EgoNCE+bwd+AdamW)"
+                  if (T, B, args.arch) == (4, 32, "base_patch16_224") else
+                  f"clip-pairs/sec (whole node), {T}f/224^2 {args.arch} + 32-tok text, B={B}/GPU, train step (fwd+gather+EgoNCE+bwd+AdamW)",
         "value": round(pairs, 2), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
