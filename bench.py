@@ -177,7 +177,7 @@ def main():
         grad_sync = Bf16GradSync(model.parameters())
     from egovlp_amd import _lib
     grid = args.gemm_grid or (248 if world > 1 else 256)
-    _lib.lib().egv_gemm_set_grid(grid)
+    ops.set_gemm_grid(grid)
     ops.WGRAD_SIDE_STREAM = bool(args.wgrad_side)
     ops.TEXT_SIDE_STREAM = bool(args.text_side)
     opt = AdamW(model.parameters(), lr=3e-5)

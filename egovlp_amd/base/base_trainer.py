@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from abc import abstractmethod
 
+import os
+
 import torch
 import torch.distributed as dist
 from numpy import inf
@@ -40,8 +42,12 @@ class Multi_BaseTrainer_dist:
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.grad_sync = None
         if self.world_size > 1:
+            from .. import ops
             from ..dist import Bf16GradSync
             self.grad_sync = Bf16GradSync(self.model.parameters())
+            # the persistent GEMM owns every CU for the length of a launch: leave one CU per XCD to the RCCL kernels of the
+            # overlapped gradient exchange (bench.py does the same; the wgrad split-K policy follows the cap)
+            ops.set_gemm_grid(int(os.environ.get("EGV_GEMM_GRID", "248")))
         self.loss = loss.to(self.device) if hasattr(loss, 'to') else loss
         self.metrics = metrics
         self.optimizer = optimizer

@@ -205,6 +205,20 @@ def zeros(shape, dtype=torch.float32, device="cuda"):
     return t
 
 
+# Persistent-workgroup cap of the big GEMM (egv_gemm_set_grid): 256 = one per CU; data-parallel runs lower it so that the RCCL
+# kernels of the overlapped gradient exchange find free CUs.  Kept here too because the wgrad split-K policy depends on it.
+GEMM_GRID = 256
+
+
+def set_gemm_grid(workgroups: int) -> int:
+    """-> the previous cap.  Multiples of 8 in [8, 256]."""
+    global GEMM_GRID
+    prev = _lib.lib().egv_gemm_set_grid(int(workgroups))
+    if 8 <= workgroups <= 256 and workgroups % 8 == 0:
+        GEMM_GRID = int(workgroups)
+    return prev
+
+
 def pad32(n):
     return (n + 31) // 32 * 32
 
@@ -287,9 +301,11 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         gemm_nt(a_t, b_t, passes=passes, out_f32=out_f32, ksplit=pick_ksplit(M, N, Kc), K=Kc)
         return cs
     if ksplit is None:
+        # as many k-slices as fit ONE round of the persistent grid (256 workgroups, or the data-parallel cap: a slice count
+        # sized for 256 on a 248-workgroup grid would spill 4 work units into a second round and double the wgrad's time)
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
         nkt = (Kd + 63) // 64
-        ksplit = max(1, min(256 // max(tiles, 1), nkt // 2))
+        ksplit = max(1, min(GEMM_GRID // max(tiles, 1), nkt // 2))
     d = GemmDesc()
     d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
     d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
