@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("EGV_ADAMW_OVERLAP", "0")),
                     help="1: AdamW updates enqueued from grad-ready hooks on a side stream under the rest of backward "
                          "(single GPU only; bit-identical results)")
+    ap.add_argument("--rccl-channels", type=int, default=0, help="N>1: cap RCCL at this many channels (= workgroups) via "
+                    "NCCL_MAX_NCHANNELS, e.g. 8 to match the CUs the 248-workgroup GEMM grid leaves free (default: RCCL's choice)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL process group, DDP wrapper and the fused all-gather even at world size 1 "
                          "(smoke test of the N>1 code path on a 1-GPU box)")
@@ -148,6 +150,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        if args.rccl_channels > 0:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
         if args.force_dist:
             os.environ["EGV_FORCE_GATHER"] = "1"
@@ -304,6 +308,7 @@ def main():
         dist.all_gather(allr, mine)
         allr = torch.stack(allr).cpu()
         out["comm"] = {"rccl_ranks": world, "backend": dist.get_backend(), "gemm_grid": grid,
+                       "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS", "default"),
                        "gradient_exchange": "DDP fp32 buckets" if args.ddp else "Bf16GradSync (bf16 buckets, async all-reduce from grad hooks)",
                        "grad_sync": None if grad_sync is None else {k: int(v) for k, v in grad_sync.stats.items() if k == "buckets"},
                        "ms_per_step_rank_min": round(float(allr[:, 0].min()), 3), "ms_per_step_rank_max": round(float(allr[:, 0].max()), 3),
