@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime initialises: see egovlp_amd/__init__.py
+
 import torch
 import torch.distributed as dist
 
@@ -123,8 +125,8 @@ def main():
                     "egovlp_amd.dist.Bf16GradSync (A/B of the gradient exchange)")
     ap.add_argument("--gemm-grid", type=int, default=0, help="persistent workgroups of the big GEMM (default: 256 at N=1, "
                     "248 at N>1 so that the overlapped RCCL kernels find free CUs)")
-    ap.add_argument("--wgrad-side", type=int, default=int(os.environ.get("EGV_WGRAD_SIDE", "0")),
-                    help="1: weight-gradient GEMMs on a second HIP stream (egovlp_amd.ops.side_stream)")
+    ap.add_argument("--wgrad-side", type=int, default=int(os.environ.get("EGV_WGRAD_SIDE", "1")),
+                    help="1 (default): weight-gradient GEMMs on their own HIP stream (egovlp_amd.ops.side_stream); 0: on the main stream")
     ap.add_argument("--text-side", type=int, default=int(os.environ.get("EGV_TEXT_SIDE", "1")),
                     help="1 (default): the DistilBERT tower on a second HIP stream under the video tower; 0: one stream")
     ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("EGV_ADAMW_OVERLAP", "0")),
@@ -132,6 +134,10 @@ def main():
                          "(single GPU only; bit-identical results)")
     ap.add_argument("--rccl-channels", type=int, default=0, help="N>1: cap RCCL at this many channels (= workgroups) via "
                     "NCCL_MAX_NCHANNELS, e.g. 8 to match the CUs the 248-workgroup GEMM grid leaves free (default: RCCL's choice)")
+    ap.add_argument("--grad-sync-hooks", type=int, default=0, help="N>1: 1 = launch the gradient buckets from autograd "
+                    "grad-ready hooks; 0 (default) = hook-free, from the block-boundary poll")
+    ap.add_argument("--no-grad-sync", action="store_true", help="diagnostics: process group and embedding gather, but no "
+                    "gradient exchange (what does the distributed environment itself cost?)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL process group, DDP wrapper and the fused all-gather even at world size 1 "
                          "(smoke test of the N>1 code path on a 1-GPU box)")
@@ -176,9 +182,13 @@ def main():
     if use_dist and args.ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=100,
                                                         gradient_as_bucket_view=True)
-    elif use_dist:
+    elif use_dist and not args.no_grad_sync:
         from egovlp_amd.dist import Bf16GradSync
-        grad_sync = Bf16GradSync(model.parameters())
+        if args.grad_sync_hooks:
+            grad_sync = Bf16GradSync(model.parameters(), stream_of=model.gradient_stream_of)
+        else:     # hook-free: buckets launched from the block-boundary poll (egovlp_amd.ops.BACKWARD_POLL)
+            grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order())
+            ops.BACKWARD_POLL = grad_sync.poll
     from egovlp_amd import _lib
     grid = args.gemm_grid or (248 if world > 1 else 256)
     ops.set_gemm_grid(grid)
@@ -186,11 +196,13 @@ def main():
     ops.TEXT_SIDE_STREAM = bool(args.text_side)
     opt = AdamW(model.parameters(), lr=3e-5)
     if args.adamw_overlap and grad_sync is None and not args.ddp:
-        opt.overlap_backward()
+        opt.overlap_backward(stream_of=model.gradient_stream_of)
     loss_fn = EgoNCE()
     batch = synth_batch(B, T=T, L=L, seed=1234, rank=rank)
     data = {"video": batch["video"].cuda(), "text": {k: v.cuda() for k, v in batch["text"].items()},
             "noun_vec": batch["noun_vec"].cuda(), "verb_vec": batch["verb_vec"].cuda()}
+
+    HOST = {}
 
     def barrier():
         if use_dist:
@@ -204,6 +216,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = egoclip_step(net, loss_fn, opt, data, world, rank, grad_sync=grad_sync)
+        HOST["enqueue_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3     # when the host was done enqueueing
         barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -283,6 +296,7 @@ def main():
                    "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
                                "adamw_overlapped_with_backward": bool(args.adamw_overlap and grad_sync is None and not args.ddp)}},
         "loss": round(loss_val, 5),
+        "host_enqueue_ms_per_step": round(HOST.get("enqueue_ms_per_step", 0.0), 3),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
     }
     if roof is not None:

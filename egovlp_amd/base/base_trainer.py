@@ -44,7 +44,14 @@ class Multi_BaseTrainer_dist:
         if self.world_size > 1:
             from .. import ops
             from ..dist import Bf16GradSync
-            self.grad_sync = Bf16GradSync(self.model.parameters())
+            if hasattr(self.model, "gradient_ready_order"):
+                # hook-free: buckets are launched from the block-boundary poll of the video tower's backward (autograd
+                # grad-ready hooks cost 0.6 ms per step more on this model, profiles/r02_d_dp_overhead.txt)
+                self.grad_sync = Bf16GradSync(self.model.parameters(), use_hooks=False,
+                                              order_hint=self.model.gradient_ready_order())
+                ops.BACKWARD_POLL = self.grad_sync.poll
+            else:
+                self.grad_sync = Bf16GradSync(self.model.parameters(), stream_of=getattr(self.model, "gradient_stream_of", None))
             # the persistent GEMM owns every CU for the length of a launch: leave one CU per XCD to the RCCL kernels of the
             # overlapped gradient exchange (bench.py does the same; the wgrad split-K policy follows the cap)
             ops.set_gemm_grid(int(os.environ.get("EGV_GEMM_GRID", "248")))

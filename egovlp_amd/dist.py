@@ -84,7 +84,21 @@ class _Bucket:
 
 class Bf16GradSync:
     def __init__(self, params, process_group=None, bucket_mb: float = 64.0,
-                 pack_fn: Optional[Callable] = None, unpack_fn: Optional[Callable] = None, broadcast: bool = True):
+                 pack_fn: Optional[Callable] = None, unpack_fn: Optional[Callable] = None, broadcast: bool = True,
+                 stream_of: Optional[Callable] = None, use_hooks: bool = True, order_hint: Optional[List] = None):
+        """`stream_of(param)` -> the HIP stream that parameter's gradient is produced on (None: the current one).  A grad-ready
+        hook keeps the parameter's AccumulateGrad node alive across iterations, and autograd runs that node on the stream
+        that was current WHEN THE HOOK WAS REGISTERED: for the text tower (its backward runs on its own stream,
+        ops.TEXT_SIDE_STREAM) a hook registered on the default stream makes the default stream wait for the text stream at
+        every text gradient -- the two towers serialise (measured: -1.2 ms of the overlap, profiles/r02_d_*).
+
+        `use_hooks=False`: no autograd hooks at all.  Merely HAVING 327 post-accumulate-grad hooks costs 1.7 ms of GPU time per
+        step on this model (measured with empty hook bodies, profiles/r02_d_dp_overhead.txt); instead the owner calls `poll()`
+        at points of backward where earlier gradients are known to be final (egovlp_amd.ops.BACKWARD_POLL, invoked at the entry
+        of every SpaceTimeBlock backward): every bucket whose parameters all have a gradient is packed and all-reduced there.
+        Needs `zero_grad(set_to_none=True)` (a gradient is "ready" when it is not None) and `order_hint`, the parameters in
+        the order their gradients become final (buckets are cut along it)."""
+        self.use_hooks = use_hooks
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("Bf16GradSync: no trainable parameters")
@@ -108,7 +122,25 @@ class Bf16GradSync:
         self._bucket_of = {}
         self._seen = set()
         self.stats = {"buckets": 0, "collectives_last_step": 0, "bytes_last_step": 0}
-        self._handles = [p.register_post_accumulate_grad_hook(self._on_ready) for p in self.params]
+        self._handles = []
+        if not use_hooks:
+            if order_hint is not None:
+                hinted = [p for p in order_hint if p.requires_grad]
+                if {id(p) for p in hinted} != {id(p) for p in self.params}:
+                    raise ValueError("Bf16GradSync: order_hint must be a permutation of the trainable parameters")
+                self._ready_order = [self._index[id(p)] for p in hinted]
+            else:
+                self._ready_order = list(range(len(self.params)))[::-1]
+            self._seen = set(self._ready_order)
+            self._build_buckets()
+            self._next = 0
+        for p in (self.params if use_hooks else []):
+            st = stream_of(p) if stream_of is not None else None
+            if st is not None and p.is_cuda:
+                with torch.cuda.stream(st):
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._on_ready))
+            else:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_ready))
 
     # ---- hooks (run on the autograd engine thread, in the order gradients become final) ----------------------------
     def _on_ready(self, p):
@@ -125,7 +157,12 @@ class Bf16GradSync:
         if b.pending == 0:
             self._launch(b)
 
+    _DIAG = __import__("os").environ.get("EGV_SYNC_DIAG", "")     # diagnostics: "hooks" = no pack / reduce / unpack, "noreduce"
+
     def _launch(self, b: _Bucket):
+        if self._DIAG == "hooks":
+            b.work = False
+            return
         if self.pack_fn is _hip_pack:
             from . import ops
             ops.join_streams_for_gradient_hook()      # gradients are produced on up to three streams (ops.side_stream, text tower)
@@ -134,9 +171,23 @@ class Bf16GradSync:
             if g is None or g.dtype != torch.float32 or not g.is_contiguous():
                 raise RuntimeError("Bf16GradSync needs dense contiguous fp32 gradients")
         self.pack_fn(grads, b.flat, b.offsets, 1.0 / self.world)
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self._DIAG == "noreduce":
+            b.work = False
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.stats["collectives_last_step"] += 1
         self.stats["bytes_last_step"] += b.numel * 2
+
+    def poll(self):
+        """Hook-free mode: launch every not-yet-launched bucket (in order) whose parameters all have their gradient."""
+        if self.use_hooks or self._buckets is None:
+            return
+        while self._next < len(self._buckets):
+            b = self._buckets[self._next]
+            if any(p.grad is None for p in b.params):
+                break
+            self._launch(b)
+            self._next += 1
 
     def _build_buckets(self):
         order = self._ready_order + [i for i in range(len(self.params)) if i not in self._seen]
@@ -160,6 +211,11 @@ class Bf16GradSync:
         return timed("grad_sync_exposed", self._finish)
 
     def _finish(self):
+        if not self.use_hooks:
+            self.poll()
+            if self._next < len(self._buckets):
+                raise RuntimeError("Bf16GradSync.finish(): a parameter received no gradient (unused parameters are not supported)")
+            self._next = 0
         if self._buckets is None:
             # first step: the ready order is known only now -> build the buckets and reduce them all here (no overlap)
             self._build_buckets()
@@ -174,8 +230,10 @@ class Bf16GradSync:
             if b.work is None:
                 raise RuntimeError("Bf16GradSync.finish(): a bucket was never launched -- some parameter received no "
                                    "gradient in this backward")
-            b.work.wait()
-            self.unpack_fn([p.grad for p in b.params], b.flat, b.offsets)
+            if b.work is not False:
+                b.work.wait()
+            if self._DIAG != "hooks":
+                self.unpack_fn([p.grad for p in b.params], b.flat, b.offsets)
             b.work = None
             b.pending = len(b.params)
         out = dict(self.stats)

@@ -137,6 +137,34 @@ class FrozenInTime(BaseModel):
             new_state_dict = self._inflate_positional_embeds(new_state_dict)
             self.load_state_dict(new_state_dict, strict=True)                                    # :88-95
 
+    def gradient_stream_of(self, param):
+        """The HIP stream `param`'s gradient is produced on: the text tower's stream for DistilBERT and txt_proj when the towers
+        run on two streams (ops.TEXT_SIDE_STREAM), else None (= the stream backward() is called on).  For code that
+        registers gradient hooks (egovlp_amd.dist.Bf16GradSync, AdamW.overlap_backward)."""
+        if not ops.TEXT_SIDE_STREAM or not param.is_cuda:
+            return None
+        ids = getattr(self, "_text_param_ids", None)
+        if ids is None:
+            ids = {id(q) for q in self.text_model.parameters()} | {id(q) for q in self.txt_proj.parameters()}
+            self._text_param_ids = ids
+        return ops.text_stream() if id(param) in ids else None
+
+    def gradient_ready_order(self):
+        """Trainable parameters in the order their gradients become final in backward(): projections and the video tower from
+        its last block to its first (autograd runs the later-created nodes first), then the text tower (created first)."""
+        video = [p for p in self.video_model.parameters()][::-1]
+        text = [p for p in self.text_model.parameters()][::-1]
+        proj = [p for p in self.vid_proj.parameters()] + [p for p in self.txt_proj.parameters()]
+        out, seen = [], set()
+        for p in proj + video + text:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+        for p in self.parameters():                 # anything not covered above (none today)
+            if p.requires_grad and id(p) not in seen:
+                out.append(p)
+        return out
+
     def set_device(self, device):
         self.device = device
 
@@ -149,6 +177,7 @@ class FrozenInTime(BaseModel):
             # tower's backward on the stream its forward ran on and orders them against the loss by itself.
             self._wc.refresh()
             main, side = torch.cuda.current_stream(), ops.text_stream()
+            ops._TEXT["main"] = main
             side.wait_stream(main)
             for t in data['text'].values():
                 t.record_stream(side)

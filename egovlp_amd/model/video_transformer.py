@@ -155,6 +155,8 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         B, T, n, H, eps = ctx.geom
         wc = ctx.wc
         Pb = Precision.bwd_passes
+        if ops.BACKWARD_POLL is not None:
+            ops.BACKWARD_POLL()         # gradients of the blocks behind this one are final: the data-parallel exchange may start
         if Pb > ctx.P:
             raise RuntimeError("backward precision bf16x3 needs a bf16x3 forward (the saved activation planes carry no lo part)")
         M, D = x2.shape

@@ -51,13 +51,13 @@ def _stream():
 # main stream: its persistent workgroups fill the CUs that the main stream's kernels leave idle (last partial round of a
 # tile grid, drain tails, the launch gaps of the small kernels).  The main stream re-joins at the end of backward (an autograd
 # engine callback queued by the first wgrad of the pass) and before any gradient hook reads a wgrad (`join_side_stream`).
-WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "0") == "1"
+WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "1") == "1"
 _SIDE = {"stream": None, "main": None, "dirty": False, "queued": False}
 
 
 # The text tower on its own stream under the video tower (model/model.py FrozenInTime.forward).
 TEXT_SIDE_STREAM = os.environ.get("EGV_TEXT_SIDE", "1") == "1"
-_TEXT = {"stream": None}
+_TEXT = {"stream": None, "main": None}   # "main": the stream forward() forked the text tower from
 
 
 def text_stream():
@@ -68,6 +68,11 @@ def text_stream():
 
 def on_text_stream():
     return _TEXT["stream"] is not None and torch.cuda.current_stream() == _TEXT["stream"]
+
+
+# Called (if set) at the entry of every SpaceTimeBlock backward: the gradients of all later blocks are final there.  The
+# hook-free gradient exchange (egovlp_amd.dist.Bf16GradSync(use_hooks=False).poll) hangs off it.
+BACKWARD_POLL = None
 
 
 class side_stream:
@@ -124,6 +129,8 @@ def join_streams_for_gradient_hook():
         cur = torch.cuda.current_stream()
         if cur != _TEXT["stream"]:
             cur.wait_stream(_TEXT["stream"])
+        elif _TEXT.get("main") is not None:
+            cur.wait_stream(_TEXT["main"])       # a hook on the text stream that also reads gradients of the video tower
 
 
 class KernelTimer:

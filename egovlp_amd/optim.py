@@ -33,8 +33,10 @@ class AdamW(torch.optim.Optimizer):
         self._ov = None     # state of overlap_backward()
 
     # ------------------------------------------------------------------------------------------ overlap with backward
-    def overlap_backward(self, min_elems=16 << 20):
-        """Arm-able overlap of the update with the backward pass (see the module docstring).  Returns self."""
+    def overlap_backward(self, min_elems=16 << 20, stream_of=None):
+        """Arm-able overlap of the update with the backward pass (see the module docstring).  Returns self.
+        `stream_of(param)`: the stream the parameter's gradient is produced on (FrozenInTime.gradient_stream_of) -- the hook is
+        registered under it so that autograd does not serialise the two towers' streams (see Bf16GradSync)."""
         if self._ov is not None:
             return self
         group_of = {}
@@ -43,8 +45,17 @@ class AdamW(torch.optim.Optimizer):
                 group_of[id(p)] = group
         self._ov = {"armed": False, "done": set(), "ready": [], "elems": 0, "min": int(min_elems), "stream": None,
                     "group_of": group_of, "dirty": False, "launches": 0}
-        self._ov["handles"] = [p.register_post_accumulate_grad_hook(self._on_grad)
-                               for group in self.param_groups for p in group["params"] if p.requires_grad]
+        self._ov["handles"] = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if not p.requires_grad:
+                    continue
+                st = stream_of(p) if stream_of is not None else None
+                if st is not None and p.is_cuda:
+                    with torch.cuda.stream(st):
+                        self._ov["handles"].append(p.register_post_accumulate_grad_hook(self._on_grad))
+                else:
+                    self._ov["handles"].append(p.register_post_accumulate_grad_hook(self._on_grad))
         return self
 
     def zero_grad(self, set_to_none=True):

@@ -23,14 +23,28 @@ def _unpack(grads, flat, offsets):
         g.copy_(flat[o:o + g.numel()].float().view_as(g))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, use_hooks=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from egovlp_amd.dist import Bf16GradSync
     torch.manual_seed(100 + rank)                     # different initial weights per rank: the broadcast must fix that
     net = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.ReLU(), torch.nn.Linear(40, 33), torch.nn.Linear(33, 7))
-    sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack)     # ~2 k elements per bucket
+    if use_hooks:
+        sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack)     # ~2 k elements per bucket
+    else:
+        # hook-free mode: buckets cut along the given ready order (last layer first); poll() is called when the gradient of the
+        # FIRST layer's weight is being produced -- the gradients of the later layers are final by then -- and again by finish()
+        order = [p for p in net.parameters()][::-1]
+        sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack, use_hooks=False, order_hint=order)
+        polled = []
+
+        def _poll(g):
+            before = sync.stats["collectives_last_step"]
+            sync.poll()
+            polled.append(sync.stats["collectives_last_step"] - before)
+            return g
+        net[0].weight.register_hook(_poll)
     w0 = [p.detach().clone() for p in net.parameters()]
     results = []
     for step in range(3):
@@ -50,14 +64,17 @@ def _worker(rank, world, port, out):
         loss.backward()
         stats = sync.finish()
         results.append(([p.grad.clone() for p in net.parameters()], Gs, stats))
+    if not use_hooks:
+        assert polled and all(n >= 1 for n in polled), polled      # the mid-backward poll did launch buckets in every step
     torch.save({"w0": w0, "results": results}, os.path.join(out, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_bf16_grad_sync_two_ranks(tmp_path):
-    world, port = 2, 29641
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("use_hooks", [True, False])
+def test_bf16_grad_sync_two_ranks(tmp_path, use_hooks):
+    world, port = 2, 29641 + (0 if use_hooks else 1)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), use_hooks), nprocs=world, join=True)
     r = [torch.load(os.path.join(str(tmp_path), f"rank{i}.pt"), weights_only=False) for i in range(world)]
     for a, b in zip(r[0]["w0"], r[1]["w0"]):
         assert torch.equal(a, b)                      # rank 0's initial weights everywhere
