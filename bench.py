@@ -192,6 +192,8 @@ def main():
     from egovlp_amd import _lib
     grid = args.gemm_grid or (248 if world > 1 else 256)
     ops.set_gemm_grid(grid)
+    if args.ddp:
+        args.wgrad_side = 0      # DDP's reducer hooks read the weight gradients during backward and know nothing of the side stream
     ops.WGRAD_SIDE_STREAM = bool(args.wgrad_side)
     ops.TEXT_SIDE_STREAM = bool(args.text_side)
     opt = AdamW(model.parameters(), lr=3e-5)

@@ -40,6 +40,10 @@ class Multi_BaseTrainer_dist:
         self.model = model.to(self.device)
         self.model.device = self.device
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # this trainer owns every gradient hook of the run (Bf16GradSync joins the streams): weight gradients may go to the
+        # side stream (egovlp_amd.ops.side_stream); EGV_WGRAD_SIDE=0 keeps them on the main stream
+        from .. import ops as _ops
+        _ops.WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "1") == "1"
         self.grad_sync = None
         if self.world_size > 1:
             from .. import ops

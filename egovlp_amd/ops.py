@@ -51,7 +51,10 @@ def _stream():
 # main stream: its persistent workgroups fill the CUs that the main stream's kernels leave idle (last partial round of a
 # tile grid, drain tails, the launch gaps of the small kernels).  The main stream re-joins at the end of backward (an autograd
 # engine callback queued by the first wgrad of the pass) and before any gradient hook reads a wgrad (`join_side_stream`).
-WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "1") == "1"
+# OFF by default in the library: code that reads a weight gradient from an autograd hook DURING backward without calling
+# `join_streams_for_gradient_hook()` first (torch's DistributedDataParallel does) would race with the side stream.  The callers
+# that own their hooks turn it on: bench.py and Multi_BaseTrainer_dist (Bf16GradSync joins; +1.1 .. 1.7 % step rate).
+WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "0") == "1"
 _SIDE = {"stream": None, "main": None, "dirty": False, "queued": False}
 
 
