@@ -132,3 +132,24 @@ def test_eval_token_padding_for_graph_replay():
     assert int(p["attention_mask"].sum()) == 11
     t16 = {"input_ids": torch.ones(2, 16, dtype=torch.long), "attention_mask": torch.ones(2, 16, dtype=torch.long)}
     assert _pad_tokens(t16, 8) is t16
+
+
+def test_gradient_ready_order_covers_every_parameter_once():
+    """FrozenInTime.gradient_ready_order() (the bucket order of the hook-free gradient exchange): a permutation of the trainable
+    parameters -- projections, then the video tower from its last block to its first, then the text tower -- and
+    gradient_stream_of() names no stream for host-resident parameters."""
+    from egovlp_amd.model.model import FrozenInTime
+    m = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
+                     load_checkpoint="")
+    order = m.gradient_ready_order()
+    params = [p for p in m.parameters() if p.requires_grad]
+    assert len(order) == len(params) and {id(p) for p in order} == {id(p) for p in params}
+    names = {id(p): k for k, p in m.named_parameters()}
+    seq = [names[id(p)] for p in order]
+    first_text = min(i for i, k in enumerate(seq) if k.startswith("text_model."))
+    last_video = max(i for i, k in enumerate(seq) if k.startswith("video_model."))
+    assert last_video < first_text                                   # the whole video tower is final before the text tower
+    b11 = min(i for i, k in enumerate(seq) if k.startswith("video_model.blocks.11."))
+    b0 = min(i for i, k in enumerate(seq) if k.startswith("video_model.blocks.0."))
+    assert b11 < b0                                                  # last block first
+    assert all(m.gradient_stream_of(p) is None for p in params[:5])  # CPU parameters: no stream

@@ -1,6 +1,7 @@
 """The N>1 code path of bench.py on a 1-GPU box, at world size 1: RCCL process group (`backend='nccl'`), the fused embedding
-all-gather and the gradient exchange -- `Bf16GradSync` (default: HIP pack kernel -> RCCL all-reduce of the bf16 bucket from the
-grad-ready hooks -> HIP unpack kernel) and, for A/B, DistributedDataParallel around the drop-in model.  The loss after the
+all-gather and the gradient exchange -- `Bf16GradSync` (default: HIP pack kernel -> RCCL all-reduce of the bf16 bucket, launched
+hook-free from the block-boundary poll of the video tower's backward -> HIP unpack kernel) and, for A/B, DistributedDataParallel
+around the drop-in model (with the wgrad side stream off: DDP's reducer hooks read gradients during backward).  The loss after the
 same steps must match the plain single-process run (up to the run-to-run noise of the atomic reductions and, for the bf16
 exchange, the 2^-9 rounding of the exchanged gradients).  W > 1 semantics are pinned on gloo (tests/test_gradsync_gloo.py,
 tests/test_gather_gloo.py); no multi-GPU box is available to `gpurun`."""
