@@ -220,6 +220,9 @@ def zeros(shape, dtype=torch.float32, device="cuda"):
 GEMM_GRID = 256
 
 
+_WGRAD_KSPLIT_DIV = int(os.environ.get("EGV_WGRAD_KSPLIT_DIV", "0"))   # A/B override of the divisor below (0 = policy)
+
+
 def set_gemm_grid(workgroups: int) -> int:
     """-> the previous cap.  Multiples of 8 in [8, 256]."""
     global GEMM_GRID
@@ -315,7 +318,12 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         # sized for 256 on a 248-workgroup grid would spill 4 work units into a second round and double the wgrad's time)
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
         nkt = (Kd + 63) // 64
-        ksplit = max(1, min(GEMM_GRID // max(tiles, 1), nkt // 2))
+        # ... and HALF of that when the wgrad runs on the side stream next to the dgrad chain: it no longer has to fill the
+        # chip by itself, half the workgroups leave CUs to the main stream's kernels, and the fp32 slabs (and the reduce that
+        # reads them) are half as big.  Same box: 796.6 -> 819.8 pairs/s (+2.9 %); a third: 788, a quarter: 635 -- the wgrads
+        # then become the critical path (profiles/r02_ab_wgrad_ksplit.txt).
+        div = _WGRAD_KSPLIT_DIV or (2 if (_SIDE["stream"] is not None and torch.cuda.current_stream() == _SIDE["stream"]) else 1)
+        ksplit = max(1, min(GEMM_GRID // max(tiles, 1) // div, nkt // 2))
     d = GemmDesc()
     d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
     d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
