@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """EgoClip pre-training step benchmark (BASELINE.json metric: clip-pairs/sec, whole node).
 
-    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+come from the environment), or -- bare `python bench.py --gpus N` -- this script launches them itself (self_launch) and
+refuses to run when fewer than N GPUs are visible.
 
 A "step" is one pass of the hot path = trainer/trainer_egoclip.py:123-141 restated in
 egovlp_amd.trainer.trainer_egoclip.egoclip_step: zero_grad, dual-encoder forward, embedding all-gather (RCCL),
@@ -105,6 +110,44 @@ def grad_rel_err(model, loss_fn, data, world, rank, set_precision, mode):
             "per_tensor": {k: round(v, 5) for k, v in errs.items()}}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script on this node with
+    torch.distributed.run (one process per GPU, RCCL rendezvous on 127.0.0.1) and return its exit code.  Fails loudly, before
+    anything is launched, when the node has fewer than N GPUs -- a 1-GPU number must never be printed as an N-GPU one."""
+    import socket
+    import subprocess
+    if not args.launch_dry_run and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible on this node",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:        # a free rendezvous port (the driver's own launcher passes --master-port itself)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_dry_run(world, rank):
+    """The launch path without a GPU: every rank joins a gloo process group, proves it with an all-reduce of its rank id and
+    rank 0 prints the JSON line (n_gpus = ranks that actually joined)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank + 1), 1.0])
+    dist.all_reduce(t)
+    joined = int(t[1])
+    ok = joined == world == dist.get_world_size() and int(t[0]) == world * (world + 1) // 2
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": joined, "ranks_joined": joined, "world_size": dist.get_world_size(),
+                          "backend": dist.get_backend(), "ok": bool(ok)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,13 +184,29 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL process group, DDP wrapper and the fused all-gather even at world size 1 "
                          "(smoke test of the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="exercise ONLY the N-rank launch path (self re-exec under torch.distributed.run, rendezvous, one "
+                         "all-reduce on the gloo backend, rank 0 prints a JSON line) -- no GPU, no model; tests/test_bench_launch.py")
     args = ap.parse_args()
 
+    # ---- N ranks: one process per GPU (reference: run/train_egoclip.py:39-45,128-134 / README.md:78-84).  Invoked bare
+    # (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this process is only the LAUNCHER: it re-executes
+    # itself under torch.distributed.run with N local ranks and passes rank 0's JSON line through.  Invoked by
+    # torch.distributed.run already (WORLD_SIZE set) it is one of the ranks.
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (one rank per GPU)")
+    if args.launch_dry_run:
+        raise SystemExit(launch_dry_run(world, rank))
+    if torch.cuda.device_count() < max(args.gpus, local_rank + 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} (local rank {local_rank}) but only {torch.cuda.device_count()} HIP "
+                         f"device(s) are visible: refusing to report a {args.gpus}-GPU number from fewer GPUs")
     torch.cuda.set_device(local_rank)
     torch.manual_seed(1234 + rank)      # the dropout masks of the text encoder are a function of torch's seed: reproducible runs
     use_dist = world > 1 or args.force_dist
@@ -168,15 +227,18 @@ def main():
     from egovlp_amd.synth import synth_batch
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
 
-    def set_precision(name):
-        if name == "mixed":
-            ops.Precision.set("bf16x3", "bf16")
-        else:
-            ops.Precision.set(name)
-
-    set_precision(args.precision)
     B, T, L = args.batch, args.frames, 32
     model = build_model(args.arch, 16, args.text_dropout).cuda().train()
+    model.text_model.seed_rank = rank     # data-parallel ranks draw different dropout masks
+    ec = model.exec_ctx                   # everything below configures THIS model's execution context (egovlp_amd.ops.ExecContext)
+
+    def set_precision(name):
+        if name == "mixed":
+            ec.set_precision("bf16x3", "bf16")
+        else:
+            ec.set_precision(name)
+
+    set_precision(args.precision)
     net = model
     grad_sync = None
     if use_dist and args.ddp:
@@ -185,20 +247,18 @@ def main():
     elif use_dist and not args.no_grad_sync:
         from egovlp_amd.dist import Bf16GradSync
         if args.grad_sync_hooks:
-            grad_sync = Bf16GradSync(model.parameters(), stream_of=model.gradient_stream_of)
-        else:     # hook-free: buckets launched from the block-boundary poll (egovlp_amd.ops.BACKWARD_POLL)
-            grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order())
-            ops.BACKWARD_POLL = grad_sync.poll
-    from egovlp_amd import _lib
+            grad_sync = Bf16GradSync(model.parameters(), stream_of=model.gradient_stream_of, exec_ctx=ec)
+        else:     # hook-free: buckets launched from the polls of the video tower's backward (ExecContext.backward_poll)
+            grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec)
+            ec.set(backward_poll=grad_sync.poll)
     grid = args.gemm_grid or (248 if world > 1 else 256)
-    ops.set_gemm_grid(grid)
+    ec.set(gemm_grid=grid)
     if args.ddp:
         args.wgrad_side = 0      # DDP's reducer hooks read the weight gradients during backward and know nothing of the side stream
-    ops.WGRAD_SIDE_STREAM = bool(args.wgrad_side)
-    ops.TEXT_SIDE_STREAM = bool(args.text_side)
+    ec.set(wgrad_side_stream=bool(args.wgrad_side), text_side_stream=bool(args.text_side))
     opt = AdamW(model.parameters(), lr=3e-5)
     if args.adamw_overlap and grad_sync is None and not args.ddp:
-        opt.overlap_backward(stream_of=model.gradient_stream_of)
+        opt.overlap_backward(stream_of=model.gradient_stream_of, exec_ctx=ec)
     loss_fn = EgoNCE()
     batch = synth_batch(B, T=T, L=L, seed=1234, rank=rank)
     data = {"video": batch["video"].cuda(), "text": {k: v.cuda() for k, v in batch["text"].items()},
@@ -234,15 +294,14 @@ def main():
     # the kernels run on, in a separate instrumented pass of the same step (so the timed value above is untouched).
     roof = None
     if not args.no_kernel_timing:
-        ops.KERNEL_TIMER = ops.KernelTimer()
-        side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False    # per-launch durations: one kernel at a time
-        tside, ops.TEXT_SIDE_STREAM = ops.TEXT_SIDE_STREAM, False
+        timer = ops.KernelTimer()
+        # per-launch durations: one kernel at a time (no side streams) while the timer is attached
+        ec.set(kernel_timer=timer, wgrad_side_stream=False, text_side_stream=False)
         for _ in range(2):
             egoclip_step(net, loss_fn, opt, data, world, rank, grad_sync=grad_sync)
         torch.cuda.synchronize()
-        kt = ops.KERNEL_TIMER.summary()
-        ops.KERNEL_TIMER = None
-        ops.WGRAD_SIDE_STREAM, ops.TEXT_SIDE_STREAM = side, tside
+        kt = timer.summary()
+        ec.set(kernel_timer=None, wgrad_side_stream=bool(args.wgrad_side), text_side_stream=bool(args.text_side))
         g_all = kt["egv_gemm_nt"]
         # the dominant kernel is gemm_big_kernel (all token-major GEMMs and every wgrad); the 128x128 kernel of the small-M
         # problems (DistilBERT, projections: latency-bound, 6 % of the GEMM time) is reported separately, not averaged in
@@ -293,7 +352,7 @@ def main():
         "dtype": "bf16", "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
         "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
-                   "parallelism": f"dp{world}", "precision": "/".join(ops.Precision.name()),
+                   "parallelism": f"dp{world}", "precision": "/".join(ec.precision_name()),
                    "text_dropout": args.text_dropout,
                    "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
                                "adamw_overlapped_with_backward": bool(args.adamw_overlap and grad_sync is None and not args.ddp)}},
@@ -326,7 +385,8 @@ def main():
         out["comm"] = {"rccl_ranks": world, "backend": dist.get_backend(), "gemm_grid": grid,
                        "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS", "default"),
                        "gradient_exchange": "DDP fp32 buckets" if args.ddp else "Bf16GradSync (bf16 buckets, async all-reduce from grad hooks)",
-                       "grad_sync": None if grad_sync is None else {k: int(v) for k, v in grad_sync.stats.items() if k == "buckets"},
+                       "grad_sync": None if grad_sync is None else {k: int(v) for k, v in grad_sync.stats.items()
+                                                                   if k in ("buckets", "launched_during_backward")},
                        "ms_per_step_rank_min": round(float(allr[:, 0].min()), 3), "ms_per_step_rank_max": round(float(allr[:, 0].max()), 3),
                        "embedding_all_gather_ms": round(float(allr[:, 1].mean()), 3),
                        "grad_sync_exposed_ms_mean": round(float(allr[:, 2].mean()), 3),

@@ -39,13 +39,13 @@ class GemmDesc(C.Structure):
         ("partial", c_p),
         ("trans", i32), ("aux_bf16", i32),
         ("colsum", c_p),
+        ("grid_cap", i32), ("reserved_", i32),
     ]
 
 
 # name -> (restype, argtypes); mirrors include/egovlp_hip.h one to one (tests/test_abi.py checks it)
 PROTOTYPES = {
     "egv_gemm_nt": (i32, [C.POINTER(GemmDesc), c_p]),
-    "egv_gemm_set_grid": (i32, [i32]),
     "egv_split_f32": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p, i64, c_p, c_p]),
     "egv_transpose_planes": (i32, [c_p, c_p, i64, i32, i32, c_p, c_p, i64, c_p, c_p]),
     "egv_layernorm_fwd": (i32, [c_p, c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, c_p, i64, c_p, c_p, c_p]),

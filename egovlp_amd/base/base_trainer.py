@@ -42,23 +42,30 @@ class Multi_BaseTrainer_dist:
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # this trainer owns every gradient hook of the run (Bf16GradSync joins the streams): weight gradients may go to the
         # side stream (egovlp_amd.ops.side_stream); EGV_WGRAD_SIDE=0 keeps them on the main stream
-        from .. import ops as _ops
-        _ops.WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "1") == "1"
+        # (safe with one backward per step and zero_grad(set_to_none=True), which egoclip_step does; a wgrad whose parameter
+        # already holds a gradient stays on the main stream by itself -- model/video_transformer.py::_lin_bwd).
+        # Settings go to the MODEL's execution context: nothing here is process-wide.
+        from .. import ops
+        ec = getattr(self.model, "exec_ctx", None) or ops.DEFAULT
+        ec.set(wgrad_side_stream=os.environ.get("EGV_WGRAD_SIDE", "1") == "1")
         self.grad_sync = None
         if self.world_size > 1:
-            from .. import ops
             from ..dist import Bf16GradSync
+            text = getattr(self.model, "text_model", None)
+            if text is not None and hasattr(text, "seed_rank"):
+                text.seed_rank = dist.get_rank()           # ranks must not draw identical dropout masks
             if hasattr(self.model, "gradient_ready_order"):
-                # hook-free: buckets are launched from the block-boundary poll of the video tower's backward (autograd
-                # grad-ready hooks cost 0.6 ms per step more on this model, profiles/r02_d_dp_overhead.txt)
+                # hook-free: buckets are launched from the polls of the video tower's backward (autograd grad-ready hooks
+                # cost 0.6 ms per step more on this model, profiles/r02_d_dp_overhead.txt)
                 self.grad_sync = Bf16GradSync(self.model.parameters(), use_hooks=False,
-                                              order_hint=self.model.gradient_ready_order())
-                ops.BACKWARD_POLL = self.grad_sync.poll
+                                              order_hint=self.model.gradient_ready_order(), exec_ctx=ec)
+                ec.set(backward_poll=self.grad_sync.poll)
             else:
-                self.grad_sync = Bf16GradSync(self.model.parameters(), stream_of=getattr(self.model, "gradient_stream_of", None))
+                self.grad_sync = Bf16GradSync(self.model.parameters(), stream_of=getattr(self.model, "gradient_stream_of", None),
+                                              exec_ctx=ec)
             # the persistent GEMM owns every CU for the length of a launch: leave one CU per XCD to the RCCL kernels of the
             # overlapped gradient exchange (bench.py does the same; the wgrad split-K policy follows the cap)
-            ops.set_gemm_grid(int(os.environ.get("EGV_GEMM_GRID", "248")))
+            ec.set(gemm_grid=int(os.environ.get("EGV_GEMM_GRID", "248")))
         self.loss = loss.to(self.device) if hasattr(loss, 'to') else loss
         self.metrics = metrics
         self.optimizer = optimizer

@@ -68,7 +68,6 @@ typedef __attribute__((ext_vector_type(4))) short s16x4v;
 typedef __attribute__((ext_vector_type(8))) short s16x8v;
 
 __device__ uint4 g_zero_page[64];  // 1 KiB of zeros: DMA source for k-rows past the end (TN)
-int g_grid_cap = 256;            // persistent workgroups per launch (process-wide tuning knob, see egv_gemm_set_grid)
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -1100,8 +1099,9 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s) {
   constexpr int dbg = 0;
 #endif
   // persistent workgroups: one per CU (144 KiB of LDS each); a grid that is a multiple of 8 keeps v % 8 == blockIdx % 8
-  // (XCD affinity).  g_grid_cap < 256 (egv_gemm_set_grid) leaves CUs to the RCCL kernels of an overlapped collective.
-  const int grid = total < g_grid_cap ? total : g_grid_cap;
+  // (XCD affinity).  p.grid_cap < 256 leaves CUs to the RCCL kernels of an overlapped collective (per launch: no process state).
+  const int cap = p.grid_cap > 0 ? p.grid_cap : 256;
+  const int grid = total < cap ? total : cap;
   EGV_LAUNCH(k, dim3(grid), dim3(512), lds_launch, s, p, dbg);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -1120,15 +1120,6 @@ int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
 }
 
 }  // namespace
-
-// Persistent-workgroup cap of the big-tile GEMM: 256 = one per CU (default).  In a data-parallel job the gradient
-// all-reduce runs as RCCL kernels UNDER the backward GEMMs; a grid that owns every CU for the whole launch starves them, so
-// multi-GPU runs set e.g. 248 (8 CUs, one per XCD, stay free).  Multiples of 8 in [8, 256]; returns the previous value.
-extern "C" int egv_gemm_set_grid(int32_t workgroups) {
-  const int prev = g_grid_cap;
-  if (workgroups >= 8 && workgroups <= 256 && workgroups % 8 == 0) g_grid_cap = workgroups;
-  return prev;
-}
 
 // Can the big kernel run this problem?  (NT: K % 64 == 0; both: M, N at least one tile, 16-B aligned rows.)
 bool egv_gemm_big_supports(const egv_gemm_desc& p) {

@@ -256,6 +256,7 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   if (!p.trans && p.K % BK != 0) return EGV_ERR_ARG;
   if (p.ksplit > 1 && !p.partial) return EGV_ERR_ARG;
   if (p.colsum && !p.trans) return EGV_ERR_ARG;
+  if (p.grid_cap != 0 && (p.grid_cap < 8 || p.grid_cap > 256 || p.grid_cap % 8 != 0)) return EGV_ERR_ARG;
   const int variant = gemm_variant(p);
   if (variant < 0) return EGV_ERR_ARG;
   if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // bf16 aux: gemm_big GELU epilogues only

@@ -85,7 +85,8 @@ class _Bucket:
 class Bf16GradSync:
     def __init__(self, params, process_group=None, bucket_mb: float = 64.0,
                  pack_fn: Optional[Callable] = None, unpack_fn: Optional[Callable] = None, broadcast: bool = True,
-                 stream_of: Optional[Callable] = None, use_hooks: bool = True, order_hint: Optional[List] = None):
+                 stream_of: Optional[Callable] = None, use_hooks: bool = True, order_hint: Optional[List] = None,
+                 exec_ctx=None):
         """`stream_of(param)` -> the HIP stream that parameter's gradient is produced on (None: the current one).  A grad-ready
         hook keeps the parameter's AccumulateGrad node alive across iterations, and autograd runs that node on the stream
         that was current WHEN THE HOOK WAS REGISTERED: for the text tower (its backward runs on its own stream,
@@ -97,8 +98,12 @@ class Bf16GradSync:
         at points of backward where earlier gradients are known to be final (egovlp_amd.ops.BACKWARD_POLL, invoked at the entry
         of every SpaceTimeBlock backward): every bucket whose parameters all have a gradient is packed and all-reduced there.
         Needs `zero_grad(set_to_none=True)` (a gradient is "ready" when it is not None) and `order_hint`, the parameters in
-        the order their gradients become final (buckets are cut along it)."""
+        the order their gradients become final (buckets are cut along it).
+
+        `exec_ctx`: the model's egovlp_amd.ops.ExecContext -- gradients are produced on up to three of ITS streams (main, text
+        tower, wgrad side stream) and a bucket's pack kernel is ordered behind all of them first."""
         self.use_hooks = use_hooks
+        self.exec_ctx = exec_ctx
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("Bf16GradSync: no trainable parameters")
@@ -121,7 +126,7 @@ class Bf16GradSync:
         self._buckets: Optional[List[_Bucket]] = None       # built after the first backward, from its ready order
         self._bucket_of = {}
         self._seen = set()
-        self.stats = {"buckets": 0, "collectives_last_step": 0, "bytes_last_step": 0}
+        self.stats = {"buckets": 0, "collectives_last_step": 0, "bytes_last_step": 0, "launched_during_backward": 0}
         self._handles = []
         if not use_hooks:
             if order_hint is not None:
@@ -165,7 +170,8 @@ class Bf16GradSync:
             return
         if self.pack_fn is _hip_pack:
             from . import ops
-            ops.join_streams_for_gradient_hook()      # gradients are produced on up to three streams (ops.side_stream, text tower)
+            # gradients are produced on up to three streams (main, text tower, wgrad side stream) of the model's context
+            (self.exec_ctx or ops.DEFAULT).join_streams_for_gradient_hook()
         grads = [p.grad for p in b.params]
         for g in grads:
             if g is None or g.dtype != torch.float32 or not g.is_contiguous():
@@ -189,8 +195,23 @@ class Bf16GradSync:
             self._launch(b)
             self._next += 1
 
+    def _agree_on_order(self, order):
+        """Every rank must cut identical buckets, or the all-reduces pair up unrelated gradients (or hang): adopt rank 0's
+        order, as DDP does with its bucket rebuild.  (Hook mode observes the order locally; the hook-free order comes from the
+        model and is the same everywhere, but costs one tiny broadcast to check.)"""
+        if self.world <= 1:
+            return order
+        t = torch.tensor(order, dtype=torch.int64, device=self.device if self.device.type == "cuda" else "cpu")
+        mine = t.clone()
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        if not torch.equal(t, mine):
+            import warnings
+            warnings.warn("Bf16GradSync: this rank observed a different gradient-ready order than rank 0; using rank 0's")
+        return [int(i) for i in t.tolist()]
+
     def _build_buckets(self):
         order = self._ready_order + [i for i in range(len(self.params)) if i not in self._seen]
+        order = self._agree_on_order(order)
         buckets, cur, cur_n = [], [], 0
         for i in order:
             p = self.params[i]
@@ -211,6 +232,8 @@ class Bf16GradSync:
         return timed("grad_sync_exposed", self._finish)
 
     def _finish(self):
+        if self._buckets is not None:      # how many buckets had already left when backward returned (the rest is exposed)
+            self.stats["launched_during_backward"] = self.stats["collectives_last_step"]
         if not self.use_hooks:
             self.poll()
             if self._next < len(self._buckets):

@@ -19,9 +19,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..ops import ACT_RELU_BWD, Precision
+from ..ops import ACT_RELU_BWD, ExecContext
 from ..utils.util import load_checkpoint_file, state_dict_data_parallel_fix
-from ..weights import WeightCache
 from .text_transformer import DistilBertModel
 from .video_transformer import SpaceTimeTransformer, _lin_bwd
 
@@ -30,32 +29,35 @@ class _ProjFn(torch.autograd.Function):
     """y = [relu](x) W^T + b on rows of x (possibly strided: the CLS row of every caption)."""
 
     @staticmethod
-    def forward(ctx, x2d, w, b, relu, wc: WeightCache):
-        P = Precision.fwd_passes
+    def forward(ctx, x2d, w, b, relu, ec: ExecContext):
+        P = ec.fwd_passes
         M, K = x2d.shape
         if relu:
             a = ops.relu_split(x2d, P)
         else:
             a, _, _ = ops.split_f32(x2d, P)
         y = torch.empty((M, w.shape[0]), dtype=torch.float32, device=x2d.device)
-        ops.gemm_nt(a, wc.get(w, need_t=False)[0], passes=P, bias=b, out_f32=y)
-        ctx.a, ctx.relu, ctx.wc, ctx.P = a, relu, wc, P
+        ops.gemm_nt(a, ec.wc.get(w, need_t=False)[0], passes=P, bias=b, out_f32=y, ec=ec)
+        ctx.a, ctx.relu, ctx.ec, ctx.P = a, relu, ec, P
         ctx.save_for_backward(x2d, w)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x2d, w = ctx.saved_tensors
-        Pb = Precision.bwd_passes
+        ec = ctx.ec
+        Pb = ec.bwd_passes
+        if not ec.on_text_stream():
+            ec.poll_backward()          # vid_proj: the first node of the video tower's backward on the main stream
         dy = dy.contiguous()
         dy_pl = ops.split_f32(dy, Pb)[0]
-        _, dW, db = _lin_bwd(dy_pl, ctx.a, None, Pb, need_dx=False)
+        _, dW, db = _lin_bwd(dy_pl, ctx.a, None, Pb, need_dx=False, params=(w,), ec=ec)
         dx = torch.empty((x2d.shape[0], x2d.shape[1]), dtype=torch.float32, device=dy.device)
-        wt = ctx.wc.get(w, need_t=True)[1]
+        wt = ec.wc.get(w, need_t=True)[1]
         if ctx.relu:
-            ops.gemm_nt(dy_pl, wt, passes=Pb, act=ACT_RELU_BWD, aux_in=x2d, out_f32=dx, K=w.shape[0])
+            ops.gemm_nt(dy_pl, wt, passes=Pb, act=ACT_RELU_BWD, aux_in=x2d, out_f32=dx, K=w.shape[0], ec=ec)
         else:
-            ops.gemm_nt(dy_pl, wt, passes=Pb, out_f32=dx, K=w.shape[0])
+            ops.gemm_nt(dy_pl, wt, passes=Pb, out_f32=dx, K=w.shape[0], ec=ec)
         return dx, dW, db, None, None
 
 
@@ -124,7 +126,10 @@ class FrozenInTime(BaseModel):
             raise NotImplementedError                                                            # :84
         self.txt_proj = txt_proj
         self.vid_proj = vid_proj
-        self._wc = WeightCache()
+        # ONE execution context for the dual encoder and its two towers: precision policy, side streams, grid cap, weight-plane
+        # cache (egovlp_amd.ops.ExecContext).  Private to this model; unset settings follow ops.DEFAULT.
+        self.exec_ctx = ops.new_context()
+        self.video_model.exec_ctx = self.text_model.exec_ctx = self.exec_ctx
 
         if load_checkpoint not in ["", None]:
             local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -141,27 +146,36 @@ class FrozenInTime(BaseModel):
         """The HIP stream `param`'s gradient is produced on: the text tower's stream for DistilBERT and txt_proj when the towers
         run on two streams (ops.TEXT_SIDE_STREAM), else None (= the stream backward() is called on).  For code that
         registers gradient hooks (egovlp_amd.dist.Bf16GradSync, AdamW.overlap_backward)."""
-        if not ops.TEXT_SIDE_STREAM or not param.is_cuda:
+        if not self.exec_ctx.text_side_stream or not param.is_cuda:
             return None
         ids = getattr(self, "_text_param_ids", None)
         if ids is None:
             ids = {id(q) for q in self.text_model.parameters()} | {id(q) for q in self.txt_proj.parameters()}
             self._text_param_ids = ids
-        return ops.text_stream() if id(param) in ids else None
+        return self.exec_ctx.text_stream() if id(param) in ids else None
+
+    # Which tower's autograd nodes are created LAST in forward() -- and therefore run FIRST in backward (the engine runs the
+    # ready node with the highest sequence number).  True: video first, then text (on its own stream, forked from an event
+    # recorded before the video tower), so that backward enqueues the small text tower first and its 66 M parameters (a third of
+    # the gradient exchange) can leave at the first poll of the video tower's backward instead of from finish().
+    TEXT_TOWER_LAST = os.environ.get("EGV_TEXT_LAST", "1") == "1"
 
     def gradient_ready_order(self):
-        """Trainable parameters in the order their gradients become final in backward(): projections and the video tower from
-        its last block to its first (autograd runs the later-created nodes first), then the text tower (created first)."""
-        video = [p for p in self.video_model.parameters()][::-1]
-        text = [p for p in self.text_model.parameters()][::-1]
-        proj = [p for p in self.vid_proj.parameters()] + [p for p in self.txt_proj.parameters()]
+        """Trainable parameters in the order their gradients become final in backward(): autograd runs the later-created nodes
+        first, so the tower forward() builds LAST comes first (its projection, then its parameters from the last layer to the
+        first), then the other tower the same way.  Bf16GradSync(use_hooks=False) cuts its buckets along this order and launches
+        them strictly in order from the backward polls -- a wrong order is not an error, it only delays every bucket to finish()
+        (tests/test_gpu_dist.py asserts buckets do leave during backward on the real model)."""
+        video = [p for p in self.vid_proj.parameters()] + [p for p in self.video_model.parameters()][::-1]
+        text = [p for p in self.txt_proj.parameters()] + [p for p in self.text_model.parameters()][::-1]
         out, seen = [], set()
-        for p in proj + video + text:
+        for p in (text + video if self.TEXT_TOWER_LAST else video + text):
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 out.append(p)
         for p in self.parameters():                 # anything not covered above (none today)
             if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
                 out.append(p)
         return out
 
@@ -171,21 +185,34 @@ class FrozenInTime(BaseModel):
     def forward(self, data, video_only=False, return_embeds=True):
         if video_only:
             return self.compute_video(data['video'])
-        if ops.TEXT_SIDE_STREAM and data['video'].is_cuda:
+        ec = self.exec_ctx
+        ec.begin_step()
+        if ec.text_side_stream and data['video'].is_cuda:
             # the two towers are independent until the loss: DistilBERT (M = B*L = 1024 token rows, latency-bound launches
             # that fill a fraction of the chip) runs on a second HIP stream under the video tower.  autograd replays each
             # tower's backward on the stream its forward ran on and orders them against the loss by itself.
-            self._wc.refresh()
-            main, side = torch.cuda.current_stream(), ops.text_stream()
-            ops._TEXT["main"] = main
-            side.wait_stream(main)
+            ec.wc.refresh()
+            main, side = torch.cuda.current_stream(), ec.text_stream()
+            ec._text["main"] = main
             for t in data['text'].values():
                 t.record_stream(side)
-            with torch.cuda.stream(side):
-                text_embeddings = self.compute_text(data['text'])
-            video_embeddings = self.compute_video(data['video'])
+            if self.TEXT_TOWER_LAST:
+                fork = torch.cuda.Event()
+                fork.record(main)                   # the text stream starts from HERE, not from behind the video tower
+                video_embeddings = self.compute_video(data['video'])
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    text_embeddings = self.compute_text(data['text'])
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    text_embeddings = self.compute_text(data['text'])
+                video_embeddings = self.compute_video(data['video'])
             main.wait_stream(side)
             text_embeddings.record_stream(main)
+        elif self.TEXT_TOWER_LAST:
+            video_embeddings = self.compute_video(data['video'])
+            text_embeddings = self.compute_text(data['text'])
         else:
             text_embeddings = self.compute_text(data['text'])
             video_embeddings = self.compute_video(data['video'])
@@ -197,7 +224,7 @@ class FrozenInTime(BaseModel):
         if isinstance(self.txt_proj, nn.Identity):
             return x2d
         lin = self.txt_proj[1]
-        return _ProjFn.apply(x2d, lin.weight, lin.bias, True, self._wc)
+        return _ProjFn.apply(x2d, lin.weight, lin.bias, True, self.exec_ctx)
 
     def compute_text(self, text_data):
         if not self.text_params['model'].startswith('distilbert'):
@@ -216,7 +243,7 @@ class FrozenInTime(BaseModel):
         if isinstance(self.vid_proj, nn.Identity):
             return v
         lin = self.vid_proj[0]
-        return _ProjFn.apply(v, lin.weight, lin.bias, False, self._wc)
+        return _ProjFn.apply(v, lin.weight, lin.bias, False, self.exec_ctx)
 
     def _inflate_positional_embeds(self, new_state_dict):
         """model/model.py:145-187: adapt temporal_embed when the checkpoint has a different num_frames."""
@@ -282,7 +309,7 @@ def sim_matrix_mm(a, b):
     out = torch.empty((n, m4), dtype=torch.float32, device=a.device)
     a_pl = ops.split_f32(a.detach().contiguous().float(), 3)[0]
     b_pl = ops.split_f32(b, 3)[0]
-    ops.gemm_nt(a_pl, b_pl, passes=3, out_f32=out)
+    ops.gemm_nt(a_pl, b_pl, passes=3, out_f32=out)      # stand-alone helper: the DEFAULT context
     return out[:, :m]
 
 

@@ -20,8 +20,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..ops import ACT_GELU, ACT_GELU_BWD, Precision
-from ..weights import WeightCache
+from ..ops import ACT_GELU, ACT_GELU_BWD, ExecContext
 from .video_transformer import _lin_bwd
 
 
@@ -72,12 +71,13 @@ class _TextLayerFn(torch.autograd.Function):
     """TransformerBlock.forward (post-LN):  sa = LN(out_lin(MHA(x)) + x);  out = LN(lin2(gelu(lin1(sa))) + sa)."""
 
     @staticmethod
-    def forward(ctx, x, mask, geom, wc: WeightCache,
+    def forward(ctx, x, mask, geom, ec: ExecContext,
                 q_w, q_b, k_w, k_b, v_w, v_b, o_w, o_b, ln1_w, ln1_b, f1_w, f1_b, f2_w, f2_b, ln2_w, ln2_b):
         B, L, H, eps, drop = geom          # drop = (attention p, attention seed, ffn p, ffn seed); p = 0 outside train()
         D = x.shape[-1]
         M = B * L
-        P = Precision.fwd_passes
+        P = ec.fwd_passes
+        wc = ec.wc
         dev = x.device
         x2 = x.contiguous().view(M, D)
         train = any(ctx.needs_input_grad)
@@ -89,25 +89,25 @@ class _TextLayerFn(torch.autograd.Function):
         # q_lin / k_lin / v_lin as ONE [M, 768] x [2304, 768]^T GEMM (M = B*L = 1024 is latency-bound: three launches -> one)
         qkv = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
         ops.gemm_nt(x_pl, wc.get_cat((q_w, k_w, v_w), need_t=False)[0], passes=P, bias=wc.get_bias_cat((q_b, k_b, v_b)),
-                    out_f32=qkv)
+                    out_f32=qkv, ec=ec)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         c_pl, lse = ops.text_attn_fwd(q, k, v, mask, B, L, H, P, drop[0], drop[1])
         s1 = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(c_pl, W(o_w), passes=P, bias=o_b, residual=x2, out_f32=s1)
+        ops.gemm_nt(c_pl, W(o_w), passes=P, bias=o_b, residual=x2, out_f32=s1, ec=ec)
         sa_pl, sa, mean1, rstd1, _ = ops.layernorm_fwd(s1, ln1_w, ln1_b, eps, P, want_f32=True)
         Hd = f1_w.shape[0]
         h = ops.empty_planes(M, Hd, P, dev)
         z = torch.empty((M, Hd), dtype=torch.float32, device=dev) if train else None
-        ops.gemm_nt(sa_pl, W(f1_w), passes=P, bias=f1_b, act=ACT_GELU, aux_out=z, out_planes=h)
+        ops.gemm_nt(sa_pl, W(f1_w), passes=P, bias=f1_b, act=ACT_GELU, aux_out=z, out_planes=h, ec=ec)
         s2 = torch.empty((M, D), dtype=torch.float32, device=dev)
         if drop[2] > 0:        # FFN.forward: dropout(lin2(gelu(lin1(x)))), then the block's residual: s2 = drop(y) + sa
-            ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, out_f32=s2)
+            ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, out_f32=s2, ec=ec)
             s2 = ops.dropout(s2, drop[2], drop[3], add=sa)
         else:
-            ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, residual=sa, out_f32=s2)
+            ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, residual=sa, out_f32=s2, ec=ec)
         _, out, mean2, rstd2, _ = ops.layernorm_fwd(s2, ln2_w, ln2_b, eps, P, want_f32=True, want_planes=False)
         if train:
-            ctx.geom, ctx.wc, ctx.P = geom, wc, P
+            ctx.geom, ctx.ec, ctx.P = geom, ec, P
             ctx.planes = (x_pl, c_pl, sa_pl, h)
             ctx.save_for_backward(mask, qkv, lse, s1, mean1, rstd1, z, s2, mean2, rstd2,
                                   q_w, k_w, v_w, o_w, ln1_w, f1_w, f2_w, ln2_w)
@@ -119,8 +119,9 @@ class _TextLayerFn(torch.autograd.Function):
          q_w, k_w, v_w, o_w, ln1_w, f1_w, f2_w, ln2_w) = ctx.saved_tensors
         x_pl, c_pl, sa_pl, h = ctx.planes
         B, L, H, eps, drop = ctx.geom
-        wc = ctx.wc
-        Pb = Precision.bwd_passes
+        ec = ctx.ec
+        wc = ec.wc
+        Pb = ec.bwd_passes
         if Pb > ctx.P:
             raise RuntimeError("backward precision bf16x3 needs a bf16x3 forward")
         M, D = s1.shape
@@ -134,23 +135,23 @@ class _TextLayerFn(torch.autograd.Function):
         g_pl = ops.split_f32(ops.dropout(d_s2, drop[2], drop[3]) if drop[2] > 0 else d_s2, Pb)[0]
         Hd = f1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
-        ops.gemm_nt(g_pl, Wt(f2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D)
-        _, d_f2w, d_f2b = _lin_bwd(g_pl, h, None, Pb, need_dx=False)
-        _, d_f1w, d_f1b = _lin_bwd(dZ, sa_pl, None, Pb, need_dx=False)
+        ops.gemm_nt(g_pl, Wt(f2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D, ec=ec)
+        _, d_f2w, d_f2b = _lin_bwd(g_pl, h, None, Pb, need_dx=False, params=(f2_w,), ec=ec)
+        _, d_f1w, d_f1b = _lin_bwd(dZ, sa_pl, None, Pb, need_dx=False, params=(f1_w,), ec=ec)
         d_sa = torch.empty((M, D), dtype=torch.float32, device=G.device)     # = d_s2 + dZ . W1
-        ops.gemm_nt(dZ, Wt(f1_w), passes=Pb, residual=d_s2, out_f32=d_sa, K=Hd)
+        ops.gemm_nt(dZ, Wt(f1_w), passes=Pb, residual=d_s2, out_f32=d_sa, K=Hd, ec=ec)
         d_s1, d_ln1w, d_ln1b = ops.layernorm_bwd(d_sa, s1, ln1_w, mean1, rstd1)
         # attention output projection
-        d_ctx, d_ow, d_ob = _lin_bwd(d_s1, c_pl, Wt(o_w), Pb)
+        d_ctx, d_ow, d_ob = _lin_bwd(d_s1, c_pl, Wt(o_w), Pb, params=(o_w,), ec=ec)
         D3 = 3 * D
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         _, _, _, dqkv = ops.text_attn_bwd(q, k, v, mask, d_ctx, lse, B, L, H, Pb, fused_out=True, dropout_p=drop[0],
                                           seed=drop[1])
         # fused q/k/v projection backward: one wgrad (dW [2304, 768] + bias grads) and one dgrad chained onto d_s1
         dqkv_pl = ops.split_f32(dqkv, Pb)[0]
-        _, dW3, db3 = _lin_bwd(dqkv_pl, x_pl, None, Pb, need_dx=False)
+        _, dW3, db3 = _lin_bwd(dqkv_pl, x_pl, None, Pb, need_dx=False, params=(q_w, k_w, v_w), ec=ec)
         acc = torch.empty((M, D), dtype=torch.float32, device=G.device)
-        ops.gemm_nt(dqkv_pl, wc.get_cat((q_w, k_w, v_w), need_t=True)[1], passes=Pb, residual=d_s1, out_f32=acc, K=D3)
+        ops.gemm_nt(dqkv_pl, wc.get_cat((q_w, k_w, v_w), need_t=True)[1], passes=Pb, residual=d_s1, out_f32=acc, K=D3, ec=ec)
         grads = [dW3[:D], db3[:D], dW3[D:2 * D], db3[D:2 * D], dW3[2 * D:], db3[2 * D:]]
         return (acc.view(B, L, D), None, None, None, *grads, d_ow, d_ob, d_ln1w, d_ln1b,
                 d_f1w, d_f1b, d_f2w, d_f2b, d_ln2w, d_ln2b)
@@ -191,12 +192,12 @@ class TransformerBlock(nn.Module):
         self.ffn = FFN(config)
         self.output_layer_norm = nn.LayerNorm(config.dim, eps=1e-12)
 
-    def forward(self, x, mask, wc, drop=(0.0, 0, 0.0, 0)):
+    def forward(self, x, mask, ec, drop=(0.0, 0, 0.0, 0)):
         B, L, D = x.shape
         a, f = self.attention, self.ffn
         geom = (B, L, a.n_heads, self.sa_layer_norm.eps, drop)
         return _TextLayerFn.apply(
-            x, mask, geom, wc,
+            x, mask, geom, ec,
             a.q_lin.weight, a.q_lin.bias, a.k_lin.weight, a.k_lin.bias, a.v_lin.weight, a.v_lin.bias,
             a.out_lin.weight, a.out_lin.bias, self.sa_layer_norm.weight, self.sa_layer_norm.bias,
             f.lin1.weight, f.lin1.bias, f.lin2.weight, f.lin2.bias,
@@ -219,7 +220,8 @@ class DistilBertModel(nn.Module):
         self._drop_calls = 0            # every train-mode forward draws fresh masks: seed = f(torch seed, call #, site)
         self.embeddings = Embeddings(self.config)
         self.transformer = Transformer(self.config)
-        self._wc = WeightCache()
+        self.exec_ctx = ops.new_context()     # FrozenInTime replaces it with the dual encoder's shared context
+        self.seed_rank = 0                    # mixed into the dropout seeds: data-parallel ranks must not draw the same masks
         # HF init (initializer_range 0.02) so random-init statistics match `DistilBertModel(DistilBertConfig())`
         for m in self.modules():
             if isinstance(m, nn.Linear):
@@ -235,7 +237,8 @@ class DistilBertModel(nn.Module):
 
     def _seed(self, site):
         # 64-bit seed of one dropout site of one forward call: torch's seed, the call counter and the site id, mixed
-        x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03 + site * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        x = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03 + site * 0x94D049BB133111EB
+             + self.seed_rank * 0xA24BAED4963EE407) & (2 ** 64 - 1)
         x ^= x >> 31
         return (x * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
 
@@ -257,5 +260,5 @@ class DistilBertModel(nn.Module):
                            (pd, self._seed(0)))
         mask = attention_mask.to(torch.int64).contiguous()
         for li, blk in enumerate(self.transformer.layer):
-            x = blk(x, mask, self._wc, (pa, self._seed(1 + 2 * li), pd, self._seed(2 + 2 * li)))
+            x = blk(x, mask, self.exec_ctx, (pa, self._seed(1 + 2 * li), pd, self._seed(2 + 2 * li)))
         return SimpleNamespace(last_hidden_state=x)

@@ -20,8 +20,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..ops import ACT_GELU, ACT_GELU_BWD, Planes, Precision
-from ..weights import WeightCache
+from ..ops import ACT_GELU, ACT_GELU_BWD, ExecContext, Planes
 
 
 # The dgrad GEMMs that feed LayerNorm-backward write fp32: handing dy over as bf16 planes instead halves those bytes but
@@ -30,33 +29,40 @@ from ..weights import WeightCache
 _LN_DY_PLANES = os.environ.get("EGV_LN_DY_PLANES", "0") == "1"
 
 
-def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False):
+def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, params=(), ec: ExecContext = None):
     """Backward of y = x W^T + b.  `dy` is fp32 [M,N] (split to bf16 planes here, one pass, no transpose) or
     already-split row-major Planes.  The SAME row-major planes feed both gradients: dgrad contracts over N
     (dy . W, weights cached transposed) and wgrad contracts over the M token rows with the TN kernel
     (dy^T x via the CDNA4 transpose read, bias gradient from the same pass).
+    `params`: the parameters (weight, bias) the returned dW / db will be accumulated into by autograd; `ec`: the model's
+    execution context (side stream, grid cap).
     -> (dx fp32 [M,K] | None, dW fp32 [N,K], db [N])."""
+    ec = ops.DEFAULT if ec is None else ec
     if not isinstance(dy, Planes):
         dy = ops.split_f32(dy, Pb)[0]
     M, K = x_pl.rows, x_pl.cols
     N = dy.cols
     dev = x_pl.hi.device
     # off the critical path: fills the CUs the dgrad chain leaves idle (ops.side_stream); the text tower's own backward is
-    # already off the video tower's stream (ops.TEXT_SIDE_STREAM) and keeps its small wgrads where they are
-    if ops.WGRAD_SIDE_STREAM and not ops.on_text_stream():
-        with ops.side_stream(dy.hi, dy.lo, x_pl.hi, x_pl.lo):
+    # already off the video tower's stream (ops.TEXT_SIDE_STREAM) and keeps its small wgrads where they are.
+    # The side stream is only safe while autograd's AccumulateGrad STEALS dW (parameter.grad is None: zero_grad(set_to_none=True),
+    # one backward per step): with a gradient already in place it enqueues `grad += dW` on the node's stream, which is not
+    # ordered behind the side stream -- such wgrads (gradient accumulation, set_to_none=False) stay on the main stream.
+    accumulating = any(p_ is not None and p_.grad is not None for p_ in params)
+    if ec.wgrad_side_stream and not ec.on_text_stream() and not accumulating:
+        with ec.side_stream(dy.hi, dy.lo, x_pl.hi, x_pl.lo):
             dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-            db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True)
+            db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec)
     else:
         dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-        db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True)
+        db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec)
     dx = None
     if need_dx and dx_planes:      # dx feeds a kernel that consumes planes (attention backward): no fp32 copy at all
         dx = ops.empty_planes(M, K, Pb, dev)
-        ops.gemm_nt(dy, wt, passes=Pb, out_planes=dx, K=N)
+        ops.gemm_nt(dy, wt, passes=Pb, out_planes=dx, K=N, ec=ec)
     elif need_dx:
         dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-        ops.gemm_nt(dy, wt, passes=Pb, out_f32=dx, K=N)
+        ops.gemm_nt(dy, wt, passes=Pb, out_f32=dx, K=N, ec=ec)
     return dx, dW, db
 
 
@@ -96,7 +102,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, geom, wc: WeightCache,
+    def forward(ctx, x, geom, ec: ExecContext,
                 n3w, n3b, tqkv_w, tqkv_b, tproj_w, tproj_b,
                 n1w, n1b, sqkv_w, sqkv_b, sproj_w, sproj_b,
                 n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
@@ -104,7 +110,8 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         S = 1 + T * n
         D = x.shape[-1]
         M = B * S
-        P = Precision.fwd_passes
+        P = ec.fwd_passes
+        wc = ec.wc
         dev = x.device
         x2 = x.contiguous().view(M, D)
         train = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward; this is the reliable signal
@@ -115,17 +122,17 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         # ---- temporal attention branch (:166-167)
         n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P)
         qkv_t = ops.empty_planes(M, 3 * D, P, dev)       # qkv never exists in fp32: the attention kernels read planes
-        ops.gemm_nt(n3, W(tqkv_w), passes=P, bias=tqkv_b, out_planes=qkv_t)
+        ops.gemm_nt(n3, W(tqkv_w), passes=P, bias=tqkv_b, out_planes=qkv_t, ec=ec)
         a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, P)
         tr = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(a_t, W(tproj_w), passes=P, bias=tproj_b, residual=x2, out_f32=tr)
+        ops.gemm_nt(a_t, W(tproj_w), passes=P, bias=tproj_b, residual=x2, out_f32=tr, ec=ec)
         # ---- spatial attention branch (:168-171)
         n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P)
         qkv_s = ops.empty_planes(M, 3 * D, P, dev)
-        ops.gemm_nt(n1, W(sqkv_w), passes=P, bias=sqkv_b, out_planes=qkv_s)
+        ops.gemm_nt(n1, W(sqkv_w), passes=P, bias=sqkv_b, out_planes=qkv_s, ec=ec)
         a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, P)
         sr = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(a_s, W(sproj_w), passes=P, bias=sproj_b, residual=x2, out_f32=sr)
+        ops.gemm_nt(a_s, W(sproj_w), passes=P, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
         # ---- MLP (:175, Mlp.forward :46-52), exact-erf GELU fused into the fc1 epilogue
         n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P)
         Hd = fc1_w.shape[0]
@@ -133,15 +140,15 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         # saved for backward: the fp32 pre-activation z in the all-bf16x3 parity mode; when backward runs single-pass bf16
         # anyway, gelu'(z) itself as bf16 -- the epilogue has Phi(z) and phi(z) in registers, the buffer is half the bytes,
         # and the fc2-dgrad epilogue becomes one multiply instead of a second erf evaluation over 77 M elements
-        z_dtype = torch.bfloat16 if (Precision.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D)) else torch.float32
+        z_dtype = torch.bfloat16 if (ec.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D)) else torch.float32
         z = torch.empty((M, Hd), dtype=z_dtype, device=dev) if train else None
         ops.gemm_nt(n2, W(fc1_w), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
-                    aux_is_grad=z is not None and z_dtype == torch.bfloat16)
+                    aux_is_grad=z is not None and z_dtype == torch.bfloat16, ec=ec)
         out = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(h, W(fc2_w), passes=P, bias=fc2_b, residual=sr, out_f32=out)
+        ops.gemm_nt(h, W(fc2_w), passes=P, bias=fc2_b, residual=sr, out_f32=out, ec=ec)
 
         if train:
-            ctx.geom, ctx.wc, ctx.P = geom, wc, P
+            ctx.geom, ctx.ec, ctx.P = geom, ec, P
             ctx.planes = (n3, a_t, n1, a_s, n2, h, qkv_t, qkv_s)
             ctx.save_for_backward(x2, mean3, rstd3, lse_t, tr, mean1, rstd1, lse_s, sr, mean2, rstd2, z,
                                   n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w)
@@ -153,10 +160,10 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
          n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w) = ctx.saved_tensors
         n3, a_t, n1, a_s, n2, h, qkv_t, qkv_s = ctx.planes
         B, T, n, H, eps = ctx.geom
-        wc = ctx.wc
-        Pb = Precision.bwd_passes
-        if ops.BACKWARD_POLL is not None:
-            ops.BACKWARD_POLL()         # gradients of the blocks behind this one are final: the data-parallel exchange may start
+        ec = ctx.ec
+        wc = ec.wc
+        Pb = ec.bwd_passes
+        ec.poll_backward()              # gradients of the blocks behind this one are final: the data-parallel exchange may start
         if Pb > ctx.P:
             raise RuntimeError("backward precision bf16x3 needs a bf16x3 forward (the saved activation planes carry no lo part)")
         M, D = x2.shape
@@ -170,20 +177,20 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         Hd = fc1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D,
-                    aux_is_grad=z.dtype == torch.bfloat16)
-        _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False)
-        d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, dx_planes=_LN_DY_PLANES)   # LayerNorm backward reads planes
+                    aux_is_grad=z.dtype == torch.bfloat16, ec=ec)
+        _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False, params=(fc2_w,), ec=ec)
+        d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, dx_planes=_LN_DY_PLANES, params=(fc1_w,), ec=ec)   # LayerNorm backward reads planes
         # d_sr = G + LN2'(d_n2)
         d_sr, d_n2w, d_n2b, d_sr_pl = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G, planes_passes=Pb)
         # ---- spatial attention backward
-        d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb, dx_planes=True)
+        d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb, dx_planes=True, params=(sproj_w,), ec=ec)
         d_qkv_s = ops.divided_attn_bwd(qkv_s, a_s, d_as, lse_s, B, T, n, H, 0, Pb)
-        d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb, dx_planes=_LN_DY_PLANES)
+        d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb, dx_planes=_LN_DY_PLANES, params=(sqkv_w,), ec=ec)
         d_tr, d_n1w, d_n1b, d_tr_pl = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1, planes_passes=Pb)
         # ---- temporal attention backward
-        d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb, dx_planes=True)
+        d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb, dx_planes=True, params=(tproj_w,), ec=ec)
         d_qkv_t = ops.divided_attn_bwd(qkv_t, a_t, d_at, lse_t, B, T, n, H, 1, Pb)
-        d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb, dx_planes=_LN_DY_PLANES)
+        d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb, dx_planes=_LN_DY_PLANES, params=(tqkv_w,), ec=ec)
         # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
         d_x, d_n3w, d_n3b, d_x_pl = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr,
                                                        planes_passes=Pb)
@@ -199,9 +206,10 @@ class _PatchTokensFn(torch.autograd.Function):
     -> token assembly.  No gradient flows to the input frames."""
 
     @staticmethod
-    def forward(ctx, video, geom, wc, proj_w, proj_b, cls_token, pos_embed, temporal_embed):
+    def forward(ctx, video, geom, ec, proj_w, proj_b, cls_token, pos_embed, temporal_embed):
         B, T, n, P_, D, T_model = geom[:6]
-        Pp = Precision.fwd_passes
+        Pp = ec.fwd_passes
+        wc = ec.wc
         mean, std = geom[6] if len(geom) > 6 else (ops.IMAGENET_MEAN, ops.IMAGENET_STD)
         aug = geom[7] if len(geom) > 7 else None
         # uint8 frames: /255 + Normalize (and, with `aug`, the train transform's crop / resize / flip) inside the gather
@@ -212,18 +220,20 @@ class _PatchTokensFn(torch.autograd.Function):
         else:   # ViT-L/14: K = 588 is zero-padded to the 64-deep k-tile on both operands
             w_pl = ops.split_f32(torch.nn.functional.pad(proj_w.detach().reshape(D, K), (0, a.cols - K)), Pp)[0]
         pe = torch.empty((a.rows, D), dtype=torch.float32, device=video.device)
-        ops.gemm_nt(a, w_pl, passes=Pp, bias=proj_b, out_f32=pe)
+        ops.gemm_nt(a, w_pl, passes=Pp, bias=proj_b, out_f32=pe, ec=ec)
         x = ops.assemble_tokens(pe, cls_token, pos_embed, temporal_embed, B, T, n, D)
-        ctx.geom, ctx.a, ctx.Pp = geom, a, Pp
-        ctx.wshape = proj_w.shape
+        ctx.geom, ctx.a, ctx.Pp, ctx.ec = geom, a, Pp, ec
+        ctx.wshape, ctx.proj_w = proj_w.shape, proj_w
         return x
 
     @staticmethod
     def backward(ctx, dx):
         B, T, n, P_, D, T_model = ctx.geom[:6]
-        Pb = Precision.bwd_passes
+        ec = ctx.ec
+        Pb = ec.bwd_passes
+        ec.poll_backward()              # every block's gradients are final here
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
-        _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False)
+        _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False, params=(ctx.proj_w,), ec=ec)
         K = ctx.wshape[1] * ctx.wshape[2] * ctx.wshape[3]
         if d_w.shape[1] != K:
             d_w = d_w[:, :K].contiguous()      # drop the zero-padded k columns
@@ -234,22 +244,24 @@ class _ClsNormFn(torch.autograd.Function):
     """`self.norm(x)[:, 0]` (:330): LayerNorm is per token, so only the B CLS rows are normalised."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, ec):
         B, S, D = x.shape
         xc = x.contiguous()
         _, y, mean, rstd, _ = ops.layernorm_fwd(xc.view(B * S, D), w, b, eps, 1, want_f32=True, want_planes=False,
                                                 rows=B, ldx=S * D)
         ctx.save_for_backward(xc, w, mean, rstd)
+        ctx.ec = ec
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xc, w, mean, rstd = ctx.saved_tensors
         B, S, D = xc.shape
+        ctx.ec.poll_backward()          # first node of the video tower's backward: what ran before it (the text tower) is final
         dx = ops.zeros(tuple(xc.shape), device=xc.device)     # only the B CLS rows receive a gradient
         _, dg, db = ops.layernorm_bwd(dy.contiguous(), xc.view(B * S, D), w, mean, rstd, rows=B, ldx=S * D,
                                       dx=dx.view(B * S, D), lddx=S * D)
-        return dx, dg, db, None
+        return dx, dg, db, None, None
 
 
 def to_2tuple(x):
@@ -327,10 +339,10 @@ class SpaceTimeBlock(nn.Module):
         self.num_heads = num_heads
         self.attention_style = attention_style
 
-    def forward(self, x, B, T, n, wc):
+    def forward(self, x, B, T, n, ec):
         geom = (B, T, n, self.num_heads, self.norm1.eps)
         return _SpaceTimeBlockFn.apply(
-            x, geom, wc,
+            x, geom, ec,
             self.norm3.weight, self.norm3.bias, self.timeattn.qkv.weight, self.timeattn.qkv.bias,
             self.timeattn.proj.weight, self.timeattn.proj.bias,
             self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias,
@@ -376,7 +388,7 @@ class SpaceTimeTransformer(nn.Module):
         nn.init.trunc_normal_(self.cls_token, std=.02, a=-2., b=2.)
         if num_frames == 1:                                                    # :272-273
             self.apply(self._init_weights)
-        self._wc = WeightCache()
+        self.exec_ctx = ops.new_context()     # FrozenInTime replaces it with the dual encoder's shared context
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -415,11 +427,12 @@ class SpaceTimeTransformer(nn.Module):
         # arrive as decoded uint8 (then x / 255 and the normalisation are fused into the patch gather on the device)
         geom = (b, curr_frames, n, P_, self.embed_dim, self.num_frames,
                 getattr(self, "input_norm", (ops.IMAGENET_MEAN, ops.IMAGENET_STD)), aug)
-        x = _PatchTokensFn.apply(x, geom, self._wc, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
+        ec = self.exec_ctx
+        x = _PatchTokensFn.apply(x, geom, ec, self.patch_embed.proj.weight, self.patch_embed.proj.bias,
                                  self.cls_token, self.pos_embed, self.temporal_embed)
         for blk in self.blocks:                                                # :325-328
-            x = blk(x, b, curr_frames, n, self._wc)
-        x = _ClsNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)   # :330
+            x = blk(x, b, curr_frames, n, ec)
+        x = _ClsNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, ec)   # :330
         return self.pre_logits(x)
 
     def forward(self, x):

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 from typing import Optional
 
@@ -23,81 +24,177 @@ from ._lib import GemmDesc, check
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 
 
-class Precision:
-    """Global precision policy.  'bf16x3' = split-bf16, three MFMA passes, fp32-grade (meets the
-    1e-3 parity bar); 'bf16' = single pass.  fwd/bwd are set independently."""
-    fwd_passes = 3
-    bwd_passes = 3
-
-    @classmethod
-    def set(cls, fwd: str = "bf16x3", bwd: Optional[str] = None):
-        table = {"bf16x3": 3, "bf16": 1}
-        cls.fwd_passes = table[fwd]
-        cls.bwd_passes = table[bwd if bwd is not None else fwd]
-
-    @classmethod
-    def name(cls):
-        inv = {3: "bf16x3", 1: "bf16"}
-        return inv[cls.fwd_passes], inv[cls.bwd_passes]
-
-
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
-
-
-# ---- side stream for work that is OFF the critical path of backward (the weight gradients) --------------------------------
-# dW = dY^T X is needed only by the optimizer, while the dgrad chain of backward waits for nothing but dX.  With
-# WGRAD_SIDE_STREAM on, every wgrad GEMM (and its split-K reduce) is enqueued on a second HIP stream behind an event of the
-# main stream: its persistent workgroups fill the CUs that the main stream's kernels leave idle (last partial round of a
-# tile grid, drain tails, the launch gaps of the small kernels).  The main stream re-joins at the end of backward (an autograd
-# engine callback queued by the first wgrad of the pass) and before any gradient hook reads a wgrad (`join_side_stream`).
-# OFF by default in the library: code that reads a weight gradient from an autograd hook DURING backward without calling
-# `join_streams_for_gradient_hook()` first (torch's DistributedDataParallel does) would race with the side stream.  The callers
-# that own their hooks turn it on: bench.py and Multi_BaseTrainer_dist (Bf16GradSync joins; +1.1 .. 1.7 % step rate).
-WGRAD_SIDE_STREAM = os.environ.get("EGV_WGRAD_SIDE", "0") == "1"
-_SIDE = {"stream": None, "main": None, "dirty": False, "queued": False}
+# ---------------------------------------------------------------------------------------------- execution context
+# Everything that used to be process-global on the hot path (precision policy, side streams and their bookkeeping, the
+# persistent-grid cap of the big GEMM, the backward poll of the data-parallel exchange, the kernel timer) lives in an
+# `ExecContext`.  Every model owns one (FrozenInTime.exec_ctx, shared with its two towers) and hands it to its autograd
+# functions, so two models -- or one model per thread / per device -- share nothing: the C ABI underneath is stateless and
+# re-entrant (include/egovlp_hip.h; the reference's DDP reducer thread is the caller this has to survive,
+# base/base_trainer.py:258).  SETTINGS a context does not set itself are inherited from its parent; `DEFAULT` is the root, and
+# the module-level names of earlier rounds (`Precision.set`, `ops.WGRAD_SIDE_STREAM = ...`, `ops.BACKWARD_POLL = ...`,
+# `ops.KERNEL_TIMER`, `ops.set_gemm_grid`) are views of DEFAULT's settings, kept for scripts and tests.  STATE (stream objects,
+# the dirty / queued flags of the wgrad stream, the weight-plane cache) is private to a context and never inherited.
+_PASSES = {"bf16x3": 3, "bf16": 1}
+_PASSES_INV = {3: "bf16x3", 1: "bf16"}
+_HARD_DEFAULTS = {
+    "fwd_passes": 3, "bwd_passes": 3,
+    # weight-gradient GEMMs on their own HIP stream.  OFF unless the owner of the gradient hooks turns it on (bench.py and
+    # Multi_BaseTrainer_dist do): code that reads a weight gradient from an autograd hook DURING backward without calling
+    # `join_streams_for_gradient_hook()` first (torch's DistributedDataParallel does) would race with the side stream.
+    "wgrad_side_stream": os.environ.get("EGV_WGRAD_SIDE", "0") == "1",
+    # the DistilBERT tower on a second HIP stream under the video tower (model/model.py FrozenInTime.forward)
+    "text_side_stream": os.environ.get("EGV_TEXT_SIDE", "1") == "1",
+    # persistent workgroups of the big GEMM: 256 = one per CU; data-parallel runs use 248 so that the RCCL kernels of the
+    # overlapped gradient exchange find free CUs.  Travels in egv_gemm_desc.grid_cap; the wgrad split-K policy follows it.
+    "gemm_grid": 256,
+    # called (if set) at points of backward where earlier gradients are final (entry of every SpaceTimeBlock backward, of the
+    # patch-embed / CLS-norm / projection nodes on the main stream): the hook-free gradient exchange hangs off it
+    # (egovlp_amd.dist.Bf16GradSync(use_hooks=False).poll)
+    "backward_poll": None,
+    "kernel_timer": None,
+}
 
 
-# The text tower on its own stream under the video tower (model/model.py FrozenInTime.forward).
-TEXT_SIDE_STREAM = os.environ.get("EGV_TEXT_SIDE", "1") == "1"
-_TEXT = {"stream": None, "main": None}   # "main": the stream forward() forked the text tower from
+class ExecContext:
+    def __init__(self, parent=None, **settings):
+        unknown = set(settings) - set(_HARD_DEFAULTS)
+        if unknown:
+            raise TypeError(f"ExecContext: unknown settings {sorted(unknown)}")
+        self.parent = parent
+        self._s = dict(settings)
+        self._side = {"stream": None, "main": None, "dirty": False, "queued": False}
+        self._text = {"stream": None, "main": None}     # "main": the stream forward() forked the text tower from
+        self._wc = None
+
+    # ---- settings (inherited) ------------------------------------------------------------------------------------------
+    def get(self, key):
+        c = self
+        while c is not None:
+            if key in c._s:
+                return c._s[key]
+            c = c.parent
+        return _HARD_DEFAULTS[key]
+
+    def set(self, **settings):
+        unknown = set(settings) - set(_HARD_DEFAULTS)
+        if unknown:
+            raise TypeError(f"ExecContext: unknown settings {sorted(unknown)}")
+        if "gemm_grid" in settings:
+            g = int(settings["gemm_grid"])
+            if not (8 <= g <= 256 and g % 8 == 0):
+                raise ValueError("gemm_grid: a multiple of 8 in [8, 256]")
+        self._s.update(settings)
+        return self
+
+    def unset(self, *keys):
+        for k in keys:
+            self._s.pop(k, None)
+        return self
+
+    def set_precision(self, fwd: str = "bf16x3", bwd: Optional[str] = None):
+        """'bf16x3' = split-bf16, three MFMA products, fp32-grade (meets the 1e-3 parity bar); 'bf16' = single pass."""
+        return self.set(fwd_passes=_PASSES[fwd], bwd_passes=_PASSES[bwd if bwd is not None else fwd])
+
+    def precision_name(self):
+        return _PASSES_INV[self.fwd_passes], _PASSES_INV[self.bwd_passes]
+
+    fwd_passes = property(lambda self: self.get("fwd_passes"))
+    bwd_passes = property(lambda self: self.get("bwd_passes"))
+    wgrad_side_stream = property(lambda self: self.get("wgrad_side_stream"))
+    text_side_stream = property(lambda self: self.get("text_side_stream"))
+    gemm_grid = property(lambda self: self.get("gemm_grid"))
+    backward_poll = property(lambda self: self.get("backward_poll"))
+    kernel_timer = property(lambda self: self.get("kernel_timer"))
+
+    def poll_backward(self):
+        fn = self.get("backward_poll")
+        if fn is not None:
+            fn()
+
+    # ---- state (private) -----------------------------------------------------------------------------------------------
+    @property
+    def wc(self):
+        """The split-bf16 operand planes of this context's weights (egovlp_amd.weights.WeightCache)."""
+        if self._wc is None:
+            from .weights import WeightCache
+            self._wc = WeightCache()
+        return self._wc
+
+    def text_stream(self):
+        if self._text["stream"] is None:
+            self._text["stream"] = torch.cuda.Stream()
+        return self._text["stream"]
+
+    def on_text_stream(self):
+        return self._text["stream"] is not None and torch.cuda.current_stream() == self._text["stream"]
+
+    def on_side_stream(self):
+        return self._side["stream"] is not None and torch.cuda.current_stream() == self._side["stream"]
+
+    # The wgrad side stream.  dW = dY^T X is needed only by the optimizer, while the dgrad chain of backward waits for nothing
+    # but dX.  With `wgrad_side_stream` on, every wgrad GEMM (and its split-K reduce) is enqueued on a second HIP stream behind
+    # an event of the main stream: its persistent workgroups fill the CUs that the main stream's kernels leave idle (last
+    # partial round of a tile grid, drain tails, the launch gaps of the small kernels).  The main stream re-joins at the end of
+    # backward (an autograd engine callback queued by the first wgrad of the pass), before any gradient hook reads a wgrad
+    # (`join_streams_for_gradient_hook`) and, unconditionally, in egoclip_step before the optimizer.
+    def side_stream(self, *inputs):
+        """`with ec.side_stream(*inputs):` -- enqueue the body on the side stream, ordered after everything already enqueued on
+        the current stream; `inputs` are the tensors the body reads (kept alive for the side stream by the allocator)."""
+        return _SideStream(self, inputs)
+
+    def begin_step(self):
+        """Start of a forward / backward pass: forget a join callback that never ran (a backward that raised leaves
+        'queued' set and later passes would not queue theirs)."""
+        self._side["queued"] = False
+
+    def join_side_stream(self):
+        """Make the main stream (the one the side work was forked from) and the current stream wait for everything enqueued on
+        the side stream."""
+        sd = self._side
+        if sd["dirty"]:
+            sd["main"].wait_stream(sd["stream"])
+            cur = torch.cuda.current_stream()
+            if cur != sd["main"]:
+                cur.wait_stream(sd["stream"])
+            sd["dirty"] = False
+
+    def _join_callback(self):
+        self._side["queued"] = False
+        self.join_side_stream()
+
+    def join_streams_for_gradient_hook(self):
+        """Gradient hooks run when a gradient has been ENQUEUED, on the stream of the node that produced it; a hook that reads
+        gradients of several parameters (a bucket of the data-parallel exchange) must first order its stream behind the other
+        streams gradients are produced on: the wgrad side stream and the text tower's stream."""
+        self.join_side_stream()
+        tx = self._text
+        if tx["stream"] is not None:
+            cur = torch.cuda.current_stream()
+            if cur != tx["stream"]:
+                cur.wait_stream(tx["stream"])
+            elif tx.get("main") is not None:
+                cur.wait_stream(tx["main"])       # a hook on the text stream that also reads gradients of the video tower
 
 
-def text_stream():
-    if _TEXT["stream"] is None:
-        _TEXT["stream"] = torch.cuda.Stream()
-    return _TEXT["stream"]
-
-
-def on_text_stream():
-    return _TEXT["stream"] is not None and torch.cuda.current_stream() == _TEXT["stream"]
-
-
-# Called (if set) at the entry of every SpaceTimeBlock backward: the gradients of all later blocks are final there.  The
-# hook-free gradient exchange (egovlp_amd.dist.Bf16GradSync(use_hooks=False).poll) hangs off it.
-BACKWARD_POLL = None
-
-
-class side_stream:
-    """`with side_stream(*inputs):` -- enqueue the body on the side stream, ordered after everything already enqueued on the
-    current stream; `inputs` are the tensors the body reads (kept alive for the side stream by the caching allocator)."""
-
-    def __init__(self, *inputs):
+class _SideStream:
+    def __init__(self, ec: ExecContext, inputs):
+        self.ec = ec
         self.inputs = [t for t in inputs if t is not None]
 
     def __enter__(self):
+        sd = self.ec._side
         main = torch.cuda.current_stream()
-        if _SIDE["stream"] is None:
-            _SIDE["stream"] = torch.cuda.Stream()
-        side = _SIDE["stream"]
+        if sd["stream"] is None:
+            sd["stream"] = torch.cuda.Stream()
+        side = sd["stream"]
         side.wait_stream(main)
         for t in self.inputs:
             t.record_stream(side)
-        _SIDE["main"], _SIDE["dirty"] = main, True
-        if not _SIDE["queued"]:
+        sd["main"], sd["dirty"] = main, True
+        if not sd["queued"]:
             try:   # inside a backward pass: join when the pass ends, whoever called backward()
-                torch.autograd.Variable._execution_engine.queue_callback(_join_callback)
-                _SIDE["queued"] = True
+                torch.autograd.Variable._execution_engine.queue_callback(self.ec._join_callback)
+                sd["queued"] = True
             except RuntimeError:
                 pass
         self.ctx = torch.cuda.stream(side)
@@ -108,32 +205,48 @@ class side_stream:
         return self.ctx.__exit__(*exc)
 
 
-def _join_callback():
-    _SIDE["queued"] = False
-    join_side_stream()
+DEFAULT = ExecContext()
 
 
-def join_side_stream():
-    """Make the main stream (the one the side work was forked from) wait for everything enqueued on the side stream."""
-    if _SIDE["dirty"]:
-        _SIDE["main"].wait_stream(_SIDE["stream"])
-        cur = torch.cuda.current_stream()
-        if cur != _SIDE["main"]:
-            cur.wait_stream(_SIDE["stream"])
-        _SIDE["dirty"] = False
+def new_context(**settings) -> ExecContext:
+    """A context with private state whose unset settings follow DEFAULT (what every model creates for itself)."""
+    return ExecContext(DEFAULT, **settings)
 
 
-def join_streams_for_gradient_hook():
-    """Gradient hooks run when a gradient has been ENQUEUED, on the stream of the node that produced it; a hook that reads
-    gradients of several parameters (a bucket of the data-parallel exchange) must first order its stream behind the other
-    streams gradients are produced on: the wgrad side stream and the text tower's stream."""
-    join_side_stream()
-    if _TEXT["stream"] is not None:
-        cur = torch.cuda.current_stream()
-        if cur != _TEXT["stream"]:
-            cur.wait_stream(_TEXT["stream"])
-        elif _TEXT.get("main") is not None:
-            cur.wait_stream(_TEXT["main"])       # a hook on the text stream that also reads gradients of the video tower
+class _PrecisionMeta(type):
+    fwd_passes = property(lambda cls: DEFAULT.fwd_passes)
+    bwd_passes = property(lambda cls: DEFAULT.bwd_passes)
+
+
+class Precision(metaclass=_PrecisionMeta):
+    """The DEFAULT context's precision policy (what every model follows unless its own context overrides it)."""
+
+    @classmethod
+    def set(cls, fwd: str = "bf16x3", bwd: Optional[str] = None):
+        DEFAULT.set_precision(fwd, bwd)
+
+    @classmethod
+    def name(cls):
+        return DEFAULT.precision_name()
+
+
+def set_gemm_grid(workgroups: int) -> int:
+    """DEFAULT's persistent-workgroup cap of the big GEMM -> the previous cap.  Multiples of 8 in [8, 256]."""
+    prev = DEFAULT.gemm_grid
+    if 8 <= workgroups <= 256 and workgroups % 8 == 0:
+        DEFAULT.set(gemm_grid=int(workgroups))
+    return prev
+
+
+def _stream(t=None):
+    """The HIP stream the next kernel is enqueued on: the current stream of the device `t` lives on.  Launching for a tensor
+    of another device than the current one would run the kernel in the wrong HIP context: refuse (wrap the call in
+    `torch.cuda.device(t.device)`)."""
+    if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise _lib.EgovlpHipError(f"tensor on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: "
+                                  "egovlp_amd ops launch on the current device's current stream "
+                                  "(use `with torch.cuda.device(t.device):`)")
+    return torch.cuda.current_stream().cuda_stream
 
 
 class KernelTimer:
@@ -166,9 +279,6 @@ class KernelTimer:
                          "flops": float(sum(r[2] for r in recs)), "issue_flops": float(sum(r[3] for r in recs)),
                          "shapes": shapes}
         return out
-
-
-KERNEL_TIMER = None
 
 
 def _p(t):
@@ -211,25 +321,11 @@ def empty_planes(rows, cols, passes, device, ld=None, zero=False):
 def zeros(shape, dtype=torch.float32, device="cuda"):
     """torch.zeros without the ATen fill kernel: caching-allocator memory + one memset node on the current stream."""
     t = torch.empty(shape, dtype=dtype, device=device)
-    check(_lib.lib().egv_zero(_p(t), t.numel() * t.element_size(), _stream()), "egv_zero")
+    check(_lib.lib().egv_zero(_p(t), t.numel() * t.element_size(), _stream(t)), "egv_zero")
     return t
 
 
-# Persistent-workgroup cap of the big GEMM (egv_gemm_set_grid): 256 = one per CU; data-parallel runs lower it so that the RCCL
-# kernels of the overlapped gradient exchange find free CUs.  Kept here too because the wgrad split-K policy depends on it.
-GEMM_GRID = 256
-
-
-_WGRAD_KSPLIT_DIV = int(os.environ.get("EGV_WGRAD_KSPLIT_DIV", "0"))   # A/B override of the divisor below (0 = policy)
-
-
-def set_gemm_grid(workgroups: int) -> int:
-    """-> the previous cap.  Multiples of 8 in [8, 256]."""
-    global GEMM_GRID
-    prev = _lib.lib().egv_gemm_set_grid(int(workgroups))
-    if 8 <= workgroups <= 256 and workgroups % 8 == 0:
-        GEMM_GRID = int(workgroups)
-    return prev
+_WGRAD_KSPLIT_DIV = int(os.environ.get("EGV_WGRAD_KSPLIT_DIV", "0"))   # A/B override of the wgrad k-slice divisor (0 = policy)
 
 
 def pad32(n):
@@ -238,9 +334,12 @@ def pad32(n):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_NONE, aux_in=None, aux_out=None,
-            out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=None, K=None, aux_is_grad=False):
+            out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=None, K=None, aux_is_grad=False,
+            ec: Optional[ExecContext] = None):
     """C[M,N] = A[M,K] . B[N,K]^T with the fused epilogue of egv_gemm_nt.  A.rows = M, B.rows = N.
-    `aux_is_grad` (bf16 aux only): the GELU epilogue saves gelu'(z) instead of z and the GELU' epilogue multiplies by it."""
+    `aux_is_grad` (bf16 aux only): the GELU epilogue saves gelu'(z) instead of z and the GELU' epilogue multiplies by it.
+    `ec`: the caller's execution context (grid cap of the big kernel, kernel timer); DEFAULT when omitted."""
+    ec = DEFAULT if ec is None else ec
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
     if ksplit is None:
@@ -266,16 +365,17 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     if ksplit > 1:
         partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device)
     d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
-    d.trans, d.colsum = 0, None
+    d.trans, d.colsum, d.grid_cap = 0, None, ec.gemm_grid
     if d.aux_bf16 and not uses_big_gemm(M, N, K):
         raise ValueError("bf16 aux buffers are only supported by the big-tile GEMM kernel (see uses_big_gemm)")
-    if KERNEL_TIMER is not None:
-        KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * K,
-                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt"), passes,
-                          key=("gemm_big " if ksplit <= 1 and uses_big_gemm(M, N, K) else "gemm_nt(128x128) ")
-                          + f"NT M={M} N={N} K={K} x{passes}")
+    timer = ec.kernel_timer
+    if timer is not None:
+        timer.time("egv_gemm_nt", 2.0 * M * N * K,
+                   lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt"), passes,
+                   key=("gemm_big " if ksplit <= 1 and uses_big_gemm(M, N, K) else "gemm_nt(128x128) ")
+                   + f"NT M={M} N={N} K={K} x{passes}")
     else:
-        check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt")
+        check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt")
 
 
 def auto_ksplit_nt(M, N, K):
@@ -297,10 +397,11 @@ def uses_big_gemm(M, N, K):
     return M >= 256 and N >= 256 and K % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
 
 
-def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=None):
+def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=None, ec: Optional[ExecContext] = None):
     """C[M,N] = A^T . B with both operands stored k-major: A is [K, M] (a.rows = K, a.cols = M), B is [K, N].
     This is the weight gradient dW = dY^T X with K = #tokens; neither operand is ever transposed in HBM
     (egv_gemm_nt, trans = 1).  -> colsum[M] = sum_k A[k, :] (the bias gradient) when want_colsum."""
+    ec = DEFAULT if ec is None else ec
     Kd, M, N = a.rows, a.cols, b.cols
     if b.rows != Kd:
         raise ValueError("gemm_tn: operands disagree on the contraction length")
@@ -311,7 +412,7 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         a_t, cs = transpose_planes(a, passes, want_colsum=want_colsum)
         b_t, _ = transpose_planes(b, passes)
         Kc = pad32(Kd)
-        gemm_nt(a_t, b_t, passes=passes, out_f32=out_f32, ksplit=pick_ksplit(M, N, Kc), K=Kc)
+        gemm_nt(a_t, b_t, passes=passes, out_f32=out_f32, ksplit=pick_ksplit(M, N, Kc), K=Kc, ec=ec)
         return cs
     if ksplit is None:
         # as many k-slices as fit ONE round of the persistent grid (256 workgroups, or the data-parallel cap: a slice count
@@ -322,8 +423,8 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         # chip by itself, half the workgroups leave CUs to the main stream's kernels, and the fp32 slabs (and the reduce that
         # reads them) are half as big.  Same box: 796.6 -> 819.8 pairs/s (+2.9 %); a third: 788, a quarter: 635 -- the wgrads
         # then become the critical path (profiles/r02_ab_wgrad_ksplit.txt).
-        div = _WGRAD_KSPLIT_DIV or (2 if (_SIDE["stream"] is not None and torch.cuda.current_stream() == _SIDE["stream"]) else 1)
-        ksplit = max(1, min(GEMM_GRID // max(tiles, 1) // div, nkt // 2))
+        div = _WGRAD_KSPLIT_DIV or (2 if ec.on_side_stream() else 1)
+        ksplit = max(1, min(ec.gemm_grid // max(tiles, 1) // div, nkt // 2))
     d = GemmDesc()
     d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
     d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
@@ -333,13 +434,14 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
     partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
     d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
-    d.trans, d.colsum, d.aux_bf16 = 1, _p(cs), 0
-    if KERNEL_TIMER is not None:
-        KERNEL_TIMER.time("egv_gemm_nt", 2.0 * M * N * Kd,
-                          lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)"), passes,
-                          key=f"gemm_big TN M={M} N={N} K={Kd} x{passes}")
+    d.trans, d.colsum, d.aux_bf16, d.grid_cap = 1, _p(cs), 0, ec.gemm_grid
+    timer = ec.kernel_timer
+    if timer is not None:
+        timer.time("egv_gemm_nt", 2.0 * M * N * Kd,
+                   lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt(trans)"), passes,
+                   key=f"gemm_big TN M={M} N={N} K={Kd} x{passes}")
     else:
-        check(_lib.lib().egv_gemm_nt(C.byref(d), _stream()), "egv_gemm_nt(trans)")
+        check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt(trans)")
     return cs
 
 
@@ -363,7 +465,7 @@ def split_f32(x2d: torch.Tensor, passes, *, want_rowmajor=True, want_transposed=
         _p(x2d), x2d.stride(0), rows, cols,
         _p(pl.hi) if pl else None, _p(pl.lo) if pl else None, pl.ld if pl else 0,
         _p(tp.hi) if tp else None, _p(tp.lo) if tp else None, tp.ld if tp else 0,
-        _p(cs), _stream()), "egv_split_f32")
+        _p(cs), _stream(x2d)), "egv_split_f32")
     return pl, tp, cs
 
 
@@ -385,7 +487,7 @@ def split_f32_multi(jobs):
     TC = i32(*[j[7] for j in jobs])
     for j in jobs:
         _need_cuda(j[0])
-    check(_lib.lib().egv_split_f32_multi(n, X, LDX, R, Cc, HI, LO, LDO, THI, TLO, LDT, TC, _stream()), "egv_split_f32_multi")
+    check(_lib.lib().egv_split_f32_multi(n, X, LDX, R, Cc, HI, LO, LDO, THI, TLO, LDT, TC, _stream(jobs[0][0])), "egv_split_f32_multi")
 
 
 def transpose_planes(x: Planes, passes, want_colsum=False):
@@ -394,14 +496,14 @@ def transpose_planes(x: Planes, passes, want_colsum=False):
     tp = empty_planes(x.cols, x.rows, passes, dev, ld=pad32(x.rows))
     cs = torch.empty(x.cols, dtype=torch.float32, device=dev) if want_colsum else None
     check(_lib.lib().egv_transpose_planes(_p(x.hi), _p(x.lo) if passes == 3 else None, x.ld, x.rows, x.cols,
-                                          _p(tp.hi), _p(tp.lo), tp.ld, _p(cs), _stream()), "egv_transpose_planes")
+                                          _p(tp.hi), _p(tp.lo), tp.ld, _p(cs), _stream(x.hi)), "egv_transpose_planes")
     return tp, cs
 
 
 def relu_split(x2d: torch.Tensor, passes) -> Planes:
     rows, cols = x2d.shape
     pl = empty_planes(rows, cols, passes, x2d.device)
-    check(_lib.lib().egv_relu_split(_p(x2d), x2d.stride(0), rows, cols, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
+    check(_lib.lib().egv_relu_split(_p(x2d), x2d.stride(0), rows, cols, _p(pl.hi), _p(pl.lo), pl.ld, _stream(x2d)),
           "egv_relu_split")
     return pl
 
@@ -423,7 +525,7 @@ def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, 
     s = torch.empty_like(x2d) if want_sum else None
     check(_lib.lib().egv_layernorm_fwd(_p(x2d), _p(x_add), ldx, _p(gamma), _p(beta), float(eps), rows, cols, _p(s),
                                        _p(pl.hi) if pl else None, _p(pl.lo) if pl else None, _p(yf), cols,
-                                       _p(mean), _p(rstd), _stream()), "egv_layernorm_fwd")
+                                       _p(mean), _p(rstd), _stream(x2d)), "egv_layernorm_fwd")
     return pl, yf, mean, rstd, s
 
 
@@ -450,7 +552,7 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
         dy_args = (_p(dy2d), None, None, dy2d.stride(0))
     check(_lib.lib().egv_layernorm_bwd(*dy_args, _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
                                        cols, _p(add1), _p(add2), _p(dx), lddx, _p(pl.hi) if pl else None,
-                                       _p(pl.lo) if pl else None, _p(dg), _p(db), _p(work), _stream()),
+                                       _p(pl.lo) if pl else None, _p(dg), _p(db), _p(work), _stream(x2d)),
           "egv_layernorm_bwd")
     if planes_passes:
         return dx, dg, db, pl
@@ -485,20 +587,20 @@ def patch_gather(video5d, P, passes, norm_mean=IMAGENET_MEAN, norm_std=IMAGENET_
         mean, std = (C.c_float * Cc)(*norm_mean), (C.c_float * Cc)(*norm_std)
         if aug is not None:
             check(_lib.lib().egv_patch_gather_u8_aug(_p(video5d), B * T, T, Cc, video5d.shape[3], video5d.shape[4], H, P,
-                                                     _p(aug[0]), mean, std, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
+                                                     _p(aug[0]), mean, std, _p(pl.hi), _p(pl.lo), pl.ld, _stream(video5d)),
                   "egv_patch_gather_u8_aug")
             return pl
         check(_lib.lib().egv_patch_gather_u8(_p(video5d), B * T, Cc, H, W, P, mean, std, _p(pl.hi), _p(pl.lo), pl.ld,
-                                             _stream()), "egv_patch_gather_u8")
+                                             _stream(video5d)), "egv_patch_gather_u8")
         return pl
-    check(_lib.lib().egv_patch_gather(_p(video5d), B * T, Cc, H, W, P, _p(pl.hi), _p(pl.lo), pl.ld, _stream()),
+    check(_lib.lib().egv_patch_gather(_p(video5d), B * T, Cc, H, W, P, _p(pl.hi), _p(pl.lo), pl.ld, _stream(video5d)),
           "egv_patch_gather")
     return pl
 
 
 def assemble_tokens(pe, cls, pos, temporal, B, T, n, D):
     x = torch.empty((B, 1 + T * n, D), dtype=torch.float32, device=pe.device)
-    check(_lib.lib().egv_assemble_tokens(_p(pe), _p(cls), _p(pos), _p(temporal), B, T, n, D, _p(x), _stream()),
+    check(_lib.lib().egv_assemble_tokens(_p(pe), _p(cls), _p(pos), _p(temporal), B, T, n, D, _p(x), _stream(pe)),
           "egv_assemble_tokens")
     return x
 
@@ -510,7 +612,7 @@ def assemble_tokens_bwd(dx, B, T, n, D, T_model):
     d_pos = torch.empty((1, n + 1, D), dtype=torch.float32, device=dev)
     d_tmp = zeros((1, T_model, D), device=dev)
     check(_lib.lib().egv_assemble_tokens_bwd(_p(dx), B, T, n, D, T_model, _p(d_pe), _p(d_cls), _p(d_pos), _p(d_tmp),
-                                             _stream()), "egv_assemble_tokens_bwd")
+                                             _stream(dx)), "egv_assemble_tokens_bwd")
     return d_pe, d_cls, d_pos, d_tmp
 
 
@@ -523,7 +625,7 @@ def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes):
     lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     work = torch.empty(_lib.lib().egv_divided_attn_fwd_work_floats(B, T, n, H, mode), dtype=torch.float32, device=dev)
     check(_lib.lib().egv_divided_attn_fwd(_p(qkv.hi), _p(qkv.lo), B, T, n, H, mode, passes, _p(out.hi), _p(out.lo),
-                                          _p(lse), _p(work), _stream()), "egv_divided_attn_fwd")
+                                          _p(lse), _p(work), _stream(qkv.hi)), "egv_divided_attn_fwd")
     return out, lse
 
 
@@ -535,7 +637,7 @@ def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, m
     work = torch.empty(_lib.lib().egv_divided_attn_bwd_work_floats(B, T, n, H), dtype=torch.float32, device=dev)
     check(_lib.lib().egv_divided_attn_bwd(_p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(d_out.hi), _p(d_out.lo),
                                           _p(lse), B, T, n, H, mode, passes, _p(dqkv.hi), _p(dqkv.lo), _p(work),
-                                          _stream()), "egv_divided_attn_bwd")
+                                          _stream(qkv.hi)), "egv_divided_attn_bwd")
     return dqkv
 
 
@@ -546,7 +648,7 @@ def text_attn_fwd(q, k, v, mask, B, L, H, passes, dropout_p=0.0, seed=0):
     lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
     check(_lib.lib().egv_text_attn_fwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), B, L, H, passes, float(dropout_p),
-                                       int(seed), _p(out.hi), _p(out.lo), _p(lse), _stream()), "egv_text_attn_fwd")
+                                       int(seed), _p(out.hi), _p(out.lo), _p(lse), _stream(q)), "egv_text_attn_fwd")
     return out, lse
 
 
@@ -562,7 +664,7 @@ def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False, d
     work = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     check(_lib.lib().egv_text_attn_bwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), _p(d_out), _p(lse), B, L, H, passes,
                                        float(dropout_p), int(seed), _p(dq), _p(dk), _p(dv), dq.stride(0), _p(work),
-                                       _stream()), "egv_text_attn_bwd")
+                                       _stream(q)), "egv_text_attn_bwd")
     return (dq, dk, dv, dqkv) if fused_out else (dq, dk, dv)
 
 
@@ -571,14 +673,14 @@ def dropout(x, p, seed, add=None):
     _need_cuda(x, add)
     x = x.contiguous()
     out = torch.empty_like(x)
-    check(_lib.lib().egv_dropout(_p(x), _p(add), _p(out), x.numel(), float(p), int(seed), _stream()), "egv_dropout")
+    check(_lib.lib().egv_dropout(_p(x), _p(add), _p(out), x.numel(), float(p), int(seed), _stream(x)), "egv_dropout")
     return out
 
 
 def embed_fwd(ids, word, pos, D):
     B, L = ids.shape
     e = torch.empty((B * L, D), dtype=torch.float32, device=word.device)
-    check(_lib.lib().egv_embed_fwd(_p(ids), _p(word), _p(pos), B, L, D, _p(e), _stream()), "egv_embed_fwd")
+    check(_lib.lib().egv_embed_fwd(_p(ids), _p(word), _p(pos), B, L, D, _p(e), _stream(word)), "egv_embed_fwd")
     return e
 
 
@@ -587,7 +689,7 @@ def embed_bwd(ids, d_e, word_shape, pos_shape, pad_id=-1):
     D = word_shape[1]
     d_word = zeros(tuple(word_shape), device=d_e.device)
     d_pos = zeros(tuple(pos_shape), device=d_e.device)
-    check(_lib.lib().egv_embed_bwd(_p(ids), _p(d_e), B, L, D, int(pad_id), _p(d_word), _p(d_pos), _stream()),
+    check(_lib.lib().egv_embed_bwd(_p(ids), _p(d_e), B, L, D, int(pad_id), _p(d_word), _p(d_pos), _stream(d_e)),
           "egv_embed_bwd")
     return d_word, d_pos
 
@@ -608,7 +710,7 @@ def egonce_fwd_bwd(text, video, noun, verb, temperature, eps=1e-8, use_noun=True
     dvv = torch.empty_like(video) if want_grads else None
     check(_lib.lib().egv_egonce_fwd_bwd(_p(text), _p(video), _p(noun), _p(verb), n, D, dn, dv, float(temperature),
                                         float(eps), int(use_noun), int(use_verb), _p(loss), _p(sim), _p(dt), _p(dvv),
-                                        _p(work), _stream()), "egv_egonce_fwd_bwd")
+                                        _p(work), _stream(text)), "egv_egonce_fwd_bwd")
     return loss, sim, dt, dvv
 
 
@@ -622,4 +724,16 @@ def adamw_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step
     N = (C.c_int64 * n)(*[p.numel() for p in params])
     check(_lib.lib().egv_adamw_multi(n, P, G, M_, V, None, None, N, float(lr), float(beta1), float(beta2),
                                      float(eps), float(weight_decay), int(step), int(correct_bias),
-                                     float(grad_scale), _stream()), "egv_adamw_multi")
+                                     float(grad_scale), _stream(params[0])), "egv_adamw_multi")
+
+
+# ---- module-level views of DEFAULT's settings (earlier rounds' names; scripts, tools and tests assign to them) -----------------
+class _OpsModule(type(sys.modules[__name__])):
+    WGRAD_SIDE_STREAM = property(lambda m: DEFAULT.wgrad_side_stream, lambda m, v: DEFAULT.set(wgrad_side_stream=bool(v)))
+    TEXT_SIDE_STREAM = property(lambda m: DEFAULT.text_side_stream, lambda m, v: DEFAULT.set(text_side_stream=bool(v)))
+    BACKWARD_POLL = property(lambda m: DEFAULT.backward_poll, lambda m, v: DEFAULT.set(backward_poll=v))
+    KERNEL_TIMER = property(lambda m: DEFAULT.kernel_timer, lambda m, v: DEFAULT.set(kernel_timer=v))
+    GEMM_GRID = property(lambda m: DEFAULT.gemm_grid)
+
+
+sys.modules[__name__].__class__ = _OpsModule

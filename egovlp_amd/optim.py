@@ -33,12 +33,13 @@ class AdamW(torch.optim.Optimizer):
         self._ov = None     # state of overlap_backward()
 
     # ------------------------------------------------------------------------------------------ overlap with backward
-    def overlap_backward(self, min_elems=16 << 20, stream_of=None):
+    def overlap_backward(self, min_elems=16 << 20, stream_of=None, exec_ctx=None):
         """Arm-able overlap of the update with the backward pass (see the module docstring).  Returns self.
         `stream_of(param)`: the stream the parameter's gradient is produced on (FrozenInTime.gradient_stream_of) -- the hook is
         registered under it so that autograd does not serialise the two towers' streams (see Bf16GradSync)."""
         if self._ov is not None:
             return self
+        self._exec_ctx = exec_ctx        # the model's ExecContext: its streams are what the early updates are ordered behind
         group_of = {}
         for group in self.param_groups:
             for p in group["params"]:
@@ -88,7 +89,7 @@ class AdamW(torch.optim.Optimizer):
         side = ov["stream"]
         # the gradients of `ps` are final on the streams that produced them: this node's stream, the text tower's stream and
         # (opt-in) the wgrad side stream -- order the current stream behind those, then the update stream behind it
-        ops.join_streams_for_gradient_hook()
+        (self._exec_ctx or ops.DEFAULT).join_streams_for_gradient_hook()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self._update(ps, 1.0)

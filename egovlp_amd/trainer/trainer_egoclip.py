@@ -104,6 +104,9 @@ def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_he
         else:
             loss = loss_fn(output)
     loss.backward()                                                         # :139
+    ec = getattr(getattr(model, 'module', model), 'exec_ctx', None)
+    if ec is not None:
+        ec.join_side_stream()       # idempotent; covers a backward whose end-of-pass callback did not run
     if grad_sync is not None:
         grad_sync.finish()
     optimizer.step()                                                        # :141

@@ -66,12 +66,13 @@ typedef struct egv_gemm_desc {
                        M >= 256, N >= 256, both multiples of 8; K is arbitrary (rows past K are zero-filled).        */
   float* colsum;    /* trans == 1 only, optional: colsum[m] = sum_k A[k,m] (the bias gradient), from the same pass;
                        with ksplit > 1, partial must hold ksplit*M*N + ksplit*M floats.                              */
+  int32_t grid_cap; /* persistent workgroups of the big-tile kernel for THIS launch: 0 = one per CU (256); data-parallel
+                       callers pass e.g. 248 so that the RCCL kernels of the overlapped gradient all-reduce find free CUs.
+                       Multiples of 8 in [8, 256]; anything else is an invalid argument.  (Per call, not per process: the
+                       library keeps no state between calls.)                                                         */
+  int32_t reserved_;
 } egv_gemm_desc;
 int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
-/* Persistent-workgroup count of the big-tile GEMM kernel (default 256 = one per CU).  Data-parallel runs lower it (e.g. 248)
- * so that the RCCL kernels of the overlapped gradient all-reduce find free CUs.  Multiples of 8 in [8, 256] are accepted;
- * returns the previous value (process-wide, read at every launch).                                                    */
-int egv_gemm_set_grid(int32_t workgroups);
 /* ---- format kernels (HBM-bound) -----------------------------------------------------------------
  * fp32 [rows, cols] -> split planes, optionally also the TRANSPOSED planes t_*[cols, ldt] (ldt >= rows,
  * columns rows..ldt-1 are zero-filled so a following GEMM can contract over a K padded to 32) and the

@@ -1,0 +1,52 @@
+"""TEST INFRASTRUCTURE: a do-nothing stand-in for libegovlp_hip.so, so that the HOST side of the package (autograd
+functions, execution contexts, stream / bucket bookkeeping, the training step, the trainer) can be driven end to end on CPU
+tensors in this GPU-less container.  Every entry point of include/egovlp_hip.h is replaced by a ctypes callback with the
+REAL prototype (egovlp_amd/_lib.PROTOTYPES), so argument counts and ctypes conversions are checked exactly as a real call
+would check them; nothing is computed -- outputs are whatever torch.empty left there.  What such a dry run pins: arity and
+types of every C-ABI call the step makes, shapes of every gradient the autograd functions return (autograd validates them
+against the parameters), the order in which gradients become final (bucket launch order of the data-parallel exchange), and
+the launch census of a step.  It says nothing about numerics: those are the -m gpu tests.
+
+Never imported by the product (`egovlp_amd/`), by bench.py or by __graft_entry__.py.
+"""
+import contextlib
+import ctypes as C
+
+
+def _make_mock(calls):
+    from egovlp_amd import _lib
+
+    class Mock:
+        pass
+
+    m = Mock()
+    m._keep = []
+    special = {"egv_version": 3, "egv_layernorm_bwd_parts": 8, "egv_divided_attn_fwd_work_floats": 4096,
+               "egv_divided_attn_bwd_work_floats": 4096, "egv_egonce_work_floats": 1 << 16}
+    for name, (res, args) in _lib.PROTOTYPES.items():
+        ret = special.get(name, 0)
+
+        def cb(*a, _name=name, _ret=ret):
+            calls.append(_name)
+            return _ret
+
+        proto = C.CFUNCTYPE(res, *args)
+        fn = proto(cb)
+        m._keep.append(fn)
+        setattr(m, name, fn)
+    return m
+
+
+@contextlib.contextmanager
+def mock_hip():
+    """with mock_hip() as calls: ...  -- `calls` is the list of C-ABI entry points invoked, in order."""
+    from egovlp_amd import _lib, ops
+    calls = []
+    saved = (_lib._lib, ops._stream, ops._need_cuda)
+    _lib._lib = _make_mock(calls)
+    ops._stream = lambda t=None: None
+    ops._need_cuda = lambda *ts: None
+    try:
+        yield calls
+    finally:
+        _lib._lib, ops._stream, ops._need_cuda = saved

@@ -136,7 +136,8 @@ def test_eval_token_padding_for_graph_replay():
 
 def test_gradient_ready_order_covers_every_parameter_once():
     """FrozenInTime.gradient_ready_order() (the bucket order of the hook-free gradient exchange): a permutation of the trainable
-    parameters -- projections, then the video tower from its last block to its first, then the text tower -- and
+    parameters -- the tower forward() builds last comes first (default: the text tower, then the video tower from its last block
+    to its first; tests/test_host_dryrun_cpu.py checks the order against what autograd really does) -- and
     gradient_stream_of() names no stream for host-resident parameters."""
     from egovlp_amd.model.model import FrozenInTime
     m = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
@@ -146,9 +147,10 @@ def test_gradient_ready_order_covers_every_parameter_once():
     assert len(order) == len(params) and {id(p) for p in order} == {id(p) for p in params}
     names = {id(p): k for k, p in m.named_parameters()}
     seq = [names[id(p)] for p in order]
-    first_text = min(i for i, k in enumerate(seq) if k.startswith("text_model."))
-    last_video = max(i for i, k in enumerate(seq) if k.startswith("video_model."))
-    assert last_video < first_text                                   # the whole video tower is final before the text tower
+    last_text = max(i for i, k in enumerate(seq) if k.startswith("text_model.") or k.startswith("txt_proj."))
+    first_video = min(i for i, k in enumerate(seq) if k.startswith("video_model.") or k.startswith("vid_proj."))
+    assert FrozenInTime.TEXT_TOWER_LAST and last_text < first_video  # the whole text tower is final before the video tower
+    assert seq[0].startswith("txt_proj.") and seq[first_video].startswith("vid_proj.")
     b11 = min(i for i, k in enumerate(seq) if k.startswith("video_model.blocks.11."))
     b0 = min(i for i, k in enumerate(seq) if k.startswith("video_model.blocks.0."))
     assert b11 < b0                                                  # last block first

