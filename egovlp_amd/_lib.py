@@ -80,6 +80,7 @@ PROTOTYPES = {
     "egv_version": (i32, []),
     "egv_split_f32_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_diag_mfma_peak": (i32, [i32, i32, c_p, c_p]),
+    "egv_diag_traffic_calib": (i32, [i32, c_p, c_p, i64, c_p]),
 }
 
 _lib = None

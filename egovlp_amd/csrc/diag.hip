@@ -107,7 +107,65 @@ __global__ __launch_bounds__(512, 2) void mfma_loop_kernel(int iters, float* out
   if (s[0] + s[1] + s[2] + s[3] == -1.0f) out[threadIdx.x] = s[0];
 }
 
+// Calibration of the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on the GEMM's own access paths (tools/traffic_calib.py):
+// a copy over a KNOWN byte count.  Loads: LDS-DMA `global_load_lds` dwordx4 (the operand path of gemm_big: 1 KiB per wave
+// instruction, 16 B per lane) or plain 16-byte global loads; stores: 16 B per lane, write-back or non-temporal (the two
+// flavours the epilogues use, common.h egv_store).  mode bits: 1 = LDS-DMA loads, 2 = nt stores, 4 = no stores (read only),
+// 8 = no loads (write only: fills dst).  Every byte of src is read once and every byte of dst written once per launch.
+template <int MODE>
+__global__ __launch_bounds__(256) void traffic_calib_kernel(const char* __restrict__ src, char* __restrict__ dst, long pieces) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* my = lds + wave * 1024;
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  u4 keep = (u4){0u, 0u, 0u, 0u};
+  const long stride = (long)gridDim.x * 4;
+  for (long p = (long)blockIdx.x * 4 + wave; p < pieces; p += stride) {
+    u4 v = (u4){(unsigned)p, 1u, 2u, 3u};
+    if constexpr ((MODE & 8) == 0) {
+      if constexpr (MODE & 1) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)my, 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        v = *(const u4*)(my + lane * 16);
+      } else {
+        v = *(const u4*)(src + p * 1024 + lane * 16);
+      }
+    }
+    if constexpr (MODE & 4) {
+      keep ^= v;
+    } else if constexpr (MODE & 2) {
+      __builtin_nontemporal_store(v, (u4*)(dst + p * 1024 + lane * 16));
+    } else {
+      *(u4*)(dst + p * 1024 + lane * 16) = v;
+    }
+  }
+  if constexpr (MODE & 4) {
+    if ((keep[0] ^ keep[1] ^ keep[2] ^ keep[3]) == 0x9E3779B9u) *(u4*)(dst + lane * 16) = keep;   // practically never: keeps the loads
+  }
+}
+
 }  // namespace
+
+extern "C" int egv_diag_traffic_calib(int32_t mode, const void* src, void* dst, int64_t bytes, void* stream) {
+  if (!src || !dst || bytes < 1024 || bytes % 1024) return EGV_ERR_ARG;
+  const long pieces = bytes / 1024;
+  const dim3 grid(2048), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+    case 0: EGV_LAUNCH(traffic_calib_kernel<0>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    case 1: EGV_LAUNCH(traffic_calib_kernel<1>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    case 2: EGV_LAUNCH(traffic_calib_kernel<2>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    case 3: EGV_LAUNCH(traffic_calib_kernel<3>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    case 4: EGV_LAUNCH(traffic_calib_kernel<4>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    case 5: EGV_LAUNCH(traffic_calib_kernel<5>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    case 8: EGV_LAUNCH(traffic_calib_kernel<8>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    case 10: EGV_LAUNCH(traffic_calib_kernel<10>, grid, block, 0, s, (const char*)src, (char*)dst, pieces); break;
+    default: return EGV_ERR_ARG;
+  }
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
 
 extern "C" int egv_diag_mfma_peak(int32_t iters, int32_t waves, float* out, void* stream) {
   if (iters == 0 || waves < 1 || waves > 8 + 200 || !out) return EGV_ERR_ARG;   // iters < 0: random operands (plain kernel)

@@ -252,6 +252,11 @@ int egv_version(void);
 /* diagnostics, not on the product path: `iters` rounds of 40 independent MFMA 16x16x32 bf16 per wave, `waves` (1..8) waves
  * per workgroup, one workgroup per CU, no memory traffic -- the chip's sustained MFMA rate (tools/mfma_peak.py). */
 int egv_diag_mfma_peak(int32_t iters, int32_t waves, float* out, void* stream);
+/* diagnostics, not on the product path: a copy of `bytes` (multiple of 1024) from src to dst on the GEMM's own memory paths,
+ * to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE counters on a known byte count (tools/traffic_calib.py).
+ * mode bits: 1 = loads by LDS-DMA (global_load_lds dwordx4, the operand path of the big GEMM; else plain 16-byte loads),
+ * 2 = non-temporal stores (else write-back), 4 = read only, 8 = write only.  Valid: 0, 1, 2, 3, 4, 5, 8, 10. */
+int egv_diag_traffic_calib(int32_t mode, const void* src, void* dst, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }
