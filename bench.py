@@ -142,6 +142,10 @@ def trajectory_drift(model, loss_fn, make_opt, steps=20, B=8, T=4, L=32, modes=(
 
     batches = [dev(synth_batch(B, T=T, L=L, seed=seed + i)) for i in range(steps)]
     held_out = dev(synth_batch(B, T=T, L=L, seed=seed + 10007))
+    ec.set_precision("bf16x3")
+    with torch.no_grad():
+        te, ve = model(held_out)
+        held_out_initial = float(loss_fn.fused(te, ve, held_out["noun_vec"], held_out["verb_vec"]))
     runs = {}
     for mode in modes:
         model.load_state_dict(sd0)
@@ -155,7 +159,8 @@ def trajectory_drift(model, loss_fn, make_opt, steps=20, B=8, T=4, L=32, modes=(
         runs[mode] = {"loss": [float(x) for x in torch.stack(losses).cpu()], "held_out": float(final),
                       "theta": {k: v.detach().clone() for k, v in model.named_parameters()}}
         del opt
-    ref, out = runs[modes[0]], {"steps": steps, "batch": B, "reference_mode": modes[0]}
+    ref, out = runs[modes[0]], {"steps": steps, "batch": B, "reference_mode": modes[0],
+                                "held_out_loss_initial": round(held_out_initial, 5)}
     names = list(ref["theta"].keys())
 
     def dist2(a, b, keys):

@@ -229,12 +229,23 @@ __global__ __launch_bounds__(256) void assemble_bwd_pos_kernel(const float* __re
   const int p = blockIdx.x;
   const long S = 1 + (long)T * n;
   const int rows = (p == 0) ? B : B * T;
+  auto tok_of = [&](int r) -> long { return (p == 0) ? (long)r * S : (long)(r / T) * S + 1 + (long)(r % T) * n + (p - 1); };
   for (int d4 = threadIdx.x; d4 < D / 4; d4 += blockDim.x) {
-    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
-      const long tok = (p == 0) ? (long)r * S : (long)(r / T) * S + 1 + (long)(r % T) * n + (p - 1);
-      s += *(const f32x4_t*)(dx + tok * D + d4 * 4);
+    // four independent row streams per thread (the loads of a 3-KiB row are 600 KB apart: latency-bound unless several are in
+    // flight), and only gridDim.y = 4 slices per position: the 2.4 M fp32 atomics of the 16-slice version were what the 193 us of
+    // this kernel went into (profiles/r02_zz_kernel_stats_timed_mixed.csv)
+    f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int r = blockIdx.y;
+    const int st = gridDim.y;
+    for (; r + 3 * st < rows; r += 4 * st) {
+      const f32x4_t a = *(const f32x4_t*)(dx + tok_of(r) * D + d4 * 4);
+      const f32x4_t b = *(const f32x4_t*)(dx + tok_of(r + st) * D + d4 * 4);
+      const f32x4_t c = *(const f32x4_t*)(dx + tok_of(r + 2 * st) * D + d4 * 4);
+      const f32x4_t d = *(const f32x4_t*)(dx + tok_of(r + 3 * st) * D + d4 * 4);
+      s0 += a; s1 += b; s2 += c; s3 += d;
     }
+    for (; r < rows; r += st) s0 += *(const f32x4_t*)(dx + tok_of(r) * D + d4 * 4);
+    const f32x4_t s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       atomicAdd(d_pos + (long)p * D + d4 * 4 + e, s[e]);
@@ -439,7 +450,7 @@ extern "C" int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, in
   if (d_pos && d_cls) {
     if (hipMemsetAsync(d_pos, 0, sizeof(float) * (size_t)(n + 1) * D, s) != hipSuccess) return EGV_ERR_LAUNCH;
     if (hipMemsetAsync(d_cls, 0, sizeof(float) * (size_t)D, s) != hipSuccess) return EGV_ERR_LAUNCH;
-    EGV_LAUNCH(assemble_bwd_pos_kernel, dim3(n + 1, 16), dim3(256), 0, s, dx, B, T, n, D, d_pos, d_cls);
+    EGV_LAUNCH(assemble_bwd_pos_kernel, dim3(n + 1, 4), dim3(256), 0, s, dx, B, T, n, D, d_pos, d_cls);
     EGV_CHECK_LAUNCH();
   }
   if (d_temporal) {

@@ -73,25 +73,31 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
 
 // backward: each wave walks rows wave_id, wave_id + nwaves, ...; per-lane partial dgamma/dbeta stay in
 // registers; one LDS reduction per block at the end -> work[block][2][cols]; a second kernel sums blocks.
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+// HBM-bound (dy + x [+ add1 + add2] in, dx + planes out: 270 .. 424 MB per launch at M = 25 120, D = 768), so what matters is
+// bytes in flight: EVERY input stream of a row (the residual-gradient addends too, which the first version fetched only after
+// the two wave reductions) is requested at the top of the row, the kernel is instantiated per row width (NV float4 per
+// lane: 3 for D = 768, so no register is spent on a fourth that is never used) and stays under 128 VGPRs, and the grid is four
+// waves per SIMD (1024 blocks): 16 waves x 12 KiB requested per CU where the old shape had 8 x 6 KiB.
+template <int NV>
+__global__ __launch_bounds__(256, NV <= 3 ? 4 : 2) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const bf16_t* __restrict__ dyh, const bf16_t* __restrict__ dyl, long lddy,
     const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int cols, const float* __restrict__ add1,
     const float* __restrict__ add2, float* __restrict__ dx, long lddx, bf16_t* __restrict__ dxh,
     bf16_t* __restrict__ dxl, float* __restrict__ work, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[2][4][MAXV * 256];
+  __shared__ float red[2][4][NV * 256];   // [dgamma/dbeta][wave][col]
   if (blockIdx.x == 0) {   // the reduce kernel (next launch on the stream) accumulates into these with atomics
     for (int c = threadIdx.x; c < cols; c += 256) {
       if (dgamma) dgamma[c] = 0.f;
       if (dbeta) dbeta[c] = 0.f;
     }
-  }  // [dgamma/dbeta][wave][col]  32 KiB
+  }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nv = cols / 4;
-  f32x4_t dg[MAXV], db[MAXV], g[MAXV];
+  f32x4_t dg[NV], db[NV], g[NV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     dg[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     db[i] = dg[i];
     g[i] = dg[i];
@@ -99,36 +105,47 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     if (c4 < nv) g[i] = *(const f32x4_t*)(gamma + c4 * 4);
   }
   const float inv_cols = 1.0f / (float)cols;
+  const bool full = (nv == NV * 64);      // D = 768 with NV = 3, D = 1024 with NV = 4: no lane is ever out of range
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    f32x4_t gy[MAXV], xh[MAXV];
-    float s1 = 0.f, s2 = 0.f;
+    f32x4_t gy[NV], xh[NV], ad[NV];
+    // ---- every load of the row, back to back
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c4 = lane + i * 64;
       gy[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       xh[i] = gy[i];
-      if (c4 < nv) {
-        f32x4_t d;
+      ad[i] = gy[i];
+      if (full || c4 < nv) {
         if (dyh) {   // dy as split-bf16 planes (written by the dgrad GEMM epilogue): half the bytes of fp32
           const u32x2_t a = *(const u32x2_t*)(dyh + (long)row * lddy + c4 * 4);
-          d = (f32x4_t){__uint_as_float(a[0] << 16), __uint_as_float(a[0] & 0xffff0000u), __uint_as_float(a[1] << 16),
-                        __uint_as_float(a[1] & 0xffff0000u)};
+          gy[i] = (f32x4_t){__uint_as_float(a[0] << 16), __uint_as_float(a[0] & 0xffff0000u), __uint_as_float(a[1] << 16),
+                            __uint_as_float(a[1] & 0xffff0000u)};
           if (dyl) {
             const u32x2_t b = *(const u32x2_t*)(dyl + (long)row * lddy + c4 * 4);
-            d += (f32x4_t){__uint_as_float(b[0] << 16), __uint_as_float(b[0] & 0xffff0000u), __uint_as_float(b[1] << 16),
-                           __uint_as_float(b[1] & 0xffff0000u)};
+            gy[i] += (f32x4_t){__uint_as_float(b[0] << 16), __uint_as_float(b[0] & 0xffff0000u), __uint_as_float(b[1] << 16),
+                               __uint_as_float(b[1] & 0xffff0000u)};
           }
         } else {
-          d = *(const f32x4_t*)(dy + (long)row * lddy + c4 * 4);
+          gy[i] = *(const f32x4_t*)(dy + (long)row * lddy + c4 * 4);
         }
-        const f32x4_t xv = *(const f32x4_t*)(x + (long)row * ldx + c4 * 4);
+        xh[i] = *(const f32x4_t*)(x + (long)row * ldx + c4 * 4);
+        if (add1) ad[i] = *(const f32x4_t*)(add1 + (long)row * lddx + c4 * 4);
+        if (add2) ad[i] += *(const f32x4_t*)(add2 + (long)row * lddx + c4 * 4);
+      }
+    }
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c4 = lane + i * 64;
+      if (full || c4 < nv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          xh[i][e] = (xv[e] - mu) * rs;
-          gy[i][e] = d[e] * g[i][e];
-          dg[i][e] += d[e] * xh[i][e];
-          db[i][e] += d[e];
+          const float d = gy[i][e];
+          xh[i][e] = (xh[i][e] - mu) * rs;
+          gy[i][e] = d * g[i][e];
+          dg[i][e] += d * xh[i][e];
+          db[i][e] += d;
           s1 += gy[i][e];
           s2 += gy[i][e] * xh[i][e];
         }
@@ -137,27 +154,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float c1 = wave_sum(s1) * inv_cols;
     const float c2 = wave_sum(s2) * inv_cols;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c4 = lane + i * 64;
-      if (c4 < nv) {
+      if (full || c4 < nv) {
         f32x4_t o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2);
-        if (add1) o += *(const f32x4_t*)(add1 + (long)row * lddx + c4 * 4);
-        if (add2) o += *(const f32x4_t*)(add2 + (long)row * lddx + c4 * 4);
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2) + ad[i][e];
         egv_store<EGV_NT_LN>(dx + (long)row * lddx + c4 * 4, o);
         if (dxh) {   // the same gradient as the next GEMM's operand (row-major split-bf16 planes, ld = cols)
-          bf16_t h[4], l[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) split_bf16(o[e], h[e], l[e]);
-          egv_store<EGV_NT_LN>(dxh + (long)row * cols + c4 * 4, (u32x2_t){pack2(h[0], h[1]), pack2(h[2], h[3])});
-          if (dxl) egv_store<EGV_NT_LN>(dxl + (long)row * cols + c4 * 4, (u32x2_t){pack2(l[0], l[1]), pack2(l[2], l[3])});
+          uint32_t h0, h1, l0, l1;
+          split_bf16x2(o[0], o[1], h0, l0);
+          split_bf16x2(o[2], o[3], h1, l1);
+          egv_store<EGV_NT_LN>(dxh + (long)row * cols + c4 * 4, (u32x2_t){h0, h1});
+          if (dxl) egv_store<EGV_NT_LN>(dxl + (long)row * cols + c4 * 4, (u32x2_t){l0, l1});
         }
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c4 = lane + i * 64;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -217,7 +232,7 @@ extern "C" int egv_layernorm_fwd(const float* x, const float* x_add, int64_t ldx
 
 extern "C" int egv_layernorm_bwd_parts(int32_t rows) {
   const int b = (rows + 3) / 4;
-  return b < 512 ? b : 512;
+  return b < 1024 ? b : 1024;       // 1024 blocks of 4 waves = 16 waves per CU (four per SIMD)
 }
 
 extern "C" int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
@@ -229,8 +244,15 @@ extern "C" int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const e
   if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
   const int parts = egv_layernorm_bwd_parts(rows);
   hipStream_t s = (hipStream_t)stream;
-  EGV_LAUNCH(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, s, dy, dy_hi, dy_lo, lddy, x, ldx, gamma, mean, rstd, rows,
-             cols, add1, add2, dx, lddx, dx_hi, dx_lo, work, dgamma, dbeta);
+  const int nv64 = (cols / 4 + 63) / 64;      // float4 per lane
+#define EGV_LN_BWD(NV)                                                                                                      \
+  EGV_LAUNCH(layernorm_bwd_kernel<NV>, dim3(parts), dim3(256), 0, s, dy, dy_hi, dy_lo, lddy, x, ldx, gamma, mean, rstd, rows, \
+             cols, add1, add2, dx, lddx, dx_hi, dx_lo, work, dgamma, dbeta)
+  if (nv64 <= 1) EGV_LN_BWD(1);
+  else if (nv64 == 2) EGV_LN_BWD(2);
+  else if (nv64 == 3) EGV_LN_BWD(3);
+  else EGV_LN_BWD(4);
+#undef EGV_LN_BWD
   EGV_CHECK_LAUNCH();
   EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 63) / 64, (parts + 63) / 64), dim3(256), 0, s, work, parts,
              cols, dgamma, dbeta);

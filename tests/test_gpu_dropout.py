@@ -65,7 +65,7 @@ def test_transformer_block_backward_uses_the_masks_of_the_forward():
     """Directional finite differences through a whole DistilBERT block with attention and FFN dropout on (fixed seeds)."""
     from egovlp_amd.model.text_transformer import DistilBertConfig, TransformerBlock
     from egovlp_amd.ops import Precision
-    from egovlp_amd.weights import WeightCache
+    from egovlp_amd.ops import new_context as WeightCache   # a fresh execution context (private weight-plane cache) per evaluation
     Precision.set("bf16x3")
     torch.manual_seed(3)
     cfg = DistilBertConfig()

@@ -52,13 +52,15 @@ def test_mixed_mode_tracks_the_fp32_grade_backward_over_20_steps(built):
         r["param_drift_mixed"]))
     for k, v in r["param_drift_per_tensor_mixed"].items():
         print("    drift %-60s %.4f" % (k, v))
-    # training really moves: the loss at the end is well below the loss at the start (same batch distribution)
-    assert sum(r["loss_bf16x3"][-3:]) < sum(r["loss_bf16x3"][:3])
+    # (synthetic pairs carry nothing to generalise from: the held-out loss does not have to drop -- 3.326 at the initial weights,
+    # 3.370 / 3.368 after 20 steps on MI355X -- what is asserted is that both modes end at the SAME place)
+    print("  held-out loss at the initial weights %.5f" % r["held_out_loss_initial"])
     # the two loss curves agree step by step, and so do the end points on a batch neither has seen
+    # (measured on MI355X, two boxes: 3.0e-3 .. 5.1e-3 / 0.7e-3 .. 1.4e-3 / 0.059 .. 0.063)
     assert r["max_rel_loss_gap_mixed"] < 2e-2, r["max_rel_loss_gap_mixed"]
-    assert r["held_out_rel_gap_mixed"] < 2e-2, r["held_out_rel_gap_mixed"]
+    assert r["held_out_rel_gap_mixed"] < 1e-2, r["held_out_rel_gap_mixed"]
     # the end points are close in units of the distance travelled (AdamW's early updates are sign-like, see the note)
-    assert r["param_drift_mixed"] < 0.35, r["param_drift_mixed"]
+    assert r["param_drift_mixed"] < 0.2, r["param_drift_mixed"]
 
 
 ORACLE_STEPS, ORACLE_B = 4, 4
