@@ -256,6 +256,9 @@ def main():
                     help="1 (default): weight-gradient GEMMs on their own HIP stream (egovlp_amd.ops.side_stream); 0: on the main stream")
     ap.add_argument("--text-side", type=int, default=int(os.environ.get("EGV_TEXT_SIDE", "1")),
                     help="1 (default): the DistilBERT tower on a second HIP stream under the video tower; 0: one stream")
+    ap.add_argument("--main-priority", type=int, default=int(os.environ.get("EGV_MAIN_PRIO", "0")),
+                    help="1: run the step on a HIGH-priority HIP stream (the wgrad / text side streams keep the default priority: "
+                         "their workgroups fill the CUs the main stream's kernels leave free instead of competing with them)")
     ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("EGV_ADAMW_OVERLAP", "0")),
                     help="1: AdamW updates enqueued from grad-ready hooks on a side stream under the rest of backward "
                          "(single GPU only; bit-identical results)")
@@ -370,6 +373,10 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax), float(loss)
 
+    if args.main_priority:
+        hp = torch.cuda.Stream(priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)          # everything below (timed steps, instrumented passes) runs on the high-priority stream
     dt, loss_val = measure(args.steps, args.warmup)
     ms = dt / args.steps * 1e3
     pairs = world * B * args.steps / dt
@@ -439,7 +446,8 @@ def main():
                    "parallelism": f"dp{world}", "precision": "/".join(ec.precision_name()),
                    "text_dropout": args.text_dropout,
                    "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
-                               "adamw_overlapped_with_backward": bool(args.adamw_overlap and grad_sync is None and not args.ddp)}},
+                               "adamw_overlapped_with_backward": bool(args.adamw_overlap and grad_sync is None and not args.ddp),
+                               "main_stream_high_priority": bool(args.main_priority)}},
         "loss": round(loss_val, 5),
         "host_enqueue_ms_per_step": round(HOST.get("enqueue_ms_per_step", 0.0), 3),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "egv_egonce_from_sim": (i32, [c_p, c_p, c_p, i32, f32, i32, i32, c_p, c_p, c_p, c_p]),
     "egv_maxmargin_fwd_bwd": (i32, [c_p, c_p, i32, f32, i32, c_p, c_p, c_p]),
     "egv_dual_softmax": (i32, [c_p, i32, i32, f32, c_p, c_p, c_p]),
+    "egv_cross_entropy_fwd_bwd": (i32, [c_p, i64, c_p, i32, i32, i64, c_p, c_p, i64, c_p]),
     "egv_adamw_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, f32, f32, f32, f32, f32, i32, i32, f32, c_p]),
     "egv_grad_pack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, f32, c_p]),
     "egv_grad_unpack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, c_p]),

@@ -501,3 +501,57 @@ extern "C" int egv_maxmargin_fwd_bwd(const float* x, const float* weight, int32_
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
+
+
+// ---- softmax cross-entropy of the classification fine-tunes (OSCC / PNR: model/loss.py:135-141 = nn.CrossEntropyLoss with its
+// defaults, mean over the targets != ignore_index; trainer/trainer_oscc.py:335-338 feeds it the [B, 2] / [B, 17] scores of
+// FrozenInTime(video_only=True) and int64 labels).  One workgroup: a wave per row (log-sum-exp by wave shuffles), the row losses
+// are summed in a fixed order through LDS, so the result is deterministic; d_logits = (softmax - onehot) / #valid.
+namespace {
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, long ld, const long long* __restrict__ target,
+                                                            int rows, int cols, long long ignore_index, float* __restrict__ loss,
+                                                            float* __restrict__ dlogits, long ldd) {
+  __shared__ float part[4];
+  __shared__ int cnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // pass 1: number of valid rows (the gradient scale), then pass 2: losses and gradients
+  int nvalid = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) nvalid += (target[r] != ignore_index);
+  nvalid = (int)wave_sum((float)nvalid);
+  if (lane == 0) cnt[wave] = nvalid;
+  __syncthreads();
+  const int valid = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  const float inv = valid > 0 ? 1.0f / (float)valid : 0.f;
+  float acc = 0.f;
+  for (int r = wave; r < rows; r += 4) {
+    const float* x = logits + (long)r * ld;
+    const long long t = target[r];
+    const bool on = t != ignore_index && t >= 0 && t < cols;
+    float m = -3.0e38f;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float se = 0.f;
+    for (int c = lane; c < cols; c += 64) se += __expf(x[c] - m);
+    se = wave_sum(se);
+    const float lse = m + __logf(se);
+    if (on) acc += lse - x[t];
+    if (dlogits) {
+      float* d = dlogits + (long)r * ldd;
+      for (int c = lane; c < cols; c += 64) d[c] = on ? (__expf(x[c] - lse) - (c == (int)t ? 1.f : 0.f)) * inv : 0.f;
+    }
+  }
+  if (lane == 0) part[wave] = acc;      // every lane of a wave holds the same acc
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = valid > 0 ? (part[0] + part[1] + part[2] + part[3]) * inv : __builtin_nanf("");
+}
+}  // namespace
+
+extern "C" int egv_cross_entropy_fwd_bwd(const float* logits, int64_t ld, const int64_t* target, int32_t rows, int32_t cols,
+                                         int64_t ignore_index, float* loss, float* dlogits, int64_t ldd, void* stream) {
+  if (!logits || !target || !loss || rows <= 0 || cols <= 0 || rows > (1 << 20) || cols > 65536 || ld < cols) return EGV_ERR_ARG;
+  if (dlogits && ldd < cols) return EGV_ERR_ARG;
+  EGV_LAUNCH(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, (long)ld, (const long long*)target, rows, cols,
+             (long long)ignore_index, loss, dlogits, (long)ldd);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}

@@ -4,7 +4,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import check
-from .ops import _p, _stream
+from .ops import _p
 
 
 def sim_fwd(a, b, eps):
@@ -19,7 +19,7 @@ def sim_fwd(a, b, eps):
     norms = torch.empty(n + m, dtype=torch.float32, device=dev)
     out = torch.empty((n, m), dtype=torch.float32, device=dev)
     check(_lib.lib().egv_sim_matrix_fwd(_p(a), _p(b), n, m, D, float(eps), _p(an), _p(bn), _p(norms), _p(out),
-                                        _stream()), "egv_sim_matrix_fwd")
+                                        ops._stream()), "egv_sim_matrix_fwd")
     return out, (an, bn, norms, n, m, D, float(eps))
 
 
@@ -28,7 +28,7 @@ def sim_bwd(data, g):
     g = g.contiguous()
     da = torch.empty_like(an)
     db = torch.empty_like(bn)
-    check(_lib.lib().egv_sim_matrix_bwd(_p(g), _p(an), _p(bn), _p(norms), n, m, D, eps, _p(da), _p(db), _stream()),
+    check(_lib.lib().egv_sim_matrix_bwd(_p(g), _p(an), _p(bn), _p(norms), n, m, D, eps, _p(da), _p(db), ops._stream()),
           "egv_sim_matrix_bwd")
     return da, db
 
@@ -46,7 +46,7 @@ def egonce_from_sim(x, sim_v, sim_n, temperature, use_noun, use_verb, want_grad=
     sv = sim_v.contiguous() if sim_v is not None else None
     sn = sim_n.contiguous() if sim_n is not None else None
     check(_lib.lib().egv_egonce_from_sim(_p(x), _p(sv), _p(sn), n, float(temperature), int(use_noun), int(use_verb),
-                                         _p(loss), _p(dx), _p(work), _stream()), "egv_egonce_from_sim")
+                                         _p(loss), _p(dx), _p(work), ops._stream()), "egv_egonce_from_sim")
     return loss, dx
 
 
@@ -62,7 +62,7 @@ def maxmargin(x, weight, margin, fix_norm, want_grad=True):
         raise ValueError("weight must have one entry per row")
     loss = torch.empty(1, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x) if want_grad else None
-    check(_lib.lib().egv_maxmargin_fwd_bwd(_p(x), _p(w), n, float(margin), int(bool(fix_norm)), _p(loss), _p(dx), _stream()),
+    check(_lib.lib().egv_maxmargin_fwd_bwd(_p(x), _p(w), n, float(margin), int(bool(fix_norm)), _p(loss), _p(dx), ops._stream()),
           "egv_maxmargin_fwd_bwd")
     return loss, dx
 
@@ -76,5 +76,21 @@ def dual_softmax(x, temp=500.0):
     n, m = x.shape
     work = torch.empty_like(x)
     out = torch.empty_like(x)
-    check(_lib.lib().egv_dual_softmax(_p(x), n, m, float(temp), _p(work), _p(out), _stream()), "egv_dual_softmax")
+    check(_lib.lib().egv_dual_softmax(_p(x), n, m, float(temp), _p(work), _p(out), ops._stream()), "egv_dual_softmax")
     return out
+
+
+def cross_entropy(logits, target, ignore_index=-100, want_grad=True):
+    """nn.CrossEntropyLoss (mean over targets != ignore_index) on [rows, classes] fp32 scores and int64 labels -> (loss[1], dlogits)."""
+    ops._need_cuda(logits, target)
+    if logits.dim() != 2 or target.dim() != 1 or target.shape[0] != logits.shape[0]:
+        raise ValueError("cross_entropy: logits [rows, classes], target [rows]")
+    x = logits.float()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    t = target.to(torch.int64).contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device) if want_grad else None
+    check(_lib.lib().egv_cross_entropy_fwd_bwd(_p(x), x.stride(0), _p(t), x.shape[0], x.shape[1], int(ignore_index), _p(loss),
+                                               _p(dx), x.shape[1], ops._stream(x)), "egv_cross_entropy_fwd_bwd")
+    return loss, dx

@@ -6,8 +6,9 @@ Two ways in, same kernels underneath (egovlp_amd/csrc/egonce.hip):
   * the fused hot path  `loss.fused(text, video, noun, verb)`: ONE call computes the three similarity
     matrices, the mask, the loss and the gradients w.r.t. both embeddings (egv_egonce_fwd_bwd).
 MaxMarginRankingLoss (:55-90) and AdaptiveMaxMarginRankingLoss (:92-133), the EPIC-MIR / Charades fine-tuning heads over the
-same similarity matrix, run on egv_maxmargin_fwd_bwd.  CrossEntropy (:135-141) is a plain nn.CrossEntropyLoss
-wrapper of the classification fine-tunes and stays out of scope.
+same similarity matrix, run on egv_maxmargin_fwd_bwd.  CrossEntropy (:135-141), the loss of the OSCC / PNR
+classification fine-tunes on the [B, classes] scores of FrozenInTime(video_only=True) (trainer/trainer_oscc.py:335-338), runs on
+egv_cross_entropy_fwd_bwd.
 """
 import torch
 from torch import nn
@@ -110,3 +111,27 @@ class AdaptiveMaxMarginRankingLoss(nn.Module):
         if weight is None:
             raise TypeError("AdaptiveMaxMarginRankingLoss needs the per-row weight (model/loss.py:109)")
         return _MaxMarginFn.apply(x, weight, self.margin, self.fix_norm)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target):
+        loss, dx = loss_ops.cross_entropy(output, target, want_grad=True)
+        ctx.save_for_backward(dx)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None
+
+
+class CrossEntropy(nn.Module):
+    """model/loss.py:135-141: `nn.CrossEntropyLoss()(output, target)` (mean reduction, ignore_index -100), the loss of
+    configs/ft/oscc.json and pnr.json."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, output, target):
+        return _CrossEntropyFn.apply(output, target)

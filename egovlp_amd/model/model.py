@@ -26,38 +26,53 @@ from .video_transformer import SpaceTimeTransformer, _lin_bwd
 
 
 class _ProjFn(torch.autograd.Function):
-    """y = [relu](x) W^T + b on rows of x (possibly strided: the CLS row of every caption)."""
+    """y = [relu](x) W^T + b on rows of x (possibly strided: the CLS row of every caption).
+    Narrow heads (projection_dim = 2 of the OSCC fine-tune, 17 of PNR: configs/ft/oscc.json, pnr.json) run with the output
+    width zero-padded to a multiple of 32 -- the GEMM writes 4-column pieces and the dgrad contracts over the output width in
+    32-deep MFMA steps; the pad rows of W are zeros, the pad columns of y / dy are dropped / zero."""
 
     @staticmethod
     def forward(ctx, x2d, w, b, relu, ec: ExecContext):
         P = ec.fwd_passes
         M, K = x2d.shape
+        N = w.shape[0]
+        Np = N if N % 32 == 0 else (N + 31) // 32 * 32
         if relu:
             a = ops.relu_split(x2d, P)
         else:
             a, _, _ = ops.split_f32(x2d, P)
-        y = torch.empty((M, w.shape[0]), dtype=torch.float32, device=x2d.device)
-        ops.gemm_nt(a, ec.wc.get(w, need_t=False)[0], passes=P, bias=b, out_f32=y, ec=ec)
-        ctx.a, ctx.relu, ctx.ec, ctx.P = a, relu, ec, P
+        if Np == N:
+            w_pl, bias = ec.wc.get(w, need_t=False)[0], b
+        else:       # tiny (Np x K): padded planes are rebuilt per call instead of living in the weight cache
+            w_pl = ops.split_f32(F.pad(w.detach(), (0, 0, 0, Np - N)), 3)[0]
+            bias = None if b is None else F.pad(b.detach(), (0, Np - N))
+        y = torch.empty((M, Np), dtype=torch.float32, device=x2d.device)
+        ops.gemm_nt(a, w_pl, passes=P, bias=bias, out_f32=y, ec=ec)
+        ctx.a, ctx.relu, ctx.ec, ctx.P, ctx.Np = a, relu, ec, P, Np
         ctx.save_for_backward(x2d, w)
-        return y
+        return y if Np == N else y[:, :N]
 
     @staticmethod
     def backward(ctx, dy):
         x2d, w = ctx.saved_tensors
         ec = ctx.ec
         Pb = ec.bwd_passes
+        N, Np = w.shape[0], ctx.Np
         if not ec.on_text_stream():
             ec.poll_backward()          # vid_proj: the first node of the video tower's backward on the main stream
-        dy = dy.contiguous()
+        dy = dy.contiguous() if Np == N else F.pad(dy, (0, Np - N))
         dy_pl = ops.split_f32(dy, Pb)[0]
         _, dW, db = _lin_bwd(dy_pl, ctx.a, None, Pb, need_dx=False, params=(w,), ec=ec)
         dx = torch.empty((x2d.shape[0], x2d.shape[1]), dtype=torch.float32, device=dy.device)
-        wt = ec.wc.get(w, need_t=True)[1]
-        if ctx.relu:
-            ops.gemm_nt(dy_pl, wt, passes=Pb, act=ACT_RELU_BWD, aux_in=x2d, out_f32=dx, K=w.shape[0], ec=ec)
+        if Np == N:
+            wt = ec.wc.get(w, need_t=True)[1]
         else:
-            ops.gemm_nt(dy_pl, wt, passes=Pb, out_f32=dx, K=w.shape[0], ec=ec)
+            wt = ops.split_f32(F.pad(w.detach(), (0, 0, 0, Np - N)), 3, want_rowmajor=False, want_transposed=True)[1]
+            dW, db = dW[:N].contiguous(), db[:N].contiguous()
+        if ctx.relu:
+            ops.gemm_nt(dy_pl, wt, passes=Pb, act=ACT_RELU_BWD, aux_in=x2d, out_f32=dx, K=Np, ec=ec)
+        else:
+            ops.gemm_nt(dy_pl, wt, passes=Pb, out_f32=dx, K=Np, ec=ec)
         return dx, dW, db, None, None
 
 

@@ -219,6 +219,14 @@ int egv_egonce_from_sim(const float* x, const float* sim_v, const float* sim_n, 
 int egv_maxmargin_fwd_bwd(const float* x, const float* weight, int32_t n, float margin, int32_t fix_norm,
                           float* loss, float* dx, void* stream);
 
+/* Softmax cross-entropy of the classification fine-tunes (OSCC / PNR heads): model/loss.py:135-141 (nn.CrossEntropyLoss with its
+ * defaults) on the [rows, cols] scores of FrozenInTime(video_only=True) (trainer/trainer_oscc.py:335-338).
+ *   loss = mean over rows with target != ignore_index of (logsumexp(x_r) - x_r[target_r]);  NaN when no row is valid (as torch);
+ *   dlogits (optional, [rows, ldd]) = (softmax(x_r) - onehot(target_r)) / #valid rows, 0 for ignored rows.
+ * Deterministic (fixed summation order).  rows <= 2^20, cols <= 65536.                                                     */
+int egv_cross_entropy_fwd_bwd(const float* logits, int64_t ld, const int64_t* target, int32_t rows, int32_t cols,
+                              int64_t ignore_index, float* loss, float* dlogits, int64_t ldd, void* stream);
+
 /* Dual-softmax re-scaling of a retrieval similarity matrix x [n texts, m videos] (run/test_epic.py:137-143, --dual_softmax):
  *   y = softmax(x / temp, dim 1) * x;  out = softmax(y, dim 0).  work: n*m floats.  temp = 500 in the reference.        */
 int egv_dual_softmax(const float* x, int32_t n, int32_t m, float temp, float* work, float* out, void* stream);

@@ -165,3 +165,23 @@ def test_hook_free_buckets_leave_during_backward_on_the_real_model(model, gloo_w
         assert launched_at[2] >= text_params // gs.bucket_elems, launched_at
     else:
         assert launched_at[0] == 0
+
+
+def test_narrow_classification_head_wiring():
+    """OSCC fine-tune head (projection_dim = 2, video_only, CrossEntropy): the padded projection returns [B, 2] scores and
+    gradients of the parameters' own shapes."""
+    from egovlp_amd.model.loss import CrossEntropy
+    from egovlp_amd.model.model import FrozenInTime
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 4,
+                                   "pretrained": True, "time_init": "rand"},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+                     projection="minimal", projection_dim=2, load_checkpoint="").train()
+    b = _batch()
+    with mock_hip() as calls:
+        scores = m({"video": b["video"]}, video_only=True)
+        assert scores.shape == (2, 2)
+        loss = CrossEntropy()(scores, torch.tensor([0, 1]))
+        loss.backward()
+    assert "egv_cross_entropy_fwd_bwd" in calls
+    assert m.vid_proj[0].weight.grad.shape == (2, 768) and m.vid_proj[0].bias.grad.shape == (2,)
+    assert m.video_model.blocks[0].mlp.fc1.weight.grad is not None and m.txt_proj[1].weight.grad is None
