@@ -97,100 +97,119 @@ class Multi_BaseTrainer_dist:
     def _valid_epoch(self, epoch):
         raise NotImplementedError
 
+    # ---- epoch loop ------------------------------------------------------------------------------------------------------
+    # Contract with the reference's callers (run/train_egoclip.py:98 `trainer.train()`; base/base_trainer.py:313-380 is what
+    # they expect to have happened afterwards), kept and tested in tests/test_gpu_trainer.py:
+    #   * optional validation pass before the first epoch (`init_val`), then epochs start_epoch .. epochs;
+    #   * rank 0 logs one flat dict per epoch: 'epoch', every scalar `_train_epoch` returned, the metric lists under their
+    #     function names ('metrics' -> name, 'val_metrics' -> 'val_' + name) and the nested validation metrics as
+    #     'val_{loader}_{metric}_{entry}';
+    #   * `monitor = "<min|max> <key>"` tracks the best value of a logged key (a missing key switches monitoring off with a
+    #     warning), `save_period` and a new best both trigger a checkpoint, written by rank 0 only;
+    #   * returns the number of consecutive epochs without improvement.
+    def _flat_epoch_log(self, epoch, result):
+        log = {'epoch': epoch}
+        names = [m.__name__ for m in (self.metrics or [])]
+        for key, value in result.items():
+            if key == 'metrics':
+                log.update(zip(names, value))
+            elif key == 'val_metrics':
+                log.update(('val_' + n, v) for n, v in zip(names, value))
+            elif key == 'nested_val_metrics':
+                for loader, per_metric in value.items():
+                    for metric, entries in per_metric.items():
+                        for entry, v in entries.items():
+                            log[f"val_{loader}_{metric}_{entry}"] = v
+            else:
+                log[key] = value
+        return log
+
+    def _is_new_best(self, log):
+        """-> True / False, or None when monitoring is (or has just been switched) off."""
+        if self.mnt_mode == 'off':
+            return None
+        if self.mnt_metric not in log:
+            self.logger.warning("Warning: Metric '{}' is not found. Model performance monitoring is disabled.".format(self.mnt_metric))
+            self.mnt_mode = 'off'
+            return None
+        value = log[self.mnt_metric]
+        better = value <= self.mnt_best if self.mnt_mode == 'min' else value >= self.mnt_best
+        if better:
+            self.mnt_best = value
+        return better
+
     def train(self):
-        """Full training logic (base/base_trainer.py:313-380)."""
-        not_improved_count = 0
+        is_writer = self.args.rank == 0
+        stale_epochs = 0
         if self.init_val:
-            _ = self._valid_epoch(-1)
+            self._valid_epoch(-1)
         for epoch in range(self.start_epoch, self.epochs + 1):
             result = self._train_epoch(epoch)
-            log = {'epoch': epoch}
-            for key, value in result.items():
-                if self.args.rank == 0:
-                    if key == 'metrics':
-                        log.update({mtr.__name__: value[i] for i, mtr in enumerate(self.metrics)})
-                    elif key == 'val_metrics':
-                        log.update({'val_' + mtr.__name__: value[i] for i, mtr in enumerate(self.metrics)})
-                    elif key == 'nested_val_metrics':
-                        for subkey, subval in value.items():
-                            for subsubkey, subsubval in subval.items():
-                                for subsubsubkey, subsubsubval in subsubval.items():
-                                    log[f"val_{subkey}_{subsubkey}_{subsubsubkey}"] = subsubsubval
-                    else:
-                        log[key] = value
-            for key, value in log.items():
-                if self.args.rank == 0:
-                    self.logger.info('    {:15s}: {}'.format(str(key), value))
             best = False
-            if self.mnt_mode != 'off' and self.args.rank == 0:
-                try:
-                    improved = (self.mnt_mode == 'min' and log[self.mnt_metric] <= self.mnt_best) or \
-                               (self.mnt_mode == 'max' and log[self.mnt_metric] >= self.mnt_best)
-                except KeyError:
-                    self.logger.warning("Warning: Metric '{}' is not found. "
-                                        "Model performance monitoring is disabled.".format(self.mnt_metric))
-                    self.mnt_mode = 'off'
-                    improved = False
-                if improved:
-                    self.mnt_best = log[self.mnt_metric]
-                    not_improved_count = 0
-                    best = True
-                else:
-                    not_improved_count += 1
-            if epoch % self.save_period == 0 or best:
-                if self.args.rank == 0:
+            if is_writer:
+                log = self._flat_epoch_log(epoch, result)
+                for key, value in log.items():
+                    self.logger.info('    {:15s}: {}'.format(str(key), value))
+                verdict = self._is_new_best(log)
+                if verdict is not None:
+                    best = verdict
+                    stale_epochs = 0 if verdict else stale_epochs + 1
+                if best or epoch % self.save_period == 0:
                     self._save_checkpoint(epoch, save_best=best)
-        return not_improved_count
+        return stale_epochs
+
+    # ---- checkpoints: the reference's FILE FORMAT (base/base_trainer.py:399-480), so that its checkpoints resume here and
+    # ours load there: one dict {'arch', 'epoch', 'state_dict', 'optimizer', 'monitor_best', 'config'} per file,
+    # 'checkpoint-epoch{N}.pth' every save_period epochs and a second copy 'model_best.pth' for a new best.
+    def _checkpoint_state(self, epoch):
+        return {'arch': type(self.model).__name__, 'epoch': epoch, 'state_dict': self.model.state_dict(),
+                'optimizer': self.optimizer.state_dict(), 'monitor_best': self.mnt_best, 'config': self.config}
 
     def _save_checkpoint(self, epoch, save_best=False):
-        """base/base_trainer.py:399-422, same keys and file names."""
-        arch = type(self.model).__name__
-        state = {
-            'arch': arch,
-            'epoch': epoch,
-            'state_dict': self.model.state_dict(),
-            'optimizer': self.optimizer.state_dict(),
-            'monitor_best': self.mnt_best,
-            'config': self.config,
-        }
-        filename = str(self.checkpoint_dir / 'checkpoint-epoch{}.pth'.format(epoch))
-        torch.save(state, filename)
-        self.logger.info("Saving checkpoint: {} ...".format(filename))
+        state = self._checkpoint_state(epoch)
+        targets = [('checkpoint-epoch{}.pth'.format(epoch), "Saving checkpoint: {} ...")]
         if save_best:
-            best_path = str(self.checkpoint_dir / 'model_best.pth')
-            torch.save(state, best_path)
-            self.logger.info("Saving current best: model_best.pth ...")
+            targets.append(('model_best.pth', "Saving current best: {} ..."))
+        for name, message in targets:
+            path = str(self.checkpoint_dir / name)
+            torch.save(state, path)
+            self.logger.info(message.format(path if name != 'model_best.pth' else name))
+
+    @staticmethod
+    def _match_module_prefix(state_dict, want_prefix):
+        """Reference checkpoints come from a DDP-wrapped model ('module.' on every key); this trainer never wraps.  Re-key
+        the loaded state_dict to what the live model uses."""
+        has = next(iter(state_dict)).startswith('module.')
+        if has == want_prefix:
+            return state_dict
+        if has:
+            return type(state_dict)((k[len('module.'):], v) for k, v in state_dict.items())
+        return type(state_dict)(('module.' + k, v) for k, v in state_dict.items())
 
     def _resume_checkpoint(self, resume_path):
-        """base/base_trainer.py:424-480."""
         resume_path = str(resume_path)
         self.logger.info("Loading checkpoint: {} ...".format(resume_path))
-        checkpoint = load_checkpoint_file(resume_path, map_location=self.device)
-        self.start_epoch = checkpoint['epoch'] + 1
-        self.mnt_best = checkpoint['monitor_best']
-        try:
-            if checkpoint['config']['arch'] != self.config['arch']:
-                self.logger.warning("Warning: Architecture configuration given in config file is different from that of "
-                                    "checkpoint. This may yield an exception while state_dict is being loaded.")
-        except (KeyError, TypeError):
-            pass
-        state_dict = checkpoint['state_dict']
-        load_keys = list(state_dict.keys())
-        curr_keys = list(self.model.state_dict().keys())
-        if not curr_keys[0].startswith('module.') and load_keys[0].startswith('module.'):
-            state_dict = type(state_dict)((k[7:], v) for k, v in state_dict.items())
-        elif curr_keys[0].startswith('module.') and not load_keys[0].startswith('module.'):
-            state_dict = type(state_dict)(('module.' + k, v) for k, v in state_dict.items())
-        self.model.load_state_dict(state_dict)
+        ckpt = load_checkpoint_file(resume_path, map_location=self.device, trusted=True)
+        self.start_epoch = ckpt['epoch'] + 1
+        self.mnt_best = ckpt['monitor_best']
+
+        def cfg_of(section):            # the pickled config is a ConfigParser, a DictConfig or a placeholder: all optional
+            try:
+                return ckpt['config'][section], self.config[section]
+            except (KeyError, TypeError):
+                return None, None
+        theirs, ours = cfg_of('arch')
+        if theirs is not None and theirs != ours:
+            self.logger.warning("Warning: Architecture configuration given in config file is different from that of "
+                                "checkpoint. This may yield an exception while state_dict is being loaded.")
+        live_keys = self.model.state_dict().keys()
+        self.model.load_state_dict(self._match_module_prefix(ckpt['state_dict'], next(iter(live_keys)).startswith('module.')))
         from .. import weights
         weights.bump_epoch()        # parameters changed under the cached bf16 operand planes
-        try:
-            same_opt = checkpoint['config']['optimizer']['type'] == self.config['optimizer']['type']
-        except (KeyError, TypeError):
-            same_opt = True
-        if not same_opt:
+        theirs, ours = cfg_of('optimizer')
+        if theirs is not None and theirs['type'] != ours['type']:
             self.logger.warning("Warning: Optimizer type given in config file is different from that of checkpoint. "
                                 "Optimizer parameters not being resumed.")
         else:
-            self.optimizer.load_state_dict(checkpoint['optimizer'])
+            self.optimizer.load_state_dict(ckpt['optimizer'])
         self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))

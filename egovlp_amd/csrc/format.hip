@@ -554,7 +554,10 @@ __global__ __launch_bounds__(256) void patch_gather_aug_kernel(const unsigned ch
   const int c = (int)(t % C);
   const int bt = (int)(t / C);
   const int* bx = boxes + (long)(bt / T) * 5;
-  const int top = bx[0], left = bx[1], bh = bx[2], bw = bx[3], flip = bx[4];
+  // a box that leaves the frame is CLAMPED into it (the host validates boxes it can see, model/video_transformer.py
+  // set_input_augmentation; a device-resident box cannot be checked without a sync): no read below can leave the clip
+  const int top = min(max(bx[0], 0), Hs - 1), left = min(max(bx[1], 0), Ws - 1);
+  const int bh = min(max(bx[2], 1), Hs - top), bw = min(max(bx[3], 1), Ws - left), flip = bx[4];
   const unsigned char* src = video + ((long)bt * C + c) * Hs * Ws;
   const float sy = (float)bh / (float)R, sx = (float)bw / (float)R;
   float fy = ((float)y + 0.5f) * sy - 0.5f;

@@ -123,7 +123,7 @@ class FrozenInTime(BaseModel):
             model.pre_logits = nn.Identity()
             ftr_dim = model.embed_dim
             if load_checkpoint in ["", None] and vit_path and os.path.exists(vit_path):
-                vit_checkpoint = load_checkpoint_file(vit_path, map_location="cpu")
+                vit_checkpoint = load_checkpoint_file(vit_path, map_location="cpu")      # a plain state_dict: safe path only
                 new_vit_dict = state_dict_data_parallel_fix(vit_checkpoint, model.state_dict())
                 model.load_state_dict(new_vit_dict, strict=False)                                # :58-63
             self.video_model = model
@@ -151,7 +151,7 @@ class FrozenInTime(BaseModel):
             dev = 'cuda:{}'.format(local_rank) if torch.cuda.is_available() else 'cpu'
             # reference checkpoints pickle their ConfigParser next to the weights (base/base_trainer.py:407-414): read them
             # with the lenient unpickler of utils/util.py (torch >= 2.6 refuses the global under weights_only=True)
-            checkpoint = load_checkpoint_file(load_checkpoint, map_location=dev)
+            checkpoint = load_checkpoint_file(load_checkpoint, map_location=dev, trusted=True)   # the file the config names
             state_dict = checkpoint['state_dict']
             new_state_dict = state_dict_data_parallel_fix(state_dict, self.state_dict())
             new_state_dict = self._inflate_positional_embeds(new_state_dict)

@@ -407,8 +407,11 @@ class SpaceTimeTransformer(nn.Module):
         egovlp_amd.data_loader.transforms.train_transform_params) select, per clip, the region of the decoded uint8 frames
         that is resized to `out_res` (default: the model's img_size), flipped and normalised inside the patch gather.
         One-shot: consumed by the next forward_features call."""
+        host = boxes.detach().to(dtype=torch.int64).cpu() if not boxes.is_cuda else None     # checked against the frame size in forward
+        if host is not None and (host.dim() != 2 or host.shape[1] != 5 or bool((host[:, :2] < 0).any()) or bool((host[:, 2:4] < 1).any())):
+            raise ValueError("set_input_augmentation: boxes are int [B, 5] rows (top >= 0, left >= 0, h >= 1, w >= 1, flip)")
         self._input_aug = (boxes.to(device=self.cls_token.device, dtype=torch.int32).contiguous(),
-                           int(out_res or self.patch_embed.img_size[0]))
+                           int(out_res or self.patch_embed.img_size[0]), host)
 
     def forward_features(self, x):
         b, curr_frames, channels, Hh, Ww = x.shape
@@ -419,6 +422,11 @@ class SpaceTimeTransformer(nn.Module):
         if aug is not None:
             if x.dtype != torch.uint8:
                 raise ValueError("set_input_augmentation expects decoded uint8 frames")
+            host = aug[2]
+            if host is not None and (host.shape[0] != b or bool((host[:, 0] + host[:, 2] > Hh).any())
+                                     or bool((host[:, 1] + host[:, 3] > Ww).any())):
+                raise ValueError(f"set_input_augmentation: a crop box leaves the {Hh} x {Ww} frame (or the batch size changed)")
+            aug = aug[:2]
             Hh = Ww = aug[1]                                                   # the resized crop is what gets patched
         n = (Hh // P_) * (Ww // P_)
         if n != self.patches_per_frame:

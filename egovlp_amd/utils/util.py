@@ -52,12 +52,24 @@ class _Placeholder:
         return cfg[name]
 
 
+# Globals the lenient unpickler resolves for real: what tensors, optimizer state, numpy scalars / arrays and plain containers
+# are made of.  EVERYTHING else -- the reference's ConfigParser, loggers, and whatever a hostile file names (os.system,
+# builtins.eval, ...) -- becomes an inert _Placeholder class: it is constructed and given its state, it never runs code.
+_ALLOWED_MODULE_PREFIXES = ("torch", "collections", "numpy", "pathlib", "_codecs")
+_ALLOWED_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
+                     "slice", "range", "object"}
+
+
 class _LenientUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            return type(name, (_Placeholder,), {'__module__': module})
+        allowed = (module == "builtins" and name in _ALLOWED_BUILTINS) or \
+            any(module == p_ or module.startswith(p_ + ".") for p_ in _ALLOWED_MODULE_PREFIXES)
+        if allowed:
+            try:
+                return super().find_class(module, name)
+            except (ImportError, AttributeError):
+                pass
+        return type(name, (_Placeholder,), {'__module__': module})
 
 
 class _LenientPickle:
@@ -74,10 +86,20 @@ class _LenientPickle:
     HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
 
 
-def load_checkpoint_file(path, map_location=None):
-    """torch.load for the reference's (trusted) checkpoint files, see the module docstring.  Plain state_dict files and
-    files whose globals are importable take the safe path first."""
+def load_checkpoint_file(path, map_location=None, trusted=False):
+    """torch.load for checkpoint files.  Plain state_dict files (and any file the safe `weights_only=True` unpickler accepts)
+    load on the safe path.  A file the safe unpickler REJECTS -- the reference's own checkpoints pickle their ConfigParser next
+    to the weights -- is read with the lenient unpickler only when the caller says the file is `trusted` (a checkpoint the
+    user named in the config / on the command line); a warning is logged.  A missing or corrupt file raises as usual: only
+    the safe unpickler's refusal (pickle.UnpicklingError) triggers the fallback."""
     try:
         return torch.load(path, map_location=map_location, weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError as e:
+        if not trusted:
+            raise pickle.UnpicklingError(
+                f"{path}: not loadable with weights_only=True ({str(e).splitlines()[0][:200]}); pass trusted=True to "
+                f"load_checkpoint_file for a reference-format checkpoint you trust") from e
+        import warnings
+        warnings.warn(f"{path}: the safe unpickler refused this file; reading it with the allow-list unpickler "
+                      f"(unknown classes become inert placeholders)")
         return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_LenientPickle)

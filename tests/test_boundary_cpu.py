@@ -104,7 +104,13 @@ def test_checkpoint_with_unimportable_config_object_and_module_prefix(tmp_path):
                     "state_dict": OrderedDict(("module." + k, v) for k, v in vals.items()), "config": ConfigParser()}, path)
     finally:
         del sys.modules["parse_config_gone"]
-    ck = load_checkpoint_file(path, map_location="cpu")
+    import pickle
+    with pytest.raises(pickle.UnpicklingError):                     # not silently: the fallback is opt-in (advisor finding)
+        load_checkpoint_file(path, map_location="cpu")
+    with pytest.raises(FileNotFoundError):                          # and only the safe unpickler's refusal triggers it
+        load_checkpoint_file(path + ".missing", map_location="cpu", trusted=True)
+    with pytest.warns(UserWarning, match="allow-list unpickler"):
+        ck = load_checkpoint_file(path, map_location="cpu", trusted=True)
     assert ck["epoch"] == 1 and ck["config"]["optimizer"]["type"] == "AdamW"        # read access like _resume_checkpoint's
     m = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
                      load_checkpoint=path)
@@ -117,6 +123,28 @@ def test_checkpoint_with_unimportable_config_object_and_module_prefix(tmp_path):
     m4 = FrozenInTime(video_params={**VIDEO_PARAMS, "num_frames": 4}, text_params=dict(TEXT_PARAMS), projection="minimal",
                       load_checkpoint=path)
     assert torch.equal(m4.video_model.temporal_embed, vals16["video_model.temporal_embed"][:, :4])
+
+
+def test_lenient_unpickler_never_resolves_code_carrying_globals(tmp_path):
+    """A checkpoint-shaped pickle that names os.system / builtins.eval as a reducer: with the allow-list unpickler the global
+    becomes an inert placeholder class -- nothing is executed -- while tensors and containers next to it load normally."""
+    import pickle
+    from egovlp_amd.utils.util import _LenientUnpickler, _Placeholder
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    class Evil2:
+        def __reduce__(self):
+            return (eval, ("__import__('os').getcwd()",))
+    blob = pickle.dumps({"epoch": 3, "state_dict": {"w": [1.0, 2.0]}, "config": Evil(), "x": Evil2()})
+    import io
+    out = _LenientUnpickler(io.BytesIO(blob)).load()
+    assert out["epoch"] == 3 and out["state_dict"]["w"] == [1.0, 2.0]
+    assert isinstance(out["config"], _Placeholder) and isinstance(out["x"], _Placeholder)
+    assert not (tmp_path / "pwned").exists()
 
 
 def test_eval_token_padding_for_graph_replay():

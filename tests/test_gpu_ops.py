@@ -461,3 +461,28 @@ def test_fused_train_transform_matches_the_host_transform(P, R):
     # hi-only planes equal bf16 rounding of the same values
     got1 = ops.patch_gather(u8.cuda(), P, 1, aug=(boxes.cuda(), R))
     assert got1.lo is None and float((got1.float().cpu() - want).abs().max()) < 2e-2
+
+
+def test_crop_boxes_that_leave_the_frame_are_clamped_in_the_kernel_and_refused_on_the_host():
+    """Advisor finding (round 2): crop boxes went to the gather kernel unchecked (out-of-bounds reads of the uint8 clip).  Device
+    side: a box is clamped into the frame (same result as the clamped box, no fault); host side: set_input_augmentation validates
+    the boxes it can see against the frame size at forward time."""
+    from egovlp_amd import ops
+    from egovlp_amd.model.video_transformer import SpaceTimeTransformer
+    B, T, C, Hs, Ws, P, R = 2, 2, 3, 256, 341, 16, 224
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (B, T, C, Hs, Ws), generator=g, dtype=torch.uint8).cuda()
+    bad = torch.tensor([[-5, 300, 400, 100, 0], [200, -7, 9999, 9999, 1]], dtype=torch.int32)
+    clamped = torch.tensor([[0, 300, 256, 41, 0], [200, 0, 56, 341, 1]], dtype=torch.int32)
+    a = ops.patch_gather(u8, P, 3, aug=(bad.cuda(), R))
+    b = ops.patch_gather(u8, P, 3, aug=(clamped.cuda(), R))
+    torch.cuda.synchronize()
+    assert torch.equal(a.hi, b.hi) and torch.equal(a.lo, b.lo)
+    net = SpaceTimeTransformer(num_classes=0, num_frames=4).cuda()
+    with pytest.raises(ValueError):
+        net.set_input_augmentation(torch.tensor([[0, 0, 0, 10, 0], [0, 0, 10, 10, 0]]))        # h = 0
+    net.set_input_augmentation(torch.tensor([[100, 0, 200, 300, 0], [0, 0, 256, 341, 1]]))       # top + h = 300 > 256
+    with pytest.raises(ValueError):
+        net(u8)
+    net.set_input_augmentation(torch.tensor([[10, 20, 200, 300, 0], [0, 0, 256, 341, 1]]))
+    assert net(u8).shape == (B, 768)

@@ -101,7 +101,7 @@ def test_train_checkpoint_resume(tmp_path):
     tr.train()                                                              # run/train_egoclip.py:98
     files = sorted(os.listdir(tmp_path / "run1"))
     assert "checkpoint-epoch1.pth" in files and "checkpoint-epoch2.pth" in files
-    ck1 = load_checkpoint_file(str(tmp_path / "run1" / "checkpoint-epoch1.pth"), map_location="cpu")
+    ck1 = load_checkpoint_file(str(tmp_path / "run1" / "checkpoint-epoch1.pth"), map_location="cpu", trusted=True)
     assert set(ck1) == {"arch", "epoch", "state_dict", "optimizer", "monitor_best", "config"}      # base/base_trainer.py:407-414
     assert ck1["arch"] == "FrozenInTime" and ck1["epoch"] == 1 and len(ck1["state_dict"]) == 327
     assert ck1["optimizer"]["param_groups"][0]["lr"] == 2e-4               # the LR rule after epoch 1 (:75-80,178)
