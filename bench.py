@@ -264,6 +264,9 @@ def main():
                          "(single GPU only; bit-identical results)")
     ap.add_argument("--rccl-channels", type=int, default=0, help="N>1: cap RCCL at this many channels (= workgroups) via "
                     "NCCL_MAX_NCHANNELS, e.g. 8 to match the CUs the 248-workgroup GEMM grid leaves free (default: RCCL's choice)")
+    ap.add_argument("--grad-exchange", default=os.environ.get("EGV_GRAD_EXCHANGE", "direct"), choices=["direct", "allreduce"],
+                    help="N>1: how a bf16 gradient bucket travels -- direct (default): all-to-all of bucket slices over all xGMI "
+                         "links, fp32 slice sum, all-gather; allreduce: RCCL's stock all_reduce of the bf16 bucket")
     ap.add_argument("--grad-sync-hooks", type=int, default=0, help="N>1: 1 = launch the gradient buckets from autograd "
                     "grad-ready hooks; 0 (default) = hook-free, from the block-boundary poll")
     ap.add_argument("--no-grad-sync", action="store_true", help="diagnostics: process group and embedding gather, but no "
@@ -334,9 +337,10 @@ def main():
     elif use_dist and not args.no_grad_sync:
         from egovlp_amd.dist import Bf16GradSync
         if args.grad_sync_hooks:
-            grad_sync = Bf16GradSync(model.parameters(), stream_of=model.gradient_stream_of, exec_ctx=ec)
+            grad_sync = Bf16GradSync(model.parameters(), stream_of=model.gradient_stream_of, exec_ctx=ec, exchange=args.grad_exchange)
         else:     # hook-free: buckets launched from the polls of the video tower's backward (ExecContext.backward_poll)
-            grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec)
+            grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
+                                     exchange=args.grad_exchange)
             ec.set(backward_poll=grad_sync.poll)
     grid = args.gemm_grid or (248 if world > 1 else 256)
     ec.set(gemm_grid=grid)
@@ -476,7 +480,10 @@ def main():
         allr = torch.stack(allr).cpu()
         out["comm"] = {"rccl_ranks": world, "backend": dist.get_backend(), "gemm_grid": grid,
                        "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS", "default"),
-                       "gradient_exchange": "DDP fp32 buckets" if args.ddp else "Bf16GradSync (bf16 buckets, async all-reduce from grad hooks)",
+                       "gradient_exchange": "DDP fp32 buckets" if args.ddp else (
+                           "Bf16GradSync direct (bf16 buckets: all-to-all of slices over all links, fp32 slice sum, all-gather; launched from "
+                           "the backward polls on a private stream)" if args.grad_exchange == "direct" else
+                           "Bf16GradSync allreduce (bf16 buckets, async RCCL all-reduce launched from the backward polls)"),
                        "grad_sync": None if grad_sync is None else {k: int(v) for k, v in grad_sync.stats.items()
                                                                    if k in ("buckets", "launched_during_backward")},
                        "ms_per_step_rank_min": round(float(allr[:, 0].min()), 3), "ms_per_step_rank_max": round(float(allr[:, 0].max()), 3),

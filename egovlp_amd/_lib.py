@@ -77,6 +77,7 @@ PROTOTYPES = {
     "egv_adamw_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, f32, f32, f32, f32, f32, i32, i32, f32, c_p]),
     "egv_grad_pack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, f32, c_p]),
     "egv_grad_unpack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, c_p]),
+    "egv_slice_sum_bf16": (i32, [c_p, i32, i64, c_p, c_p]),
     "egv_relu_split": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p]),
     "egv_version": (i32, []),
     "egv_split_f32_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

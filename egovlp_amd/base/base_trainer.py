@@ -58,11 +58,12 @@ class Multi_BaseTrainer_dist:
                 # hook-free: buckets are launched from the polls of the video tower's backward (autograd grad-ready hooks
                 # cost 0.6 ms per step more on this model, profiles/r02_d_dp_overhead.txt)
                 self.grad_sync = Bf16GradSync(self.model.parameters(), use_hooks=False,
-                                              order_hint=self.model.gradient_ready_order(), exec_ctx=ec)
+                                              order_hint=self.model.gradient_ready_order(), exec_ctx=ec,
+                                              exchange=os.environ.get("EGV_GRAD_EXCHANGE", "direct"))
                 ec.set(backward_poll=self.grad_sync.poll)
             else:
                 self.grad_sync = Bf16GradSync(self.model.parameters(), stream_of=getattr(self.model, "gradient_stream_of", None),
-                                              exec_ctx=ec)
+                                              exec_ctx=ec, exchange=os.environ.get("EGV_GRAD_EXCHANGE", "direct"))
             # the persistent GEMM owns every CU for the length of a launch: leave one CU per XCD to the RCCL kernels of the
             # overlapped gradient exchange (bench.py does the same; the wgrad split-K policy follows the cap)
             ec.set(gemm_grid=int(os.environ.get("EGV_GEMM_GRID", "248")))

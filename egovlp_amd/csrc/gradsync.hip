@@ -81,7 +81,37 @@ int run(int32_t count, float* const* f32, const int64_t* numel, bf16_t* flat, co
   return flush();
 }
 
+// The local step of the DIRECT exchange (egovlp_amd.dist.Bf16GradSync, exchange = "direct"): after the all-to-all every rank holds
+// `world` slices -- its own slice of every peer's bucket, back to back -- and sums them in FP32 (one rounding to bf16 at the end,
+// where a bf16 all-reduce rounds after every one of its world - 1 additions); the reduced slice is then all-gathered.
+// 16-byte accesses (8 bf16 per lane), world <= 64.
+__global__ __launch_bounds__(256) void slice_sum_kernel(const bf16_t* __restrict__ recv, int world, long slice, bf16_t* __restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= slice) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < world; ++p) {
+    const u32x4_t w = *(const u32x4_t*)(recv + (long)p * slice + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[2 * e] += __uint_as_float(w[e] << 16);
+      acc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+    }
+  }
+  *(u32x4_t*)(out + i) = (u32x4_t){f32x2_to_bf16x2(acc[0], acc[1]), f32x2_to_bf16x2(acc[2], acc[3]), f32x2_to_bf16x2(acc[4], acc[5]),
+                                   f32x2_to_bf16x2(acc[6], acc[7])};
+}
+
 }  // namespace
+
+extern "C" int egv_slice_sum_bf16(const egv_bf16* recv, int32_t world, int64_t slice_elems, egv_bf16* out, void* stream) {
+  if (!recv || !out || world < 1 || world > 64 || slice_elems <= 0 || slice_elems % 8 != 0) return EGV_ERR_ARG;
+  if ((((size_t)recv) & 15) || (((size_t)out) & 15)) return EGV_ERR_ARG;
+  const long lanes = slice_elems / 8;
+  EGV_LAUNCH(slice_sum_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, recv, world, (long)slice_elems,
+             (bf16_t*)out);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
 
 extern "C" int egv_grad_pack_bf16(int32_t count, const float* const* grads, const int64_t* numel, egv_bf16* flat,
                                   const int64_t* offsets, float scale, void* stream) {

@@ -15,6 +15,16 @@ are per-link bound):
     waits for the collectives and unpacks the means into the fp32 `.grad` tensors (`egv_grad_unpack_bf16`);
   * no graph walk, no module wrapper: `model.state_dict()` keeps the reference's key names on every world size.
 
+Two ways to move a bucket (`exchange`):
+  * "direct" (default): the all-reduce is spelled out as what a fully connected xGMI node is good at (every
+    GPU has a private link to every other, a ring keeps five of the seven idle) -- ONE all-to-all in which rank r receives slice
+    r of every peer's bucket over all links at once, a LOCAL sum of those W slices in fp32 (`egv_slice_sum_bf16`: one rounding
+    to bf16 instead of the W - 1 roundings of a bf16 all-reduce), and ONE all-gather of the reduced slices.  The same bytes per
+    rank as a ring all-reduce (2 (W-1)/W of the bucket), W-1 links busy instead of 2.  The whole chain -- pack, all-to-all, sum,
+    all-gather -- is enqueued on a private exchange stream behind an event of the compute streams, so backward never waits
+    for it; `finish()` makes the compute stream wait for the chain's last event;
+  * "allreduce": RCCL's stock `all_reduce(SUM)` of the bf16 bucket (bf16 accumulation inside the collective).
+
 Semantics equal DDP's: after `finish()` every rank holds (1/W) * sum_r grad_r in p.grad (up to bf16 rounding of the
 exchanged values, 2^-9 relative -- the single-pass backward that produces them rounds its GEMM operands the same way).
 Initial parameters are broadcast from rank 0 at construction, as DDP does.
@@ -58,6 +68,12 @@ def _hip_pack(grads, flat, offsets, scale):
     _lib.check(_lib.lib().egv_grad_pack_bf16(n, P, N, flat.data_ptr(), O, float(scale), ops._stream()), "egv_grad_pack_bf16")
 
 
+def _hip_slice_sum(recv, world, slice_elems, out):
+    from . import _lib, ops
+    _lib.check(_lib.lib().egv_slice_sum_bf16(recv.data_ptr(), int(world), int(slice_elems), out.data_ptr(), ops._stream(recv)),
+               "egv_slice_sum_bf16")
+
+
 def _hip_unpack(grads, flat, offsets):
     from . import _lib, ops
     n = len(grads)
@@ -68,16 +84,21 @@ def _hip_unpack(grads, flat, offsets):
 
 
 class _Bucket:
-    __slots__ = ("params", "offsets", "flat", "pending", "work", "numel")
+    __slots__ = ("params", "offsets", "flat", "pending", "work", "numel", "recv", "red", "slice")
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, world=1, direct=False):
         self.params = params
         self.offsets, off = [], 0
         for p in params:
             self.offsets.append(off)
             off += (p.numel() + 7) // 8 * 8          # every tensor starts on a 16-byte boundary of the bf16 buffer
+        if direct:                                   # W equal slices, each a whole number of 16-byte pieces
+            off = (off + 8 * world - 1) // (8 * world) * (8 * world)
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.bfloat16, device=device)     # the padding stays zero forever
+        self.slice = off // world if direct else 0
+        self.recv = torch.empty(off, dtype=torch.bfloat16, device=device) if direct else None
+        self.red = torch.empty(self.slice, dtype=torch.bfloat16, device=device) if direct else None
         self.pending = len(params)
         self.work = None
 
@@ -86,7 +107,7 @@ class Bf16GradSync:
     def __init__(self, params, process_group=None, bucket_mb: float = 64.0,
                  pack_fn: Optional[Callable] = None, unpack_fn: Optional[Callable] = None, broadcast: bool = True,
                  stream_of: Optional[Callable] = None, use_hooks: bool = True, order_hint: Optional[List] = None,
-                 exec_ctx=None):
+                 exec_ctx=None, exchange: str = "direct", slice_sum_fn: Optional[Callable] = None):
         """`stream_of(param)` -> the HIP stream that parameter's gradient is produced on (None: the current one).  A grad-ready
         hook keeps the parameter's AccumulateGrad node alive across iterations, and autograd runs that node on the stream
         that was current WHEN THE HOOK WAS REGISTERED: for the text tower (its backward runs on its own stream,
@@ -102,6 +123,11 @@ class Bf16GradSync:
 
         `exec_ctx`: the model's egovlp_amd.ops.ExecContext -- gradients are produced on up to three of ITS streams (main, text
         tower, wgrad side stream) and a bucket's pack kernel is ordered behind all of them first."""
+        if exchange not in ("direct", "allreduce"):
+            raise ValueError("Bf16GradSync: exchange is 'direct' or 'allreduce'")
+        self.exchange = exchange
+        self.slice_sum_fn = slice_sum_fn or _hip_slice_sum
+        self._xstream = None            # the private stream of the direct exchange (created on first use, CUDA only)
         self.use_hooks = use_hooks
         self.exec_ctx = exec_ctx
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -176,13 +202,41 @@ class Bf16GradSync:
         for g in grads:
             if g is None or g.dtype != torch.float32 or not g.is_contiguous():
                 raise RuntimeError("Bf16GradSync needs dense contiguous fp32 gradients")
-        self.pack_fn(grads, b.flat, b.offsets, 1.0 / self.world)
-        if self._DIAG == "noreduce":
-            b.work = False
+        if self.exchange == "direct" and self._DIAG != "noreduce":
+            self._launch_direct(b, grads)
         else:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pack_fn(grads, b.flat, b.offsets, 1.0 / self.world)
+            if self._DIAG == "noreduce":
+                b.work = False
+            else:
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.stats["collectives_last_step"] += 1
         self.stats["bytes_last_step"] += b.numel * 2
+
+    def _launch_direct(self, b: _Bucket, grads):
+        """pack -> all-to-all (slice r of every peer's bucket comes to rank r, all links at once) -> fp32 sum of the W slices ->
+        all-gather of the reduced slices, all on the private exchange stream: nothing here makes the compute stream or the host
+        wait (a collective issued inside `torch.cuda.stream(xs)` orders RCCL's stream behind xs and xs behind the collective)."""
+        def chain():
+            self.pack_fn(grads, b.flat, b.offsets, 1.0 / self.world)
+            dist.all_to_all_single(b.recv, b.flat, group=self.group)
+            self.slice_sum_fn(b.recv, self.world, b.slice, b.red)
+            dist.all_gather_into_tensor(b.flat, b.red, group=self.group)
+        if self.device.type != "cuda":
+            chain()
+            b.work = False
+            return
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream()
+        xs, cur = self._xstream, torch.cuda.current_stream()
+        xs.wait_stream(cur)              # `cur` has just been ordered behind every stream gradients are produced on
+        for g in grads:
+            g.record_stream(xs)
+        with torch.cuda.stream(xs):
+            chain()
+            done = torch.cuda.Event()
+            done.record(xs)
+        b.work = done
 
     def poll(self):
         """Hook-free mode: launch every not-yet-launched bucket (in order) whose parameters all have their gradient."""
@@ -222,7 +276,7 @@ class Bf16GradSync:
             cur_n += p.numel()
         if cur:
             buckets.append(cur)
-        self._buckets = [_Bucket(ps, self.device) for ps in buckets]
+        self._buckets = [_Bucket(ps, self.device, self.world, self.exchange == "direct") for ps in buckets]
         self._bucket_of = {self._index[id(p)]: b for b in self._buckets for p in b.params}
         self.stats["buckets"] = len(self._buckets)
 
@@ -253,7 +307,9 @@ class Bf16GradSync:
             if b.work is None:
                 raise RuntimeError("Bf16GradSync.finish(): a bucket was never launched -- some parameter received no "
                                    "gradient in this backward")
-            if b.work is not False:
+            if isinstance(b.work, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(b.work)      # direct exchange: the chain's last event
+            elif b.work is not False:
                 b.work.wait()
             if self._DIAG != "hooks":
                 self.unpack_fn([p.grad for p in b.params], b.flat, b.offsets)

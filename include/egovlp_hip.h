@@ -240,6 +240,11 @@ int egv_grad_pack_bf16(int32_t count, const float* const* grads, const int64_t* 
                        const int64_t* offsets, float scale, void* stream);
 int egv_grad_unpack_bf16(int32_t count, float* const* grads, const int64_t* numel, const egv_bf16* flat,
                          const int64_t* offsets, void* stream);
+/* The local reduction of the DIRECT gradient exchange (all-to-all of bucket slices over all xGMI links, then all-gather; SURVEY
+ * 5 / 8(e): xGMI is point to point, a ring keeps 5 of the 7 links idle): recv holds `world` slices of slice_elems bf16 each (this
+ * rank's slice of every peer's bucket); out[i] = bf16(sum_p float(recv[p][i])) -- fp32 accumulation, ONE rounding.
+ * slice_elems % 8 == 0, 16-byte aligned pointers, world <= 64.                                                            */
+int egv_slice_sum_bf16(const egv_bf16* recv, int32_t world, int64_t slice_elems, egv_bf16* out, void* stream);
 
 /* ---- optimizer ----------------------------------------------------------------------------------------
  * transformers==4.2.1 AdamW (run/train_egoclip.py:73, configs/pt/egoclip.json:49-54) over a list of

@@ -31,17 +31,19 @@ def _run(cmd, env):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("exchange", ["bf16sync", "ddp"])
+@pytest.mark.parametrize("exchange", ["bf16sync", "bf16sync-allreduce", "ddp"])
 def test_bench_under_rccl_world1_matches_single_process(exchange):
     common = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-fast-mode",
               "--no-kernel-timing", "--precision", "bf16x3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     plain = _run([sys.executable] + common, env)
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                 "--master-port", str(_free_port())] + common + ["--force-dist"] + (["--ddp"] if exchange == "ddp" else []), env)
+                 "--master-port", str(_free_port())] + common + ["--force-dist"] + (["--ddp"] if exchange == "ddp" else []) +
+                (["--grad-exchange", "allreduce"] if exchange == "bf16sync-allreduce" else []), env)
     assert dist["n_gpus"] == 1 and dist["config"]["parallelism"] == "dp1"
     assert dist["comm"]["rccl_ranks"] == 1 and dist["comm"]["backend"] == "nccl"
-    if exchange == "bf16sync":
+    if exchange.startswith("bf16sync"):
+        assert ("direct" in dist["comm"]["gradient_exchange"]) == (exchange == "bf16sync")
         assert dist["comm"]["grad_sync"]["buckets"] >= 5            # 180.9 M parameters in 64 MB bf16 buckets
         # the hook-free exchange overlaps: all buckets but the tail leave from the polls inside backward (round-2 advisor
         # finding: with a wrong gradient_ready_order every bucket left from finish(), fully exposed)

@@ -23,7 +23,11 @@ def _unpack(grads, flat, offsets):
         g.copy_(flat[o:o + g.numel()].float().view_as(g))
 
 
-def _worker(rank, world, port, out, use_hooks=True):
+def _slice_sum(recv, world, slice_elems, out):
+    out.copy_(recv.view(world, slice_elems).float().sum(0).to(torch.bfloat16))       # fp32 accumulation, one rounding
+
+
+def _worker(rank, world, port, out, use_hooks=True, exchange="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -31,12 +35,14 @@ def _worker(rank, world, port, out, use_hooks=True):
     torch.manual_seed(100 + rank)                     # different initial weights per rank: the broadcast must fix that
     net = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.ReLU(), torch.nn.Linear(40, 33), torch.nn.Linear(33, 7))
     if use_hooks:
-        sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack)     # ~2 k elements per bucket
+        sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack, exchange=exchange,
+                            slice_sum_fn=_slice_sum)     # ~2 k elements per bucket
     else:
         # hook-free mode: buckets cut along the given ready order (last layer first); poll() is called when the gradient of the
         # FIRST layer's weight is being produced -- the gradients of the later layers are final by then -- and again by finish()
         order = [p for p in net.parameters()][::-1]
-        sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack, use_hooks=False, order_hint=order)
+        sync = Bf16GradSync(net.parameters(), bucket_mb=0.004, pack_fn=_pack, unpack_fn=_unpack, use_hooks=False, order_hint=order,
+                            exchange=exchange, slice_sum_fn=_slice_sum)
         polled = []
 
         def _poll(g):
@@ -71,21 +77,31 @@ def _worker(rank, world, port, out, use_hooks=True):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("use_hooks", [True, False])
-def test_bf16_grad_sync_two_ranks(tmp_path, use_hooks):
-    world, port = 2, 29641 + (0 if use_hooks else 1)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), use_hooks), nprocs=world, join=True)
+@pytest.mark.parametrize("use_hooks,exchange,world", [(True, "allreduce", 2), (False, "allreduce", 2), (True, "direct", 2),
+                                                      (False, "direct", 2), (False, "direct", 3)])
+def test_bf16_grad_sync_ranks(tmp_path, use_hooks, exchange, world):
+    """Both exchanges (RCCL-style all-reduce of the bf16 bucket; the direct all-to-all -> fp32 slice sum -> all-gather), hook and
+    hook-free launch, two ranks -- and three for the direct exchange (bucket length padded to 3 equal 16-byte-aligned slices)."""
+    port = 29641 + (0 if use_hooks else 1) + (2 if exchange == "direct" else 0) + 4 * (world - 2)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), use_hooks, exchange), nprocs=world, join=True)
     r = [torch.load(os.path.join(str(tmp_path), f"rank{i}.pt"), weights_only=False) for i in range(world)]
-    for a, b in zip(r[0]["w0"], r[1]["w0"]):
-        assert torch.equal(a, b)                      # rank 0's initial weights everywhere
+    for other in r[1:]:
+        for a, b in zip(r[0]["w0"], other["w0"]):
+            assert torch.equal(a, b)                  # rank 0's initial weights everywhere
     for step in range(3):
-        g0, G0, st0 = r[0]["results"][step]
-        g1, G1, st1 = r[1]["results"][step]
+        gs = [r[k]["results"][step][0] for k in range(world)]
+        Gs = [r[k]["results"][step][1] for k in range(world)]
+        st0 = r[0]["results"][step][2]
         assert st0["buckets"] >= 2 and st0["collectives_last_step"] == st0["buckets"]
-        for i in range(len(g0)):
-            assert torch.equal(g0[i], g1[i])          # every rank ends with the same gradient
-            if step < 2:
-                assert torch.equal(g0[i], (G0[i] + G1[i]) / world), (step, i)        # (1/W) * sum, bit for bit
+        for i in range(len(gs[0])):
+            for k in range(1, world):
+                assert torch.equal(gs[0][i], gs[k][i])          # every rank ends with the same gradient
+            if step < 2 and world == 2:
+                assert torch.equal(gs[0][i], (Gs[0][i] + Gs[1][i]) / world), (step, i)        # (1/W) * sum, bit for bit
+            elif exchange == "direct":
+                # fp32 accumulation of the pre-scaled bf16 values, ONE rounding at the end
+                want = sum((G[i] / world).to(torch.bfloat16).float() for G in Gs).to(torch.bfloat16).float()
+                assert torch.equal(gs[0][i], want), (step, i)
             else:
-                want = ((G0[i] / world).to(torch.bfloat16) + (G1[i] / world).to(torch.bfloat16)).float()
-                assert torch.equal(g0[i], want), (step, i)
+                want = ((Gs[0][i] / world).to(torch.bfloat16) + (Gs[1][i] / world).to(torch.bfloat16)).float()
+                assert torch.equal(gs[0][i], want), (step, i)
