@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--main-priority", type=int, default=int(os.environ.get("EGV_MAIN_PRIO", "0")),
                     help="1: run the step on a HIGH-priority HIP stream (the wgrad / text side streams keep the default priority: "
                          "their workgroups fill the CUs the main stream's kernels leave free instead of competing with them)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("EGV_GRAPH_STEP", "0")),
+                    help="1: the whole step (forward, loss, backward, AdamW; all three streams) is captured into a HIP graph once and "
+                         "replayed (egovlp_amd.graph.GraphedTrainStep; single GPU): one launch per step instead of ~840")
     ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("EGV_ADAMW_OVERLAP", "0")),
                     help="1: AdamW updates enqueued from grad-ready hooks on a side stream under the rest of backward "
                          "(single GPU only; bit-identical results)")
@@ -362,13 +365,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphed = {}
+
+    def one_step():
+        if args.graph and world == 1 and not use_dist and ec.kernel_timer is None:
+            from egovlp_amd.graph import GraphedTrainStep
+            key = ec.precision_name()
+            if key not in graphed:          # one graph per precision mode (the secondary fast-mode leg re-captures)
+                for g_ in graphed.values():
+                    g_.disable()
+                graphed.clear()
+                graphed[key] = GraphedTrainStep(model, loss_fn, opt)
+            return graphed[key](data)
+        return egoclip_step(net, loss_fn, opt, data, world, rank, grad_sync=grad_sync)
+
     def measure(steps, warmup):
-        for _ in range(warmup):
-            egoclip_step(net, loss_fn, opt, data, world, rank, grad_sync=grad_sync)
+        for _ in range(max(warmup, 3) if args.graph else warmup):     # graphed: 2 eager steps + the capture before the clock starts
+            one_step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss = egoclip_step(net, loss_fn, opt, data, world, rank, grad_sync=grad_sync)
+            loss = one_step()
         HOST["enqueue_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3     # when the host was done enqueueing
         barrier()
         dt = time.perf_counter() - t0
@@ -382,6 +399,9 @@ def main():
         hp.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(hp)          # everything below (timed steps, instrumented passes) runs on the high-priority stream
     dt, loss_val = measure(args.steps, args.warmup)
+    for g_ in graphed.values():           # the instrumented legs below run eagerly
+        g_.disable()
+    graphed.clear()
     ms = dt / args.steps * 1e3
     pairs = world * B * args.steps / dt
 
@@ -451,7 +471,8 @@ def main():
                    "text_dropout": args.text_dropout,
                    "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
                                "adamw_overlapped_with_backward": bool(args.adamw_overlap and grad_sync is None and not args.ddp),
-                               "main_stream_high_priority": bool(args.main_priority)}},
+                               "main_stream_high_priority": bool(args.main_priority),
+                               "step_replayed_from_hip_graph": bool(args.graph and world == 1 and not use_dist)}},
         "loss": round(loss_val, 5),
         "host_enqueue_ms_per_step": round(HOST.get("enqueue_ms_per_step", 0.0), 3),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
@@ -501,6 +522,9 @@ def main():
         # outside the parity bar, reported for reference only -- `value` above is the parity-mode number)
         set_precision("bf16")
         dt2, loss2 = measure(args.steps, max(args.warmup, 2))
+        for g_ in graphed.values():
+            g_.disable()
+        graphed.clear()
         out["fast_mode_bf16"] = {"value": round(world * B * args.steps / dt2, 2), "unit": "clip-pairs/s",
                                  "ms_per_step": round(dt2 / args.steps * 1e3, 3), "loss": round(loss2, 5),
                                  "step_mfma_frac": None if key not in FWD_GFLOP_PER_PAIR else round(

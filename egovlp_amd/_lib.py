@@ -62,10 +62,10 @@ PROTOTYPES = {
     "egv_divided_attn_bwd_work_floats": (i64, [i32, i32, i32, i32]),
     "egv_embed_fwd": (i32, [c_p, c_p, c_p, i32, i32, i32, c_p, c_p]),
     "egv_embed_bwd": (i32, [c_p, c_p, i32, i32, i32, i64, c_p, c_p, c_p]),
-    "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, i64, c_p, i32, i32, i32, i32, f32, u64, c_p, c_p, c_p, c_p]),
-    "egv_text_attn_bwd": (i32, [c_p, c_p, c_p, i64, c_p, c_p, c_p, i32, i32, i32, i32, f32, u64, c_p, c_p, c_p, i64, c_p, c_p]),
+    "egv_text_attn_fwd": (i32, [c_p, c_p, c_p, i64, c_p, i32, i32, i32, i32, f32, u64, c_p, c_p, c_p, c_p, c_p]),
+    "egv_text_attn_bwd": (i32, [c_p, c_p, c_p, i64, c_p, c_p, c_p, i32, i32, i32, i32, f32, u64, c_p, c_p, c_p, c_p, i64, c_p, c_p]),
     "egv_zero": (i32, [c_p, i64, c_p]),
-    "egv_dropout": (i32, [c_p, c_p, c_p, i64, f32, u64, c_p]),
+    "egv_dropout": (i32, [c_p, c_p, c_p, i64, f32, u64, c_p, c_p]),
     "egv_egonce_fwd_bwd": (i32, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, f32, f32, i32, i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_egonce_work_floats": (i64, [i32, i32]),
     "egv_sim_matrix_fwd": (i32, [c_p, c_p, i32, i32, i32, f32, c_p, c_p, c_p, c_p, c_p]),
@@ -74,7 +74,7 @@ PROTOTYPES = {
     "egv_maxmargin_fwd_bwd": (i32, [c_p, c_p, i32, f32, i32, c_p, c_p, c_p]),
     "egv_dual_softmax": (i32, [c_p, i32, i32, f32, c_p, c_p, c_p]),
     "egv_cross_entropy_fwd_bwd": (i32, [c_p, i64, c_p, i32, i32, i64, c_p, c_p, i64, c_p]),
-    "egv_adamw_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, f32, f32, f32, f32, f32, i32, i32, f32, c_p]),
+    "egv_adamw_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, f32, f32, f32, f32, f32, i32, i32, f32, c_p, c_p]),
     "egv_grad_pack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, f32, c_p]),
     "egv_grad_unpack_bf16": (i32, [i32, c_p, c_p, c_p, c_p, c_p]),
     "egv_slice_sum_bf16": (i32, [c_p, i32, i64, c_p, c_p]),

@@ -25,7 +25,13 @@ struct AdamTable {
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t, float lr, float b1, float b2, float eps, float wd,
-                                                    float step_size, float grad_scale) {
+                                                    float step_size, float grad_scale, const float* __restrict__ hyper) {
+  // hyper (optional, device): {lr, step_size} of THIS step -- a step replayed from a HIP graph keeps its launch arguments, so
+  // whatever changes from step to step (bias correction, learning-rate schedule) is read from memory the host updates
+  if (hyper) {
+    lr = hyper[0];
+    step_size = hyper[1];
+  }
   int ti = 0;
   while (ti + 1 < t.count && (int)blockIdx.x >= t.blk_start[ti + 1]) ++ti;   // <= 47 scalar compares
   const long base = (long)((int)blockIdx.x - t.blk_start[ti]) * CHUNK;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamTable t, float lr,
 extern "C" int egv_adamw_multi(int32_t count, float* const* p, const float* const* g, float* const* m, float* const* v,
                                egv_bf16* const* w_hi, egv_bf16* const* w_lo, const int64_t* numel, float lr,
                                float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                               int32_t correct_bias, float grad_scale, void* stream) {
+                               int32_t correct_bias, float grad_scale, const float* hyper_dev, void* stream) {
   if (count < 0 || !p || !g || !m || !v || !numel || step < 1) return EGV_ERR_ARG;
   float step_size = lr;
   if (correct_bias) {
@@ -100,7 +106,7 @@ extern "C" int egv_adamw_multi(int32_t count, float* const* p, const float* cons
     t.blk_start[nt] = nb;
     t.count = nt;
     EGV_LAUNCH(adamw_kernel, dim3(nb), dim3(256), 0, s, t, lr, beta1, beta2, eps, weight_decay, step_size,
-                       grad_scale);
+                       grad_scale, hyper_dev);
     EGV_CHECK_LAUNCH();
     nt = 0;
     nb = 0;

@@ -125,8 +125,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const
         // O = (P o M') V: d = dO . V is the gradient w.r.t. the DROPPED weights; dP = d o M' (the mask of the forward,
         // regenerated), and delta = sum_k P dP = rowsum(dO o O) as without dropout
         const uint64_t rowbase = (((uint64_t)grp.b * g.H + grp.h) * g.S + (uint64_t)min(qi, g.nq - 1)) * g.S;
+        const EgvDrop dr = egv_drop_resolve(g.drop);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[r] *= egv_drop_scale(g.drop, rowbase + kf * 16 + 4 * gq + r);
+        for (int r = 0; r < 4; ++r) d[r] *= egv_drop_scale(dr, rowbase + kf * 16 + 4 * gq + r);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttGeom g, cons
           if (excl_cls && r0 + 4 * gq + r == g.nq) pr = 0.f;
           float mk = 1.0f;      // dropout mask of the forward for (query r0 + 4 gq + r, key kj), DistilBERT only
           if (MODE == MODE_TEXT && g.drop.thresh != 0u)
-            mk = egv_drop_scale(g.drop, (((uint64_t)grp.b * g.H + grp.h) * g.S + (uint64_t)min(r0 + 4 * gq + r, g.nq - 1)) * g.S + kc);
+            mk = egv_drop_scale(egv_drop_resolve(g.drop), (((uint64_t)grp.b * g.H + grp.h) * g.S + (uint64_t)min(r0 + 4 * gq + r, g.nq - 1)) * g.S + kc);
           pv[4 * t + r] = pr * mk;                      // dV = (P o M')^T dO
           dsv[4 * t + r] = pr * (d[r] * mk - D4[r]);    // dS = P o (dP - delta), dP = (dO . V) o M'
         }
@@ -545,8 +546,8 @@ int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf
 
 extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
                                  const float* d_out, const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
-                                 float dropout_p, uint64_t seed, float* dq, float* dk, float* dv, int64_t lddqkv,
-                                 float* delta_work, void* stream) {
+                                 float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* dq, float* dk, float* dv,
+                                 int64_t lddqkv, float* delta_work, void* stream) {
   if (!q || !k || !v || !mask || !d_out || !lse || !dq || !dk || !dv || !delta_work) return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   AttGeom g;
@@ -559,7 +560,7 @@ extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v,
   g.mask = (const long long*)mask;
   if (ldqkv < HD || lddqkv < HD || ldqkv % 4 != 0 || lddqkv % 4 != 0) return EGV_ERR_ARG;
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return EGV_ERR_ARG;
-  g.drop = egv_make_drop(dropout_p, seed);      // the (p, seed) of the matching egv_text_attn_fwd call
+  g.drop = egv_make_drop(dropout_p, seed, seed_dev);      // the (p, seed, device seed words) of the matching egv_text_attn_fwd call
   AttGrad gr;
   gr.dq = dq; gr.dk = dk; gr.dv = dv;
   gr.gh = gr.gl = nullptr;

@@ -112,10 +112,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
       // dropout on the attention weights (HF eager attention: softmax -> dropout -> . V): the survivors of P are scaled by
       // 1 / (1 - p); the normaliser l is the softmax's and does not change
       const uint64_t rowbase = (((uint64_t)grp.b * g.H + grp.h) * g.S + (uint64_t)min(qi, g.nq - 1)) * g.S;
+      const EgvDrop dr = egv_drop_resolve(g.drop);
 #pragma unroll
       for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[kf][r] *= egv_drop_scale(g.drop, rowbase + kf * 16 + 4 * gq + r);
+        for (int r = 0; r < 4; ++r) s[kf][r] *= egv_drop_scale(dr, rowbase + kf * 16 + 4 * gq + r);
     }
 
     f32x4_t o[4];
@@ -346,7 +347,7 @@ int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, i
 
 extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
                                  int32_t B, int32_t L, int32_t H, int32_t passes, float dropout_p, uint64_t seed,
-                                 egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream) {
+                                 const uint64_t* seed_dev, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream) {
   if (!q || !k || !v || !out_hi || B <= 0 || L <= 0 || H <= 0) return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   if (passes == 3 && !out_lo) return EGV_ERR_ARG;
@@ -360,6 +361,6 @@ extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v,
   g.mask = (const long long*)mask;
   if (!mask || ldqkv < HD || ldqkv % 4 != 0) return EGV_ERR_ARG;
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return EGV_ERR_ARG;
-  g.drop = egv_make_drop(dropout_p, seed);
+  g.drop = egv_make_drop(dropout_p, seed, seed_dev);
   return dispatch_fwd<MODE_TEXT>(g, B * H, passes, out_hi, out_lo, HD, lse, nullptr, (hipStream_t)stream);
 }

@@ -138,14 +138,25 @@ __device__ __forceinline__ uint32_t egv_mix32(uint32_t x) {
 struct EgvDrop {
   uint32_t s0, s1, thresh;   // seed words; keep <=> hash >= thresh (thresh = p * 2^32)
   float scale;               // 1 / (1 - p); 0 threshold and scale 1 when p == 0
+  const uint32_t* dev;       // optional DEVICE seed words {lo, hi}, XOR-ed into (s0, s1) by the kernel: a step captured into a
+                             // HIP graph keeps its host-side seed as a launch argument forever, so what changes from replay to
+                             // replay has to live in memory the graph reads (egovlp_amd/graph.py GraphedTrainStep)
 };
+__device__ __forceinline__ EgvDrop egv_drop_resolve(EgvDrop d) {   // once per kernel, before the first egv_drop_scale
+  if (d.dev) {
+    d.s0 ^= d.dev[0];
+    d.s1 ^= d.dev[1];
+  }
+  return d;
+}
 __device__ __forceinline__ float egv_drop_scale(const EgvDrop& d, uint64_t idx) {
   const uint32_t h = egv_mix32(egv_mix32((uint32_t)idx ^ d.s0) ^ (uint32_t)(idx >> 32) ^ d.s1);
   return h >= d.thresh ? d.scale : 0.0f;
 }
-static inline EgvDrop egv_make_drop(float p, uint64_t seed) {
+static inline EgvDrop egv_make_drop(float p, uint64_t seed, const uint64_t* seed_dev = nullptr) {
   EgvDrop d;
   d.s0 = (uint32_t)seed; d.s1 = (uint32_t)(seed >> 32);
+  d.dev = (const uint32_t*)seed_dev;
   if (!(p > 0.f)) { d.thresh = 0u; d.scale = 1.0f; return d; }
   const double t = (double)p * 4294967296.0;
   d.thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;

@@ -495,7 +495,8 @@ extern "C" int egv_version(void) { return 1; }
 // call with x = dy is the backward (the mask is regenerated from (p, seed)); `add` fuses the residual of `LN(ffn(x) + x)`.
 namespace {
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ add,
-                                                      float* __restrict__ out, long n, EgvDrop d) {
+                                                      float* __restrict__ out, long n, EgvDrop d0) {
+  const EgvDrop d = egv_drop_resolve(d0);
   const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 + 3 < n) {
     f32x4_t v = *(const f32x4_t*)(x + i4);
@@ -509,11 +510,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 }
 }  // namespace
 
-extern "C" int egv_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int egv_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed,
+                           const uint64_t* seed_dev, void* stream) {
   if (!x || !out || n <= 0 || !(p >= 0.f && p < 1.f)) return EGV_ERR_ARG;
   if ((((size_t)x) | ((size_t)out) | ((size_t)add)) & 15) return EGV_ERR_ARG;
   const long blocks = (n / 4 + 256) / 256;
-  EGV_LAUNCH(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, add, out, (long)n, egv_make_drop(p, seed));
+  EGV_LAUNCH(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, add, out, (long)n, egv_make_drop(p, seed, seed_dev));
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

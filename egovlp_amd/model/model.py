@@ -198,16 +198,15 @@ class FrozenInTime(BaseModel):
         self.device = device
 
     def forward(self, data, video_only=False, return_embeds=True):
-        if video_only:
-            return self.compute_video(data['video'])
         ec = self.exec_ctx
         ec.begin_step()
+        if video_only:
+            return self.compute_video(data['video'])
         if ec.text_side_stream and data['video'].is_cuda:
             # the two towers are independent until the loss: DistilBERT (M = B*L = 1024 token rows, latency-bound launches
             # that fill a fraction of the chip) runs on a second HIP stream under the video tower.  autograd replays each
             # tower's backward on the stream its forward ran on and orders them against the loss by itself.
-            ec.wc.refresh()
-            main, side = torch.cuda.current_stream(), ec.text_stream()
+            main, side = torch.cuda.current_stream(), ec.text_stream()      # (begin_step refreshed the weight planes on `main`)
             ec._text["main"] = main
             for t in data['text'].values():
                 t.record_stream(side)

@@ -49,7 +49,7 @@ class _EmbedFn(torch.autograd.Function):
         e = ops.embed_fwd(ids.contiguous(), word, pos, D)
         _, y, mean, rstd, _ = ops.layernorm_fwd(e, ln_w, ln_b, eps, 1, want_f32=True, want_planes=False)
         if drop[0] > 0:
-            y = ops.dropout(y, drop[0], drop[1])
+            y = ops.dropout(y, drop[0], drop[1], seed_dev=drop[2])
         ctx.save_for_backward(ids, e, ln_w, mean, rstd)
         ctx.shapes = (word.shape, pos.shape, pad_id)
         ctx.drop = drop
@@ -61,7 +61,7 @@ class _EmbedFn(torch.autograd.Function):
         D = e.shape[1]
         dy = dy.contiguous().view(-1, D)
         if ctx.drop[0] > 0:
-            dy = ops.dropout(dy, ctx.drop[0], ctx.drop[1])
+            dy = ops.dropout(dy, ctx.drop[0], ctx.drop[1], seed_dev=ctx.drop[2])
         de, dg, db = ops.layernorm_bwd(dy, e, ln_w, mean, rstd)
         d_word, d_pos = ops.embed_bwd(ids.contiguous(), de, ctx.shapes[0], ctx.shapes[1], ctx.shapes[2])
         return None, d_word, d_pos, dg, db, None, None, None
@@ -73,7 +73,7 @@ class _TextLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask, geom, ec: ExecContext,
                 q_w, q_b, k_w, k_b, v_w, v_b, o_w, o_b, ln1_w, ln1_b, f1_w, f1_b, f2_w, f2_b, ln2_w, ln2_b):
-        B, L, H, eps, drop = geom          # drop = (attention p, attention seed, ffn p, ffn seed); p = 0 outside train()
+        B, L, H, eps, drop = geom          # drop = (attention p, attention seed, ffn p, ffn seed, device seed words | None); p = 0 outside train()
         D = x.shape[-1]
         M = B * L
         P = ec.fwd_passes
@@ -91,7 +91,7 @@ class _TextLayerFn(torch.autograd.Function):
         ops.gemm_nt(x_pl, wc.get_cat((q_w, k_w, v_w), need_t=False)[0], passes=P, bias=wc.get_bias_cat((q_b, k_b, v_b)),
                     out_f32=qkv, ec=ec)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
-        c_pl, lse = ops.text_attn_fwd(q, k, v, mask, B, L, H, P, drop[0], drop[1])
+        c_pl, lse = ops.text_attn_fwd(q, k, v, mask, B, L, H, P, drop[0], drop[1], seed_dev=drop[4])
         s1 = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(c_pl, W(o_w), passes=P, bias=o_b, residual=x2, out_f32=s1, ec=ec)
         sa_pl, sa, mean1, rstd1, _ = ops.layernorm_fwd(s1, ln1_w, ln1_b, eps, P, want_f32=True)
@@ -102,7 +102,7 @@ class _TextLayerFn(torch.autograd.Function):
         s2 = torch.empty((M, D), dtype=torch.float32, device=dev)
         if drop[2] > 0:        # FFN.forward: dropout(lin2(gelu(lin1(x)))), then the block's residual: s2 = drop(y) + sa
             ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, out_f32=s2, ec=ec)
-            s2 = ops.dropout(s2, drop[2], drop[3], add=sa)
+            s2 = ops.dropout(s2, drop[2], drop[3], add=sa, seed_dev=drop[4])
         else:
             ops.gemm_nt(h, W(f2_w), passes=P, bias=f2_b, residual=sa, out_f32=s2, ec=ec)
         _, out, mean2, rstd2, _ = ops.layernorm_fwd(s2, ln2_w, ln2_b, eps, P, want_f32=True, want_planes=False)
@@ -132,7 +132,7 @@ class _TextLayerFn(torch.autograd.Function):
 
         d_s2, d_ln2w, d_ln2b = ops.layernorm_bwd(G, s2, ln2_w, mean2, rstd2)
         # FFN (d_s2 reaches lin2 through the dropout mask of the forward; the residual branch takes it as it is)
-        g_pl = ops.split_f32(ops.dropout(d_s2, drop[2], drop[3]) if drop[2] > 0 else d_s2, Pb)[0]
+        g_pl = ops.split_f32(ops.dropout(d_s2, drop[2], drop[3], seed_dev=drop[4]) if drop[2] > 0 else d_s2, Pb)[0]
         Hd = f1_w.shape[0]
         dZ = ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(g_pl, Wt(f2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D, ec=ec)
@@ -146,7 +146,7 @@ class _TextLayerFn(torch.autograd.Function):
         D3 = 3 * D
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         _, _, _, dqkv = ops.text_attn_bwd(q, k, v, mask, d_ctx, lse, B, L, H, Pb, fused_out=True, dropout_p=drop[0],
-                                          seed=drop[1])
+                                          seed=drop[1], seed_dev=drop[4])
         # fused q/k/v projection backward: one wgrad (dW [2304, 768] + bias grads) and one dgrad chained onto d_s1
         dqkv_pl = ops.split_f32(dqkv, Pb)[0]
         _, dW3, db3 = _lin_bwd(dqkv_pl, x_pl, None, Pb, need_dx=False, params=(q_w, k_w, v_w), ec=ec)
@@ -192,7 +192,7 @@ class TransformerBlock(nn.Module):
         self.ffn = FFN(config)
         self.output_layer_norm = nn.LayerNorm(config.dim, eps=1e-12)
 
-    def forward(self, x, mask, ec, drop=(0.0, 0, 0.0, 0)):
+    def forward(self, x, mask, ec, drop=(0.0, 0, 0.0, 0, None)):
         B, L, D = x.shape
         a, f = self.attention, self.ffn
         geom = (B, L, a.n_heads, self.sa_layer_norm.eps, drop)
@@ -222,6 +222,10 @@ class DistilBertModel(nn.Module):
         self.transformer = Transformer(self.config)
         self.exec_ctx = ops.new_context()     # FrozenInTime replaces it with the dual encoder's shared context
         self.seed_rank = 0                    # mixed into the dropout seeds: data-parallel ranks must not draw the same masks
+        # HIP-graph replay of the training step (egovlp_amd/graph.py): a device int64[1] whose value is XOR-ed into every
+        # dropout seed by the kernels, and the host-side call counter stops advancing -- what changes from replay to replay
+        # must live in device memory, launch arguments are frozen at capture
+        self.seed_device = None
         # HF init (initializer_range 0.02) so random-init statistics match `DistilBertModel(DistilBertConfig())`
         for m in self.modules():
             if isinstance(m, nn.Linear):
@@ -252,13 +256,14 @@ class DistilBertModel(nn.Module):
         e = self.embeddings
         pd = self.config.dropout if self.training else 0.0
         pa = self.config.attention_dropout if self.training else 0.0
-        if pd > 0 or pa > 0:
+        sdev = self.seed_device
+        if (pd > 0 or pa > 0) and sdev is None:
             self._drop_calls += 1
         x = _EmbedFn.apply(input_ids, e.word_embeddings.weight, e.position_embeddings.weight,
                            e.LayerNorm.weight, e.LayerNorm.bias, e.LayerNorm.eps,
                            -1 if e.word_embeddings.padding_idx is None else e.word_embeddings.padding_idx,
-                           (pd, self._seed(0)))
+                           (pd, self._seed(0), sdev))
         mask = attention_mask.to(torch.int64).contiguous()
         for li, blk in enumerate(self.transformer.layer):
-            x = blk(x, mask, self.exec_ctx, (pa, self._seed(1 + 2 * li), pd, self._seed(2 + 2 * li)))
+            x = blk(x, mask, self.exec_ctx, (pa, self._seed(1 + 2 * li), pd, self._seed(2 + 2 * li), sdev))
         return SimpleNamespace(last_hidden_state=x)

@@ -144,8 +144,10 @@ class ExecContext:
 
     def begin_step(self):
         """Start of a forward / backward pass: forget a join callback that never ran (a backward that raised leaves
-        'queued' set and later passes would not queue theirs)."""
+        'queued' set and later passes would not queue theirs), and validate / refresh the weight-plane cache once for the step."""
         self._side["queued"] = False
+        if self._wc is not None:
+            self._wc.begin_step()
 
     def join_side_stream(self):
         """Make the main stream (the one the side work was forked from) and the current stream wait for everything enqueued on
@@ -160,6 +162,8 @@ class ExecContext:
 
     def _join_callback(self):
         self._side["queued"] = False
+        if self._wc is not None:
+            self._wc.begin_step()
         self.join_side_stream()
 
     def join_streams_for_gradient_hook(self):
@@ -344,30 +348,24 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     K = a.cols if K is None else K
     if ksplit is None:
         ksplit = auto_ksplit_nt(M, N, K)
-    d = GemmDesc()
-    d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
-    d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
-    d.M, d.N, d.K, d.passes = M, N, K, passes
-    d.alpha, d.act = alpha, act
-    d.bias = _p(bias)
-    d.residual, d.ldr = _p(residual), (residual.stride(0) if residual is not None else 0)
     aux = aux_in if aux_in is not None else aux_out
-    d.aux_in, d.aux_out, d.ldaux = _p(aux_in), _p(aux_out), (aux.stride(0) if aux is not None else 0)
-    d.aux_bf16 = int(aux is not None and aux.dtype == torch.bfloat16)
+    aux_bf16 = int(aux is not None and aux.dtype == torch.bfloat16)
     if aux_is_grad:
-        if not d.aux_bf16:
+        if not aux_bf16:
             raise ValueError("aux_is_grad needs a bf16 aux buffer")
-        d.aux_bf16 = 2
-    d.out_f32, d.ldo = _p(out_f32), (out_f32.stride(0) if out_f32 is not None else 0)
-    if out_planes is not None:
-        d.out_hi, d.out_lo, d.ldoh = _p(out_planes.hi), _p(out_planes.lo), out_planes.ld
-    partial = None
-    if ksplit > 1:
-        partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device)
-    d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
-    d.trans, d.colsum, d.grid_cap = 0, None, ec.gemm_grid
-    if d.aux_bf16 and not uses_big_gemm(M, N, K):
+        aux_bf16 = 2
+    if aux_bf16 and not uses_big_gemm(M, N, K):
         raise ValueError("bf16 aux buffers are only supported by the big-tile GEMM kernel (see uses_big_gemm)")
+    partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device) if ksplit > 1 else None
+    # one positional construction (the field order of egv_gemm_desc): 30 attribute stores cost ~6 us of host time per GEMM,
+    # and the step issues 296 of them
+    d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, K, passes, alpha, act, _p(bias),
+                 _p(residual), (residual.stride(0) if residual is not None else 0),
+                 _p(aux_in), _p(aux_out), (aux.stride(0) if aux is not None else 0),
+                 _p(out_f32), (out_f32.stride(0) if out_f32 is not None else 0),
+                 _p(out_planes.hi) if out_planes is not None else None, _p(out_planes.lo) if out_planes is not None else None,
+                 out_planes.ld if out_planes is not None else 0,
+                 ksplit, 0, _p(partial), 0, aux_bf16, None, ec.gemm_grid, 0)
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * K,
@@ -425,16 +423,11 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         # then become the critical path (profiles/r02_ab_wgrad_ksplit.txt).
         div = _WGRAD_KSPLIT_DIV or (2 if ec.on_side_stream() else 1)
         ksplit = max(1, min(ec.gemm_grid // max(tiles, 1) // div, nkt // 2))
-    d = GemmDesc()
-    d.a_hi, d.a_lo, d.lda = _p(a.hi), _p(a.lo), a.ld
-    d.b_hi, d.b_lo, d.ldb = _p(b.hi), _p(b.lo), b.ld
-    d.M, d.N, d.K, d.passes = M, N, Kd, passes
-    d.alpha, d.act = 1.0, ACT_NONE
-    d.out_f32, d.ldo = _p(out_f32), out_f32.stride(0)
     cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
     partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
-    d.ksplit, d.accumulate, d.partial = ksplit, 0, _p(partial)
-    d.trans, d.colsum, d.aux_bf16, d.grid_cap = 1, _p(cs), 0, ec.gemm_grid
+    d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, Kd, passes, 1.0, ACT_NONE, None,
+                 None, 0, None, None, 0, _p(out_f32), out_f32.stride(0), None, None, 0,
+                 ksplit, 0, _p(partial), 1, 0, _p(cs), ec.gemm_grid, 0)
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * Kd,
@@ -641,18 +634,19 @@ def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, m
     return dqkv
 
 
-def text_attn_fwd(q, k, v, mask, B, L, H, passes, dropout_p=0.0, seed=0):
+def text_attn_fwd(q, k, v, mask, B, L, H, passes, dropout_p=0.0, seed=0, seed_dev=None):
     """q, k, v: fp32 [B*L, H*64] tensors, or column-block views of one fused [B*L, 3*H*64] projection output.
-    dropout_p > 0: attention-probability dropout with the counter-based mask of (dropout_p, seed)."""
+    dropout_p > 0: attention-probability dropout with the counter-based mask of (dropout_p, seed ^ *seed_dev); seed_dev: an
+    optional device int64[1] holding the per-step part of the seed (HIP-graph replay, egovlp_amd/graph.py)."""
     out = empty_planes(B * L, H * 64, passes, q.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     assert q.stride(0) == k.stride(0) == v.stride(0) and q.stride(1) == 1
     check(_lib.lib().egv_text_attn_fwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), B, L, H, passes, float(dropout_p),
-                                       int(seed), _p(out.hi), _p(out.lo), _p(lse), _stream(q)), "egv_text_attn_fwd")
+                                       int(seed), _p(seed_dev), _p(out.hi), _p(out.lo), _p(lse), _stream(q)), "egv_text_attn_fwd")
     return out, lse
 
 
-def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False, dropout_p=0.0, seed=0):
+def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False, dropout_p=0.0, seed=0, seed_dev=None):
     """-> (dq, dk, dv); with fused_out they are the column blocks of ONE [B*L, 3*H*64] tensor (returned 4th)."""
     HD = H * 64
     if fused_out:
@@ -663,17 +657,17 @@ def text_attn_bwd(q, k, v, mask, d_out, lse, B, L, H, passes, fused_out=False, d
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     work = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     check(_lib.lib().egv_text_attn_bwd(_p(q), _p(k), _p(v), q.stride(0), _p(mask), _p(d_out), _p(lse), B, L, H, passes,
-                                       float(dropout_p), int(seed), _p(dq), _p(dk), _p(dv), dq.stride(0), _p(work),
+                                       float(dropout_p), int(seed), _p(seed_dev), _p(dq), _p(dk), _p(dv), dq.stride(0), _p(work),
                                        _stream(q)), "egv_text_attn_bwd")
     return (dq, dk, dv, dqkv) if fused_out else (dq, dk, dv)
 
 
-def dropout(x, p, seed, add=None):
-    """out = x * M'(p, seed) + add (elementwise, contiguous fp32); with x = dy the same call is the backward."""
+def dropout(x, p, seed, add=None, seed_dev=None):
+    """out = x * M'(p, seed ^ *seed_dev) + add (elementwise, contiguous fp32); with x = dy the same call is the backward."""
     _need_cuda(x, add)
     x = x.contiguous()
     out = torch.empty_like(x)
-    check(_lib.lib().egv_dropout(_p(x), _p(add), _p(out), x.numel(), float(p), int(seed), _stream(x)), "egv_dropout")
+    check(_lib.lib().egv_dropout(_p(x), _p(add), _p(out), x.numel(), float(p), int(seed), _p(seed_dev), _stream(x)), "egv_dropout")
     return out
 
 
@@ -714,7 +708,7 @@ def egonce_fwd_bwd(text, video, noun, verb, temperature, eps=1e-8, use_noun=True
     return loss, sim, dt, dvv
 
 
-def adamw_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step, correct_bias=True, grad_scale=1.0):
+def adamw_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step, correct_bias=True, grad_scale=1.0, hyper_dev=None):
     n = len(params)
     arr = C.c_void_p * n
     P = arr(*[p.data_ptr() for p in params])
@@ -724,7 +718,7 @@ def adamw_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step
     N = (C.c_int64 * n)(*[p.numel() for p in params])
     check(_lib.lib().egv_adamw_multi(n, P, G, M_, V, None, None, N, float(lr), float(beta1), float(beta2),
                                      float(eps), float(weight_decay), int(step), int(correct_bias),
-                                     float(grad_scale), _stream(params[0])), "egv_adamw_multi")
+                                     float(grad_scale), _p(hyper_dev), _stream(params[0])), "egv_adamw_multi")
 
 
 # ---- module-level views of DEFAULT's settings (earlier rounds' names; scripts, tools and tests assign to them) -----------------

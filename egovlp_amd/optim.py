@@ -31,6 +31,7 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       correct_bias=correct_bias))
         self._ov = None     # state of overlap_backward()
+        self._graph_hyper = None
 
     # ------------------------------------------------------------------------------------------ overlap with backward
     def overlap_backward(self, min_elems=16 << 20, stream_of=None, exec_ctx=None):
@@ -164,10 +165,21 @@ class AdamW(torch.optim.Optimizer):
             ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
         self._launch(group, ps, gs, ms, vs, step, grad_scale)
 
-    @staticmethod
-    def _launch(group, ps, gs, ms, vs, step, grad_scale):
+    def _launch(self, group, ps, gs, ms, vs, step, grad_scale):
         if not ps:
             return
         b1, b2 = group["betas"]
+        # graph_hyper: per param group, device floats {lr, step_size} the host refreshes before every HIP-graph replay
+        # (egovlp_amd/graph.py GraphedTrainStep); None in eager mode
+        hyper = self._graph_hyper.get(id(group)) if self._graph_hyper else None
         ops.adamw_multi(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
-                        group["correct_bias"], grad_scale)
+                        group["correct_bias"], grad_scale, hyper_dev=hyper)
+
+
+def adamw_step_size(lr, beta1, beta2, step, correct_bias=True):
+    """The step-dependent scalar of transformers-4.2.1 AdamW: lr * sqrt(1 - beta2^t) / (1 - beta1^t) (double precision, as the
+    C entry point computes it)."""
+    if not correct_bias:
+        return float(lr)
+    import math
+    return float(lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step))

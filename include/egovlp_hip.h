@@ -172,21 +172,24 @@ int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, int32_t L, in
  * mask [B, L] int64 (0 = padded key -> -inf).  Output split planes [B, L, H*64]; probs are recomputed
  * in backward from lse [B,H,L].                                                                     */
 int egv_text_attn_fwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask, int32_t B,
-                      int32_t L, int32_t H, int32_t passes, float dropout_p, uint64_t seed, egv_bf16* out_hi,
-                      egv_bf16* out_lo, float* lse, void* stream);
+                      int32_t L, int32_t H, int32_t passes, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                      egv_bf16* out_hi, egv_bf16* out_lo, float* lse, void* stream);
 /* q, k, v (and dq, dk, dv) rows are ldqkv (lddqkv) floats apart: H*64 for separate tensors, 3*H*64 when they are the
  * three column blocks of one fused [B*L, 3*H*64] projection output (one GEMM instead of three).
  * dropout_p > 0: HF's attention dropout (softmax -> dropout -> . V, modeling_distilbert.py eager attention) with the
- * counter-based mask keep(seed, ((b*H + h)*L + query)*L + key); the backward regenerates it from the same (dropout_p, seed). */
+ * counter-based mask keep(seed, ((b*H + h)*L + query)*L + key); the backward regenerates it from the same (dropout_p, seed).
+ * seed_dev (optional, DEVICE, one uint64): XOR-ed into `seed` by the kernel when it runs -- the part of the seed that changes
+ * from replay to replay of a step captured into a HIP graph (launch arguments are frozen at capture).                      */
 int egv_text_attn_bwd(const float* q, const float* k, const float* v, int64_t ldqkv, const int64_t* mask,
                       const float* d_out, const float* lse, int32_t B, int32_t L, int32_t H, int32_t passes,
-                      float dropout_p, uint64_t seed, float* dq, float* dk, float* dv, int64_t lddqkv,
-                      float* delta_work /* B*H*L floats */, void* stream);
+                      float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* dq, float* dk, float* dv,
+                      int64_t lddqkv, float* delta_work /* B*H*L floats */, void* stream);
 /* Zero-fill (hipMemsetAsync on `stream`) of a buffer the caller has just allocated.                                    */
 int egv_zero(void* p, int64_t bytes, void* stream);
 /* Elementwise dropout of DistilBERT (embedding output, FFN output): out[i] = x[i] * M'(i) + (add ? add[i] : 0) with
  * M'(i) = keep(seed, i) ? 1 / (1 - p) : 0.  The same call with x = dy is its backward.  16-byte aligned pointers.      */
-int egv_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed, void* stream);
+int egv_dropout(const float* x, const float* add, float* out, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev,
+                void* stream);
 
 /* ---- contrastive head ---------------------------------------------------------------------------------
  * sim_matrix x3 + EgoNCE/NormSoftmaxLoss forward AND backward in one launch
@@ -249,11 +252,14 @@ int egv_slice_sum_bf16(const egv_bf16* recv, int32_t world, int64_t slice_elems,
 /* ---- optimizer ----------------------------------------------------------------------------------------
  * transformers==4.2.1 AdamW (run/train_egoclip.py:73, configs/pt/egoclip.json:49-54) over a list of
  * tensors given as HOST arrays of device pointers (copied into kernel arguments in chunks), fused with
- * the refresh of the split-bf16 weight planes the GEMMs read (w_hi/w_lo may be NULL per tensor).    */
+ * the refresh of the split-bf16 weight planes the GEMMs read (w_hi/w_lo may be NULL per tensor).
+ * hyper_dev (optional, DEVICE, 2 floats {lr, step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t)}): when given, the kernel reads
+ * the two step-dependent scalars from there instead of taking them from lr / step -- for a step replayed from a HIP graph,
+ * whose launch arguments are frozen at capture (the host refreshes the two floats before every replay).             */
 int egv_adamw_multi(int32_t count, float* const* p, const float* const* g, float* const* m, float* const* v,
                     egv_bf16* const* w_hi, egv_bf16* const* w_lo, const int64_t* numel,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                    int32_t correct_bias, float grad_scale, void* stream);
+                    int32_t correct_bias, float grad_scale, const float* hyper_dev, void* stream);
 
 /* ---- misc -----------------------------------------------------------------------------------------------
  * gather rows: out[r,:] = x[idx_stride * r * ld ...] helper for CLS-row extraction is done with strides in
