@@ -195,6 +195,7 @@ class TransformerBlock(nn.Module):
     def forward(self, x, mask, ec, drop=(0.0, 0, 0.0, 0, None)):
         B, L, D = x.shape
         a, f = self.attention, self.ffn
+        drop = tuple(drop) + (None,) * (5 - len(drop))       # (attention p, seed, ffn p, seed[, device seed word])
         geom = (B, L, a.n_heads, self.sa_layer_norm.eps, drop)
         return _TextLayerFn.apply(
             x, mask, geom, ec,
