@@ -386,8 +386,13 @@ __global__ __launch_bounds__(256) void attn_time_fwd8_kernel(const bf16_t* __res
 // first version unrolled everything, needed > 256 VGPRs (1 wave per SIMD) and ran at 229 us per call.
 // The CLS token's raw dq / dk / dv partials stay in registers across locations: one LDS reduction + one atomicAdd per
 // channel per workgroup.
-template <int TMAX, int HPW>
-__global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void attn_time_bwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
+// WPB = waves per workgroup.  A workgroup always covers 16 consecutive locations (one LDS reduction + one round of atomics for
+// the CLS token's partials per 16 locations); with WPB = 4 a wave walks four of them one after the other, with WPB = 16 every
+// wave has ONE location.  Each location is a dependent chain of ~T + 2 load round trips, so the kernel's time is (chains a
+// wave slot runs in sequence) x (chain latency): at B = 32 there are 18 816 chains for 4 096 wave slots -- 1.15 waves per slot
+// = two rounds of four chains with WPB = 4, 4.6 waves per slot = five rounds of one chain with WPB = 16.
+template <int TMAX, int HPW, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void attn_time_bwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
                                                                const bf16_t* __restrict__ doh,
                                                                const bf16_t* __restrict__ dol,
                                                                const float* __restrict__ lse,
@@ -395,7 +400,8 @@ __global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void at
                                                                int H, bf16_t* __restrict__ gh, bf16_t* __restrict__ gl,
                                                                float* __restrict__ dcls) {
   constexpr int LPH = 64 / HPW, CPL = HPW;
-  __shared__ float red[3][4][64 * CPL];
+  __shared__ float red[3][WPB][64 * CPL];
+  constexpr int LPW = 16 / WPB;              // locations per wave
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int HQ = H / HPW;
@@ -428,8 +434,8 @@ __global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void at
   for (int c = 0; c < CPL; ++c) dqc[c] = dkc[c] = dvc[c] = 0.f;
 
 #pragma unroll 1
-  for (int ii = 0; ii < 4; ++ii) {
-    const int i = ic * 16 + wave * 4 + ii;
+  for (int ii = 0; ii < LPW; ++ii) {
+    const int i = ic * 16 + wave * LPW + ii;
     if (i >= n) break;
     float k[TMAX][CPL], v[TMAX][CPL], dk[TMAX][CPL], dv[TMAX][CPL];
 #pragma unroll
@@ -518,9 +524,16 @@ __global__ __launch_bounds__(256, (TMAX <= 4) ? 4 : (TMAX <= 8 ? 3 : 2)) void at
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int x = lane * CPL + c;
-      atomicAdd(a + c, red[0][0][x] + red[0][1][x] + red[0][2][x] + red[0][3][x]);
-      atomicAdd(a + 64 + c, red[1][0][x] + red[1][1][x] + red[1][2][x] + red[1][3][x]);
-      atomicAdd(a + 128 + c, red[2][0][x] + red[2][1][x] + red[2][2][x] + red[2][3][x]);
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPB; ++w) {
+        r0 += red[0][w][x];
+        r1 += red[1][w][x];
+        r2 += red[2][w][x];
+      }
+      atomicAdd(a + c, r0);
+      atomicAdd(a + 64 + c, r1);
+      atomicAdd(a + 128 + c, r2);
     }
   }
 }
@@ -656,7 +669,16 @@ int launch_time_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const
   // stream, csrc/common.h EGV_NT_TIME_BWD): 128 -> 99 us per call at B=32 (profiles/r02_tb_time_attention_bwd.txt);
   // EGV_TIME_HPW=2 selects the 4-byte-lane kernel for A/B
   static const int want4 = getenv("EGV_TIME_HPW") ? atoi(getenv("EGV_TIME_HPW")) == 4 : 1;
-  if (H % 4 == 0 && TMAX <= 4 && want4) {
+  // default 8 waves x 2 locations (isolated, B = 32: 95 us at 4 x 4, 80-84 at 8 x 2, 87 at 16 x 1; profiles/r03_attention_time_bwd_ab.txt);
+  // EGV_TIME_BWD_WPB=4 / 16 select the other shapes for A/B
+  static const int wpb = getenv("EGV_TIME_BWD_WPB") ? atoi(getenv("EGV_TIME_BWD_WPB")) : 8;
+  if (H % 4 == 0 && TMAX <= 4 && want4 && wpb == 16) {
+    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4, 16>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(1024), 0, s, qh, ql, doh, dol,
+               lse, delta, B, T, n, H, gh, gl, dcls);
+  } else if (H % 4 == 0 && TMAX <= 4 && want4 && wpb == 8) {
+    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4, 8>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(512), 0, s, qh, ql, doh, dol,
+               lse, delta, B, T, n, H, gh, gl, dcls);
+  } else if (H % 4 == 0 && TMAX <= 4 && want4) {
     EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
                lse, delta, B, T, n, H, gh, gl, dcls);
   } else if (H % 2 == 0 && TMAX <= 8) {
