@@ -99,7 +99,10 @@ def grad_rel_err(model, loss_fn, data, world, rank, set_precision, mode):
 
     pd, pa = model.text_model.config.dropout, model.text_model.config.attention_dropout
     model.text_model.set_dropout(0.0, 0.0)          # two calls draw different masks: compare the deterministic function
+    poll = model.exec_ctx.backward_poll             # these backward passes are measurements, not steps: no gradient exchange
+    model.exec_ctx.set(backward_poll=None)
     ref, got = grads("bf16x3"), grads(mode)
+    model.exec_ctx.set(backward_poll=poll)
     model.text_model.set_dropout(pd, pa)
     set_precision(mode)
     for p_ in model.parameters():
