@@ -194,15 +194,18 @@ class Bf16GradSync:
         if self._DIAG == "hooks":
             b.work = False
             return
-        if self.pack_fn is _hip_pack:
+        direct = self.exchange == "direct" and self._DIAG != "noreduce"
+        if self.pack_fn is _hip_pack and not (direct and self.device.type == "cuda"):
             from . import ops
-            # gradients are produced on up to three streams (main, text tower, wgrad side stream) of the model's context
+            # gradients are produced on up to three streams (main, text tower, wgrad side stream) of the model's context: the
+            # all-reduce is issued behind the CURRENT stream, which therefore has to wait for the other two (the direct
+            # exchange orders its own private stream behind all three instead and leaves the compute streams alone)
             (self.exec_ctx or ops.DEFAULT).join_streams_for_gradient_hook()
         grads = [p.grad for p in b.params]
         for g in grads:
             if g is None or g.dtype != torch.float32 or not g.is_contiguous():
                 raise RuntimeError("Bf16GradSync needs dense contiguous fp32 gradients")
-        if self.exchange == "direct" and self._DIAG != "noreduce":
+        if direct:
             self._launch_direct(b, grads)
         else:
             self.pack_fn(grads, b.flat, b.offsets, 1.0 / self.world)
@@ -228,8 +231,12 @@ class Bf16GradSync:
             return
         if self._xstream is None:
             self._xstream = torch.cuda.Stream()
-        xs, cur = self._xstream, torch.cuda.current_stream()
-        xs.wait_stream(cur)              # `cur` has just been ordered behind every stream gradients are produced on
+        xs = self._xstream
+        if self.pack_fn is _hip_pack:
+            from . import ops
+            (self.exec_ctx or ops.DEFAULT).order_behind_gradient_streams(xs)      # xs waits; main / text / wgrad streams do not
+        else:
+            xs.wait_stream(torch.cuda.current_stream())
         for g in grads:
             g.record_stream(xs)
         with torch.cuda.stream(xs):

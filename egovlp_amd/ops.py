@@ -166,6 +166,16 @@ class ExecContext:
             self._wc.begin_step()
         self.join_side_stream()
 
+    def order_behind_gradient_streams(self, stream):
+        """Make `stream` (a private stream of the gradient exchange) wait for everything enqueued so far on the streams gradients
+        are produced on -- the current one, the wgrad side stream, the text tower's -- WITHOUT making any of those wait: the
+        exchange reads finished gradients, the backward pass that produces the next ones keeps running."""
+        stream.wait_stream(torch.cuda.current_stream())
+        if self._side["stream"] is not None:
+            stream.wait_stream(self._side["stream"])
+        if self._text["stream"] is not None:
+            stream.wait_stream(self._text["stream"])
+
     def join_streams_for_gradient_hook(self):
         """Gradient hooks run when a gradient has been ENQUEUED, on the stream of the node that produced it; a hook that reads
         gradients of several parameters (a bucket of the data-parallel exchange) must first order its stream behind the other
