@@ -178,8 +178,15 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
   }
 }
 
-template <int MF, bool TN, int EPI, bool F3>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg_arg) {
+// MIXED (F3, MF = 5 only): row bands of TWO heights in one launch.  The first nb5 bands are 320 rows, the rest 256: a 256-row tile
+// runs in the 320-row instance with the fifth 16-row fragment group of every wave switched off (its MFMAs are skipped under a
+// wave-uniform branch, its LDS rows simply stay unused), i.e. in 4/5 of the time.  Tile ids are dealt round by round (round r =
+// ids [r G, (r + 1) G), XCD remap inside a round), bands in id order, so every workgroup gets the tall tiles in its early rounds
+// and the short ones in its last: M = 25 120 x N = 2304 is 53 + 32 bands = 765 tiles = 5 + 5 + 4 units per workgroup where 79
+// bands of 320 rows are 711 tiles = 3 rounds of 5 (-6.7 %); N = 3072: 5 + 5 + 5 + 4 instead of 4 x 5 (-5 %).
+template <int MF, bool TN, int EPI, bool F3, bool MIXED = false>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg_arg, const int nb5_arg) {
+  static_assert(!MIXED || (F3 && MF == 5 && !TN), "mixed row bands: the fused three-product NT instance with 320-row tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef EGV_DIAG
   const int dbg = dbg_arg;      // `make diag` build only (tools/gemm_trace.py, tools/gemm_bench.py with EGV_GEMM_DBG)
@@ -222,7 +229,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   };
 
   const int tiles_n = (p.N + BNB - 1) / BNB;
-  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nb5 = MIXED ? nb5_arg : 0;
+  const int tiles_m = MIXED ? nb5 + (p.M - nb5 * 320 + 255) / 256 : (p.M + BM - 1) / BM;
   const int nwg = tiles_m * tiles_n;
   const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
   const int total = nwg * ksplit;
@@ -237,6 +245,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   // ---- DMA (global -> LDS) source offsets, in elements, relative to the tile origin of the current k-tile -----
   long a_voff, b_voff;
   unsigned nt_avo = 0, nt_bvo = 0, avo = 0, bvo = 0;
+  // MIXED: in a 256-row tile the loader wave w owns global rows w * 64 .. (LDS rows stay w * 80 ..): 16 rows less per wave index
+  const unsigned avo_adj4 = MIXED ? (unsigned)((wave & 3) * 16 * p.lda * 2) : 0u;
   int tn_col = 0;   // TN: this lane's source column (elements) before the per-piece unit XOR
   if (!TN) {
     const int chunk = (lane & 7) ^ (lane >> 3);                 // LDS position (lane&7) holds source chunk pos^(row&7)
@@ -370,7 +380,26 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   int m0, n0, z, tn, kt_begin, kt_end, nt;    // current tile
   int st_seg, st_kt;                          // next k-tile to be staged (of the tile being staged)
   int sm0, sn0, skt_begin, skt_end;           // origin / k-range of the tile being staged
-  auto decode = [&](int v, int& om0, int& on0, int& oz, int& otn, int& okb, int& oke) {
+  int mf = MF, smf = MF, nmf = MF;            // MIXED: 16-row fragment groups per wave of the current / staged / next tile (5 or 4)
+  auto decode = [&](int v, int& om0, int& on0, int& oz, int& otn, int& okb, int& oke, int& omf) {
+    omf = MF;
+    if constexpr (MIXED) {
+      // round-wise dealing (see the template comment): ksplit == 1 here
+      oz = 0;
+      const int G = (int)gridDim.x;
+      const int r = v / G;
+      const int left = nwg - r * G;
+      const int wg = r * G + xcd_remap(v - r * G, left < G ? left : G);
+      const int tm = wg / tiles_n;
+      otn = wg - tm * tiles_n;
+      const bool five = tm < nb5;
+      omf = five ? 5 : 4;
+      om0 = min(five ? tm * 320 : nb5 * 320 + (tm - nb5) * 256, p.M - omf * 64);
+      on0 = min(otn * BNB, p.N - BNB);
+      okb = 0;
+      oke = nkt_total;
+      return;
+    }
     oz = v / nwg;
     const int wg = xcd_remap(v - oz * nwg, nwg);
     const int tm = wg / tiles_n;
@@ -395,7 +424,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       if (isa) {
         const char* ab = (const char*)((pl ? p.a_lo : p.a_hi) + (long)sm0 * p.lda + (long)st_kt * KTD);
         if (i == i0 || j == 0) run = avo + (unsigned)(j * 32 * p.lda);
-        glds16(ab + (size_t)run, lds + pl * F3_ALO + (w * GA + j) * 1024);
+        // MIXED, 256-row tile: a wave's share is 64 rows (four pieces); the fifth would read past the band
+        if (!(MIXED && j == GA - 1 && smf == 4)) glds16(ab + (size_t)run, lds + pl * F3_ALO + (w * GA + j) * 1024);
         run += (unsigned)(32 * p.lda);
       } else {
         const char* bb = (const char*)((pl ? p.b_lo : p.b_hi) + (long)sn0 * p.ldb + (long)st_kt * KTD);
@@ -444,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   };
   auto stage = [&](int buf) {   // one k-tile of tile (sm0, sn0) -> LDS stage `buf`
     char* lds = smem + buf * STAGE;
-    avo = nt_avo; bvo = nt_bvo;
+    avo = nt_avo - ((MIXED && smf == 4) ? avo_adj4 : 0u); bvo = nt_bvo;
     if (loader) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) piece(lds, i, 0);
@@ -454,9 +484,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 
   int v = blockIdx.x;
   if (v >= total) return;
-  decode(v, m0, n0, z, tn, kt_begin, kt_end);
+  decode(v, m0, n0, z, tn, kt_begin, kt_end, mf);
   nt = max(kt_end - kt_begin, 0) * nseg;
-  sm0 = m0; sn0 = n0; skt_begin = kt_begin; skt_end = kt_end; st_seg = 0; st_kt = kt_begin;
+  sm0 = m0; sn0 = n0; skt_begin = kt_begin; skt_end = kt_end; st_seg = 0; st_kt = kt_begin; smf = mf;
   if (nt > 0) stage(0);
   if (!TN) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -494,11 +524,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       };
       auto rd_al = [&](unsigned ra) { static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; Al[i] = ld128_asm<i * 1024 + F3_ALO>(ra); }); };
       auto rd_ah = [&](auto Ic, unsigned ra) { constexpr int i = decltype(Ic)::value; Ah[i] = ld128_asm<i * 1024>(ra); };
+      const bool grp5 = !MIXED || mf == 5;          // wave-uniform: does this tile use the fifth fragment group?
       auto pass = [&](auto Jc, const bf16x8_t& b, bf16x8_t (&a)[MF]) {
         constexpr int j = decltype(Jc)::value;
         static_for<0, MF>([&](auto Ic) {
           constexpr int i = decltype(Ic)::value;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0);
+          if (MIXED && i == MF - 1) {
+            if (grp5) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0);
+          }
         });
       };
       auto k_tile3 = [&](const int t) {
@@ -506,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         const int sb = (t & 1) * STAGE;
         const unsigned ra = fa3 + sb, rb = fb3 + sb;
         char* dma_lds = smem + (STAGE - sb);
-        avo = nt_avo; bvo = nt_bvo;
+        avo = nt_avo - ((MIXED && smf == 4) ? avo_adj4 : 0u); bvo = nt_bvo;
         asm volatile("" : "+v"(avo), "+v"(bvo));
         static_for<0, NFW>([&](auto Jc) {
           constexpr int j = decltype(Jc)::value;
@@ -560,7 +595,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, MF>([&](auto Ic) {
               constexpr int i = decltype(Ic)::value;
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
+              if (MIXED && i == MF - 1) {
+                if (grp5) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
+              }
               __builtin_amdgcn_sched_barrier(0);
               if constexpr (i > 0) {
                 if (HN) rd_ah(std::integral_constant<int, i - 1>{}, na);     // its last reader is the MFMA before this one
@@ -816,7 +855,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     int el = lane;
     asm volatile("" : "+v"(el));
     char* const ep = smem + STAGE + wave * EPW;
-    const int mw = m0 + wm * MF * 16;
+    const int mfe = MIXED ? mf : MF;            // fragment groups of this tile
+    const int mw = m0 + wm * mfe * 16;
     const int nw = n0 + wn * 128;
     const int wsw = el & 7;
     char* const wbase = ep + (el & 15) * 512 + (((el >> 4) ^ (wsw & 3)) << 4);
@@ -874,9 +914,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     __builtin_amdgcn_sched_barrier(0);
     if (has_next) {
       // first k-tile of the NEXT output tile -> stage 0, in flight while this tile's epilogue drains through stage 1
-      decode(vn, nm0, nn0, nz, ntn, nkb, nke);
+      decode(vn, nm0, nn0, nz, ntn, nkb, nke, nmf);
       nnt = max(nke - nkb, 0) * nseg;
-      sm0 = nm0; sn0 = nn0; skt_begin = nkb; skt_end = nke; st_seg = 0; st_kt = nkb;
+      sm0 = nm0; sn0 = nn0; skt_begin = nkb; skt_end = nke; st_seg = 0; st_kt = nkb; smf = nmf;
       if (nnt > 0) stage(0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -888,7 +928,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #endif
     if (no_store) {
 #pragma unroll 1
-      for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) put_i(i);
+      for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) put_i(i);
     } else if (!lay16) {
       // ---------------- f32 layout: lane -> 4 columns, two 512-B rows per wave instruction ----------------
       const int n = nw + 4 * L32;
@@ -906,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         }
         if (EPI == EPI_LINEAR && pf_res) {
 #pragma unroll 1
-          for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+          for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) {
             pf_issue();
             put_i(i);
             static_for<0, 8>([&](auto Tc) {
@@ -918,7 +958,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           }
         } else {
 #pragma unroll 1
-          for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+          for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) {
             put_i(i);
 #pragma unroll 1
             for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
@@ -929,11 +969,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             }
           }
         }
-        nvm = MF * 8;
+        nvm = mfe * 8;
       } else {
         // GELU / GELU' / generic epilogues without plane outputs (test shapes): loads in the loop
 #pragma unroll 1
-        for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+        for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) {
           put_i(i);
 #pragma unroll 1
           for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
@@ -1013,7 +1053,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           dh += ld4;
         };
 #pragma unroll 1
-        for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+        for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) {
           if constexpr (EPI == EPI_GELU_BWD) {
             pf_issue();
             put_i(i);
@@ -1029,11 +1069,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) row16(it, b0);
           }
         }
-        nvm = MF * 4 * (1 + (dlo ? 1 : 0) + (dz ? 1 : 0));
+        nvm = mfe * 4 * (1 + (dlo ? 1 : 0) + (dz ? 1 : 0));
       } else {
         // plane output together with fp32 side outputs / in-loop inputs (test shapes, the all-bf16x3 mode's fp32 z): rolled
 #pragma unroll 1
-        for (int i = 0; EGV_COLD_LOOP(i < MF); ++i) {
+        for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) {
           put_i(i);
 #pragma unroll 1
           for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) {
@@ -1060,7 +1100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     }
 #endif
     if (!has_next) break;
-    v = vn; m0 = nm0; n0 = nn0; z = nz; tn = ntn; kt_begin = nkb; kt_end = nke; nt = nnt;
+    v = vn; m0 = nm0; n0 = nn0; z = nz; tn = ntn; kt_begin = nkb; kt_end = nke; nt = nnt; mf = nmf;
     // k-tile 0 of the new tile must have landed before the barrier.  Only the DMA-issuing waves have anything to wait for,
     // and the DMA is OLDER than the nvm epilogue accesses issued behind it (one in-order counter): vmcnt(N <= nvm) retires
     // the DMA and leaves the last N stores in flight under the next main loop (they are waited for with the DMA of k-tile 1,
@@ -1077,15 +1117,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   }
 }
 
-template <int MF, bool TN, int EPI, bool F3 = false>
-int launch_big(const egv_gemm_desc& p, hipStream_t s) {
+template <int MF, bool TN, int EPI, bool F3 = false, bool MIXED = false>
+int launch_big(const egv_gemm_desc& p, hipStream_t s, int nb5 = 0) {
   constexpr int BM = MF * 64;
   constexpr int lds = 2 * (BM * 128 + BNB * 128);
   int lds_launch = lds;
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNB - 1) / BNB);
+  const int bands = MIXED ? nb5 + (p.M - nb5 * 320 + 255) / 256 : (p.M + BM - 1) / BM;
+  const int tiles = bands * ((p.N + BNB - 1) / BNB);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   const int total = tiles * ks;
-  auto k = gemm_big_kernel<MF, TN, EPI, F3>;
+  auto k = gemm_big_kernel<MF, TN, EPI, F3, MIXED>;
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
@@ -1102,14 +1143,42 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s) {
   // (XCD affinity).  p.grid_cap < 256 leaves CUs to the RCCL kernels of an overlapped collective (per launch: no process state).
   const int cap = p.grid_cap > 0 ? p.grid_cap : 256;
   const int grid = total < cap ? total : cap;
-  EGV_LAUNCH(k, dim3(grid), dim3(512), lds_launch, s, p, dbg);
+  EGV_LAUNCH(k, dim3(grid), dim3(512), lds_launch, s, p, dbg, nb5);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
+}
+
+// Mixed row bands (see gemm_big_kernel): -> nb5 (number of 320-row bands, the rest are 256 rows), or -1 when the uniform 320-row
+// tiling is at least as good.  Same number of rounds R as the uniform tiling; as many bands as R rounds of `grid` workgroups can
+// take; cost = 5 per round that still contains a 320-row tile + 4 per round of 256-row tiles only.
+int pick_mixed_bands(const egv_gemm_desc& p, int grid) {
+  static const int off = getenv("EGV_GEMM_MIXED") ? atoi(getenv("EGV_GEMM_MIXED")) == 0 : 0;     // A/B: EGV_GEMM_MIXED=0
+  if (off || p.M < 640 || grid < 8) return -1;
+  const int tn = (p.N + BNB - 1) / BNB;
+  const int tiles5 = ((p.M + 319) / 320) * tn;
+  const int R = (tiles5 + grid - 1) / grid;
+  if (R < 2) return -1;
+  const int NB = (R * grid) / tn;                             // bands R rounds can hold
+  int nb5 = (p.M - 256 * NB + 63) / 64;                       // 320 nb5 + 256 (NB - nb5) >= M
+  if (nb5 < 0) nb5 = 0;
+  if (nb5 > NB) return -1;
+  const int r5 = (nb5 * tn + grid - 1) / grid;                // rounds that contain a 320-row tile
+  const int cost = 5 * r5 + 4 * (R - r5);
+  return cost < 5 * R ? nb5 : -1;
 }
 
 template <int MF, bool TN, bool F3 = false>
 int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
   if (p.ksplit > 1 || TN) return launch_big<MF, TN, EPI_RAW, F3>(p, s);   // split-K slab / wgrad: plain fp32 output
+  if constexpr (F3 && MF == 5 && !TN) {
+    // the two multi-round forward shapes of the step (qkv: plane outputs; fc1: GELU + planes + saved gelu') with mixed row bands
+    const int cap = p.grid_cap > 0 ? p.grid_cap : 256;
+    const int nb5 = pick_mixed_bands(p, cap);
+    if (nb5 >= 0 && p.alpha == 1.0f) {
+      if (p.act == EGV_ACT_NONE && (p.bias || p.residual || p.out_hi)) return launch_big<5, false, EPI_LINEAR, true, true>(p, s, nb5);
+      if (p.act == EGV_ACT_GELU) return launch_big<5, false, EPI_GELU, true, true>(p, s, nb5);
+    }
+  }
   if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
     if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, F3>(p, s);
     return launch_big<MF, false, EPI_LINEAR, F3>(p, s);

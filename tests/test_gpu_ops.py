@@ -165,6 +165,38 @@ def test_gemm_big_tiles(ops, passes, M, N, K):
     assert rel(pl.float(), ref) < TOL[passes] * 2 + 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,grid", [(25120, 2304, 128, 256), (25120, 3072, 64, 256), (25000, 2304, 64, 256), (25120, 2304, 64, 248),
+                                         (16400, 3072, 64, 256)])
+def test_gemm_big_mixed_row_bands(ops, M, N, K, grid):
+    """The multi-round three-pass forward shapes (qkv: N = 2304, fc1: N = 3072 at M = 25 120 tokens) run with MIXED row bands --
+    320-row tiles first, 256-row tiles in the last round, dealt round by round (csrc/gemm_big.hip, MIXED) -- so that the last
+    round is a short one.  Every output element must still be the plain product: LINEAR epilogue (bias -> planes, the qkv
+    flavour) and GELU epilogue (planes + saved gelu' as bf16, the fc1 flavour), ragged M (last band shifted inwards), the
+    248-workgroup data-parallel grid, and ViT-L's token count."""
+    g = torch.Generator().manual_seed(M + N + K + grid)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    ec = ops.new_context(gemm_grid=grid)
+    A, Bm = planes_from(ops, a, 3), planes_from(ops, b, 3)
+    ref = a.double() @ b.double().t() + bias
+    pl = ops.empty_planes(M, N, 3, "cuda")
+    pl.hi.fill_(float("nan")); pl.lo.fill_(float("nan"))
+    ops.gemm_nt(A, Bm, passes=3, bias=bias.cuda(), out_planes=pl, ec=ec)
+    got = pl.float()
+    assert bool(torch.isfinite(got).all())                      # every tile was written
+    assert rel(got, ref) < TOL[3] * 2 + 1e-5
+    gp = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    h = ops.empty_planes(M, N, 3, "cuda")
+    h.hi.fill_(float("nan")); h.lo.fill_(float("nan"))
+    ops.gemm_nt(A, Bm, passes=3, bias=bias.cuda(), act=ops.ACT_GELU, aux_out=gp, out_planes=h, aux_is_grad=True, ec=ec)
+    zd = ref.clone().requires_grad_(True)
+    F.gelu(zd).sum().backward()
+    assert bool(torch.isfinite(h.float()).all()) and bool(torch.isfinite(gp.float()).all())
+    assert rel(h.float(), F.gelu(ref)) < 1e-5
+    assert rel(gp.float(), zd.grad) < 3e-3
+
+
 def test_gemm_big_gelu_epilogues_bf16_aux(ops):
     """fc1 / fc2-dgrad flavour of gemm_big: fast-erf GELU (+ pre-activation saved as bf16) and GELU' from the bf16 copy."""
     g = torch.Generator().manual_seed(3)
