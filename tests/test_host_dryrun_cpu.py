@@ -103,13 +103,11 @@ def test_gemm_desc_carries_the_grid_cap_per_call(model):
 
 
 def _cpu_pack(grads, flat, offsets, scale):
-    for g, o in zip(grads, offsets):
-        flat[o:o + g.numel()] = (g.reshape(-1) * scale).to(torch.bfloat16)
+    pass            # only the ORDER in which buckets are launched is under test here (the arithmetic: tests/test_gradsync_gloo.py)
 
 
 def _cpu_unpack(grads, flat, offsets):
-    for g, o in zip(grads, offsets):
-        g.copy_(flat[o:o + g.numel()].float().view_as(g))
+    pass
 
 
 @pytest.fixture()
@@ -132,7 +130,7 @@ def test_hook_free_buckets_leave_during_backward_on_the_real_model(model, gloo_w
     try:
         ec = model.exec_ctx
         gs = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), pack_fn=_cpu_pack,
-                          unpack_fn=_cpu_unpack, broadcast=False, exec_ctx=ec)
+                          unpack_fn=_cpu_unpack, broadcast=False, exec_ctx=ec, exchange="allreduce", bucket_mb=64.0)
         launched_at = []           # (# buckets launched so far) at every poll
         def poll():
             gs.poll()
