@@ -402,6 +402,17 @@ def main():
         hp.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(hp)          # everything below (timed steps, instrumented passes) runs on the high-priority stream
     dt, loss_val = measure(args.steps, args.warmup)
+    # what ONE step costs the host when nothing pushes back: enqueue a step onto idle streams (3 repetitions, minimum).  The
+    # steady-state figure above (time until the host has enqueued `steps` steps) also contains the waits for space in the
+    # hardware queues once the host is a full step ahead of the GPU -- back-pressure, not work.
+    idle = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        one_step()
+        idle.append((time.perf_counter() - t0_) * 1e3)
+    torch.cuda.synchronize()
+    HOST["enqueue_idle_ms"] = min(idle)
     for g_ in graphed.values():           # the instrumented legs below run eagerly
         g_.disable()
     graphed.clear()
@@ -478,6 +489,7 @@ def main():
                                "step_replayed_from_hip_graph": bool(args.graph and world == 1 and not use_dist)}},
         "loss": round(loss_val, 5),
         "host_enqueue_ms_per_step": round(HOST.get("enqueue_ms_per_step", 0.0), 3),
+        "host_enqueue_ms_from_idle_streams": round(HOST.get("enqueue_idle_ms", 0.0), 3),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
     }
     if roof is not None:
