@@ -342,6 +342,21 @@ def zeros(shape, dtype=torch.float32, device="cuda"):
 _WGRAD_KSPLIT_DIV = int(os.environ.get("EGV_WGRAD_KSPLIT_DIV", "0"))   # A/B override of the wgrad k-slice divisor (0 = policy)
 
 
+_SIZE_CACHE = {}
+
+
+def _cached_size(kind, *geom):
+    """Workspace sizes are pure functions of the geometry: ask the library once per geometry (the step asks ~100 times)."""
+    key = (kind,) + geom
+    v = _SIZE_CACHE.get(key)
+    if v is None:
+        lib = _lib.lib()
+        fn = {"ln_parts": lib.egv_layernorm_bwd_parts, "attn_fwd": lib.egv_divided_attn_fwd_work_floats,
+              "attn_bwd": lib.egv_divided_attn_bwd_work_floats}[kind]
+        v = _SIZE_CACHE[key] = int(fn(*geom))
+    return v
+
+
 def pad32(n):
     return (n + 31) // 32 * 32
 
@@ -546,7 +561,7 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
         lddx = cols
     dg = torch.empty(cols, dtype=torch.float32, device=dev)
     db = torch.empty(cols, dtype=torch.float32, device=dev)
-    parts = _lib.lib().egv_layernorm_bwd_parts(rows)
+    parts = _cached_size("ln_parts", rows)
     work = torch.empty(2 * cols * parts, dtype=torch.float32, device=dev)
     pl = empty_planes(rows, cols, planes_passes, dev) if planes_passes else None
     if dy_pl is not None:
@@ -626,7 +641,7 @@ def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes):
     dev = qkv.hi.device
     out = empty_planes(B * S, H * 64, passes, dev)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
-    work = torch.empty(_lib.lib().egv_divided_attn_fwd_work_floats(B, T, n, H, mode), dtype=torch.float32, device=dev)
+    work = torch.empty(_cached_size("attn_fwd", B, T, n, H, mode), dtype=torch.float32, device=dev)
     check(_lib.lib().egv_divided_attn_fwd(_p(qkv.hi), _p(qkv.lo), B, T, n, H, mode, passes, _p(out.hi), _p(out.lo),
                                           _p(lse), _p(work), _stream(qkv.hi)), "egv_divided_attn_fwd")
     return out, lse
@@ -637,7 +652,7 @@ def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, m
     S = 1 + T * n
     dev = qkv.hi.device
     dqkv = empty_planes(B * S, 3 * H * 64, passes, dev)
-    work = torch.empty(_lib.lib().egv_divided_attn_bwd_work_floats(B, T, n, H), dtype=torch.float32, device=dev)
+    work = torch.empty(_cached_size("attn_bwd", B, T, n, H), dtype=torch.float32, device=dev)
     check(_lib.lib().egv_divided_attn_bwd(_p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(d_out.hi), _p(d_out.lo),
                                           _p(lse), B, T, n, H, mode, passes, _p(dqkv.hi), _p(dqkv.lo), _p(work),
                                           _stream(qkv.hi)), "egv_divided_attn_bwd")

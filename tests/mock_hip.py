@@ -46,7 +46,9 @@ def mock_hip():
     _lib._lib = _make_mock(calls)
     ops._stream = lambda t=None: None
     ops._need_cuda = lambda *ts: None
+    ops._SIZE_CACHE.clear()                  # workspace sizes answered by the mock must not outlive it
     try:
         yield calls
     finally:
         _lib._lib, ops._stream, ops._need_cuda = saved
+        ops._SIZE_CACHE.clear()
