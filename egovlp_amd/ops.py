@@ -62,7 +62,7 @@ class ExecContext:
             raise TypeError(f"ExecContext: unknown settings {sorted(unknown)}")
         self.parent = parent
         self._s = dict(settings)
-        self._side = {"stream": None, "main": None, "dirty": False, "queued": False}
+        self._side = {"stream": None, "main": None, "dirty": False, "queued": False, "extra": [], "rr": 0}
         self._text = {"stream": None, "main": None}     # "main": the stream forward() forked the text tower from
         self._wc = None
 
@@ -129,7 +129,10 @@ class ExecContext:
         return self._text["stream"] is not None and torch.cuda.current_stream() == self._text["stream"]
 
     def on_side_stream(self):
-        return self._side["stream"] is not None and torch.cuda.current_stream() == self._side["stream"]
+        if self._side["stream"] is None:
+            return False
+        cur = torch.cuda.current_stream()
+        return cur == self._side["stream"] or any(cur == s_ for s_ in self._side["extra"])
 
     # The wgrad side stream.  dW = dY^T X is needed only by the optimizer, while the dgrad chain of backward waits for nothing
     # but dX.  With `wgrad_side_stream` on, every wgrad GEMM (and its split-K reduce) is enqueued on a second HIP stream behind
@@ -154,10 +157,11 @@ class ExecContext:
         the side stream."""
         sd = self._side
         if sd["dirty"]:
-            sd["main"].wait_stream(sd["stream"])
             cur = torch.cuda.current_stream()
-            if cur != sd["main"]:
-                cur.wait_stream(sd["stream"])
+            for st in [sd["stream"]] + sd["extra"]:
+                sd["main"].wait_stream(st)
+                if cur != sd["main"]:
+                    cur.wait_stream(st)
             sd["dirty"] = False
 
     def _join_callback(self):
@@ -173,6 +177,8 @@ class ExecContext:
         stream.wait_stream(torch.cuda.current_stream())
         if self._side["stream"] is not None:
             stream.wait_stream(self._side["stream"])
+            for st in self._side["extra"]:
+                stream.wait_stream(st)
         if self._text["stream"] is not None:
             stream.wait_stream(self._text["stream"])
 
@@ -200,7 +206,10 @@ class _SideStream:
         main = torch.cuda.current_stream()
         if sd["stream"] is None:
             sd["stream"] = torch.cuda.Stream()
-        side = sd["stream"]
+            sd["extra"] = [torch.cuda.Stream() for _ in range(_wgrad_stream_count() - 1)]
+        pool = [sd["stream"]] + sd["extra"]
+        side = pool[sd["rr"] % len(pool)]
+        sd["rr"] += 1
         side.wait_stream(main)
         for t in self.inputs:
             t.record_stream(side)
@@ -339,7 +348,20 @@ def zeros(shape, dtype=torch.float32, device="cuda"):
     return t
 
 
+_WGRAD_STREAMS = int(os.environ.get("EGV_WGRAD_STREAMS", "0"))       # A/B override (0 = policy below)
 _WGRAD_KSPLIT_DIV = int(os.environ.get("EGV_WGRAD_KSPLIT_DIV", "0"))   # A/B override of the wgrad k-slice divisor (0 = policy)
+
+
+def _wgrad_stream_count():
+    """How many side streams the weight-gradient GEMMs are dealt to (round robin).  TWO in a single-process run: with a third of the
+    k-slices each, two wgrads fit next to each other on the CUs the main stream's kernels leave free (+0.7 .. 0.9 % step rate on
+    three boxes).  ONE as soon as a process group exists: RCCL's and the gradient exchange's streams are in play then, and with a
+    second wgrad stream on top the step collapses from 39 to 48.5 ms (world size 1 under RCCL; three wgrad streams do the same
+    without RCCL; more hardware queues do not help) -- profiles/r03_stream_ab.txt."""
+    if _WGRAD_STREAMS > 0:
+        return _WGRAD_STREAMS
+    import torch.distributed as dist
+    return 1 if (dist.is_available() and dist.is_initialized()) else 2
 
 
 _SIZE_CACHE = {}
@@ -446,7 +468,8 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         # chip by itself, half the workgroups leave CUs to the main stream's kernels, and the fp32 slabs (and the reduce that
         # reads them) are half as big.  Same box: 796.6 -> 819.8 pairs/s (+2.9 %); a third: 788, a quarter: 635 -- the wgrads
         # then become the critical path (profiles/r02_ab_wgrad_ksplit.txt).
-        div = _WGRAD_KSPLIT_DIV or (2 if ec.on_side_stream() else 1)
+        # (a third with two wgrad streams: two of them then share the free CUs)
+        div = _WGRAD_KSPLIT_DIV or ((3 if ec._side["extra"] else 2) if ec.on_side_stream() else 1)
         ksplit = max(1, min(ec.gemm_grid // max(tiles, 1) // div, nkt // 2))
     cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
     partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
