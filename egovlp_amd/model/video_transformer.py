@@ -50,7 +50,7 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, pa
     # ordered behind the side stream -- such wgrads (gradient accumulation, set_to_none=False) stay on the main stream.
     accumulating = any(p_ is not None and p_.grad is not None for p_ in params)
     if ec.wgrad_side_stream and not ec.on_text_stream() and not accumulating:
-        with ec.side_stream(dy.hi, dy.lo, x_pl.hi, x_pl.lo):
+        with ec.side_stream(dy.hi, dy.lo, x_pl.hi, x_pl.lo, cost=float(M) * N * K):
             dW = torch.empty((N, K), dtype=torch.float32, device=dev)
             db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec)
     else:

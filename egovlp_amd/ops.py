@@ -140,15 +140,18 @@ class ExecContext:
     # partial round of a tile grid, drain tails, the launch gaps of the small kernels).  The main stream re-joins at the end of
     # backward (an autograd engine callback queued by the first wgrad of the pass), before any gradient hook reads a wgrad
     # (`join_streams_for_gradient_hook`) and, unconditionally, in egoclip_step before the optimizer.
-    def side_stream(self, *inputs):
+    def side_stream(self, *inputs, cost=1.0):
         """`with ec.side_stream(*inputs):` -- enqueue the body on the side stream, ordered after everything already enqueued on
-        the current stream; `inputs` are the tensors the body reads (kept alive for the side stream by the allocator)."""
-        return _SideStream(self, inputs)
+        the current stream; `inputs` are the tensors the body reads (kept alive for the side stream by the allocator).  With
+        several side streams the body goes to the one with the least work dealt to it so far in this step (`cost`: any additive
+        measure, the callers pass MACs)."""
+        return _SideStream(self, inputs, cost)
 
     def begin_step(self):
         """Start of a forward / backward pass: forget a join callback that never ran (a backward that raised leaves
         'queued' set and later passes would not queue theirs), and validate / refresh the weight-plane cache once for the step."""
         self._side["queued"] = False
+        self._side["load"] = None
         if self._wc is not None:
             self._wc.begin_step()
 
@@ -197,8 +200,9 @@ class ExecContext:
 
 
 class _SideStream:
-    def __init__(self, ec: ExecContext, inputs):
+    def __init__(self, ec: ExecContext, inputs, cost=1.0):
         self.ec = ec
+        self.cost = float(cost)
         self.inputs = [t for t in inputs if t is not None]
 
     def __enter__(self):
@@ -208,8 +212,12 @@ class _SideStream:
             sd["stream"] = torch.cuda.Stream()
             sd["extra"] = [torch.cuda.Stream() for _ in range(_wgrad_stream_count() - 1)]
         pool = [sd["stream"]] + sd["extra"]
-        side = pool[sd["rr"] % len(pool)]
-        sd["rr"] += 1
+        load = sd.get("load")
+        if load is None or len(load) != len(pool):
+            load = sd["load"] = [0.0] * len(pool)
+        k = min(range(len(pool)), key=load.__getitem__)      # least-loaded stream (ties: the first)
+        load[k] += self.cost
+        side = pool[k]
         side.wait_stream(main)
         for t in self.inputs:
             t.record_stream(side)
