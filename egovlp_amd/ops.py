@@ -215,7 +215,11 @@ class _SideStream:
         load = sd.get("load")
         if load is None or len(load) != len(pool):
             load = sd["load"] = [0.0] * len(pool)
-        k = min(range(len(pool)), key=load.__getitem__)      # least-loaded stream (ties: the first)
+        if _WGRAD_DEAL == "rr":
+            k = sd["rr"] % len(pool)
+            sd["rr"] += 1
+        else:
+            k = min(range(len(pool)), key=load.__getitem__)      # least-loaded stream (ties: the first)
         load[k] += self.cost
         side = pool[k]
         side.wait_stream(main)
@@ -357,6 +361,7 @@ def zeros(shape, dtype=torch.float32, device="cuda"):
 
 
 _WGRAD_STREAMS = int(os.environ.get("EGV_WGRAD_STREAMS", "0"))       # A/B override (0 = policy below)
+_WGRAD_DEAL = os.environ.get("EGV_WGRAD_DEAL", "load")                # "rr": round robin (A/B)
 _WGRAD_KSPLIT_DIV = int(os.environ.get("EGV_WGRAD_KSPLIT_DIV", "0"))   # A/B override of the wgrad k-slice divisor (0 = policy)
 
 
