@@ -80,3 +80,64 @@ def test_oscc_pnr_head_train_step_matches_oracle(classes):
     assert errs["scores"] < 1e-3 and errs["loss"] < 1e-3
     assert all(v < 3e-3 for k, v in errs.items() if k.startswith("d ")), errs
     assert all(p.grad is None for k, p in m.named_parameters() if k.startswith("text_model.") or k.startswith("txt_proj."))
+
+
+def _golden():
+    import os
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "heads.npz"))
+
+
+@pytest.mark.parametrize("key", ["ce_64x2", "ce_37x17"])
+def test_cross_entropy_matches_reference_class_golden(key):
+    """tests/golden/heads.npz part (a): the reference's own CrossEntropy class (model/loss.py:135-141), run in the build
+    container by tests/golden/make_golden.py, on the scores / labels stored with its loss and gradient."""
+    from egovlp_amd.model.loss import CrossEntropy
+    G = _golden()
+    x = torch.from_numpy(G["x_" + key]).cuda().requires_grad_(True)
+    t = torch.from_numpy(G["t_" + key]).cuda()
+    loss = CrossEntropy()(x, t)
+    loss.backward()
+    assert abs(float(loss) - float(G["loss_" + key])) < 1e-5 * max(1.0, abs(float(G["loss_" + key])))
+    assert rel(x.grad, G["grad_" + key]) < 1e-5
+
+
+@pytest.mark.parametrize("classes", [2, 17])
+def test_oscc_pnr_head_train_step_matches_reference_golden(classes):
+    """tests/golden/heads.npz part (b): the REFERENCE model (model/model.py FrozenInTime, projection_dim = classes,
+    `video_only=True`, trainer/trainer_oscc.py:335-338) stepped in the build container; here the drop-in on the same weights
+    (synth seed 21) and the same clip (redrawn from the same CPU generator, corner-checked) must give its scores, its loss, the
+    head's gradients and slices + norms of two encoder gradients."""
+    from egovlp_amd.model.loss import CrossEntropy
+    from egovlp_amd.model.model import FrozenInTime
+    from egovlp_amd.ops import Precision
+    G = _golden()
+    k = "head%d" % classes
+    B, T = 3, 4
+    gg = torch.Generator().manual_seed(8 + classes)                      # == make_golden.heads_inputs
+    video = torch.randn(B, T, 3, 224, 224, generator=gg)
+    state = torch.randint(0, classes, (B,), generator=gg)
+    assert torch.equal(video[:, :, :, :2, :2], torch.from_numpy(G["video_corner_" + k])), "the CPU generator drew another clip"
+    assert torch.equal(state, torch.from_numpy(G["state_" + k]))
+    Precision.set("bf16x3")
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 4,
+                                   "pretrained": True, "time_init": "rand"},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+                     projection="minimal", projection_dim=classes, load_checkpoint="")
+    m.load_state_dict(synth_state_dict({n: v.shape for n, v in m.state_dict().items()}, seed=21), strict=True)
+    m = m.cuda().train()
+    scores = m({"video": video.cuda()}, video_only=True)
+    loss = CrossEntropy()(scores, state.cuda())
+    loss.backward()
+    params = dict(m.named_parameters())
+    errs = {"scores": rel(scores, G["scores_" + k]),
+            "loss": abs(float(loss) - float(G["loss_" + k])) / abs(float(G["loss_" + k])),
+            "d vid_proj.w": rel(params["vid_proj.0.weight"].grad, G["g_vid_proj_w_" + k]),
+            "d vid_proj.b": rel(params["vid_proj.0.bias"].grad, G["g_vid_proj_b_" + k])}
+    for name in ("video_model.blocks.11.mlp.fc2.weight", "video_model.blocks.0.attn.qkv.weight"):
+        gr = params[name].grad
+        errs["d " + name + "[:8,:64]"] = rel(gr[:8, :64], G["g:%s:%s" % (name, k)])
+        errs["|d " + name + "|"] = abs(float(gr.float().norm()) - float(G["gn:%s:%s" % (name, k)])) / float(G["gn:%s:%s" % (name, k)])
+    print("head classes=%d vs the reference's own run:" % classes, {n: "%.2e" % v for n, v in errs.items()})
+    assert errs["scores"] < 1e-3 and errs["loss"] < 1e-3
+    assert all(v < 3e-3 for n, v in errs.items() if "d " in n), errs

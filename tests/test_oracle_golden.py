@@ -141,3 +141,32 @@ def test_retrieval_heads_match_the_reference(golden_dir, full):
     assert rel(tok, g["text_tokens"]) < 2e-5
     assert rel(tok[:, 0], te) < 1e-6                    # token 0 is the sentence embedding of compute_text
     assert rel(ve, g["video_only"]) < 2e-5
+
+
+@pytest.mark.parametrize("classes", [2, 17])
+def test_classification_head_oracle_matches_the_reference(golden_dir, classes):
+    """§8(f4): the OSCC / PNR head as tests/test_gpu_heads.py's oracle leg computes it (oracle video encoder, a linear head,
+    torch's cross-entropy) against the reference model's own train step (heads.npz part b: model/model.py FrozenInTime with
+    projection_dim = classes, video_only=True, trainer/trainer_oscc.py:335-338): scores, loss, head gradients, an encoder
+    gradient slice."""
+    import torch.nn.functional as F
+    g = np.load(os.path.join(golden_dir, "heads.npz"))
+    k = "head%d" % classes
+    gg = torch.Generator().manual_seed(8 + classes)                      # == make_golden.heads_inputs
+    video = torch.randn(3, 4, 3, 224, 224, generator=gg)
+    state = torch.randint(0, classes, (3,), generator=gg)
+    assert torch.equal(video[:, :, :, :2, :2], torch.from_numpy(g["video_corner_" + k]))
+    from egovlp_amd.model.schema import state_dict_schema
+    schema = state_dict_schema(projection_dim=classes, num_frames=4)
+    watch = ("vid_proj.0.weight", "vid_proj.0.bias", "video_model.blocks.11.mlp.fc2.weight")
+    sd = {n: v.requires_grad_(n in watch) for n, v in synth_state_dict(schema, seed=21).items()}
+    feats = O.video_encoder(video, sd, O.VideoCfg(num_frames=4))
+    scores = F.linear(feats, sd["vid_proj.0.weight"], sd["vid_proj.0.bias"])
+    loss = F.cross_entropy(scores, state)
+    loss.backward()
+    assert rel(scores.detach(), g["scores_" + k]) < 1e-4
+    assert abs(float(loss) - float(g["loss_" + k])) < 1e-5 * abs(float(g["loss_" + k]))
+    assert rel(sd["vid_proj.0.weight"].grad, g["g_vid_proj_w_" + k]) < 1e-4
+    assert rel(sd["vid_proj.0.bias"].grad, g["g_vid_proj_b_" + k]) < 1e-4
+    name = "video_model.blocks.11.mlp.fc2.weight"
+    assert rel(sd[name].grad[:8, :64], g["g:%s:%s" % (name, k)]) < 1e-4
