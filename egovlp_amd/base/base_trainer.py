@@ -9,8 +9,8 @@ file: `{'arch', 'epoch', 'state_dict', 'optimizer', 'monitor_best', 'config'}` a
 
 Different by design: the reference wraps the model in `DistributedDataParallel(find_unused_parameters=True)`
 (:258, fp32 bucketed all-reduce + a graph walk per step although no parameter is ever unused).  Here the model is NOT
-wrapped: at world size > 1 gradients are averaged by `egovlp_amd.dist.Bf16GradSync` (bf16 buckets, RCCL all-reduce launched
-from grad-ready hooks while backward is still running).  `self.model` therefore has the same attribute surface and
+wrapped: at world size > 1 gradients are averaged by `egovlp_amd.dist.Bf16GradSync` (bf16 buckets, exchanged over RCCL while
+backward is still running: launched hook-free from the block-boundary polls of the video tower's backward, on a private stream).  `self.model` therefore has the same attribute surface and
 `state_dict` keys (no `module.` prefix) on every world size.
 """
 from __future__ import annotations
