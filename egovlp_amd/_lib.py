@@ -39,7 +39,8 @@ class GemmDesc(C.Structure):
         ("partial", c_p),
         ("trans", i32), ("aux_bf16", i32),
         ("colsum", c_p),
-        ("grid_cap", i32), ("reserved_", i32),
+        ("grid_cap", i32), ("out_fmt", i32),
+        ("out_bf", c_p),
     ]
 
 
@@ -81,6 +82,9 @@ PROTOTYPES = {
     "egv_relu_split": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p]),
     "egv_version": (i32, []),
     "egv_split_f32_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "egv_f16f6_encode": (i32, [c_p, i64, i32, i32, c_p, c_p, c_p, i64, c_p]),
+    "egv_f16f6_encode_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "egv_layernorm_fwd_f16f6": (i32, [c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
     "egv_diag_mfma_peak": (i32, [i32, i32, c_p, c_p]),
     "egv_diag_traffic_calib": (i32, [i32, c_p, c_p, i64, c_p]),
 }

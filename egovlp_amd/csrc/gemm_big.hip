@@ -48,6 +48,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "f6.h"
 #include "egovlp_hip.h"
 
 namespace {
@@ -62,7 +63,9 @@ enum { EPI_RAW = 0,      // store the accumulators (split-K partial slab, or pla
        EPI_LINEAR = 1,   // + bias, + residual -> fp32 and/or planes
        EPI_GELU = 2,     // + bias, pre-activation -> aux_out, gelu -> fp32 and/or planes
        EPI_GELU_BWD = 3, // * gelu'(aux_in) -> fp32 and/or planes
-       EPI_GENERIC = 4 };// everything at run time (alpha, ReLU', ...)
+       EPI_GENERIC = 4,  // everything at run time (alpha, ReLU', ...)
+       EPI_GELU_F6 = 5 };// EPI_GELU with the activation written in the f16f6 operand format (csrc/f6.h): fp16 plane + MXFP6 slots
+                         // [+ bf16 plane for the backward], the saved gelu' as bf16 -- fc1 forward of the f16f6 mode
 
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
 typedef __attribute__((ext_vector_type(8))) short s16x8v;
@@ -112,6 +115,36 @@ __device__ __forceinline__ void lgkm_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void tie(bf16x8_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void tie(f16x8_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void tie(u32x4_t& x) { asm volatile("" : "+v"(x)); }
+template <int OFF>
+__device__ __forceinline__ f16x8_t ld128h_asm(unsigned addr) {
+  u32x4_t r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return __builtin_bit_cast(f16x8_t, r);
+}
+// One MXFP6 slot (32 B: 24 B of codes, the scale byte, pad) of the f16f6 loop: two 16-byte reads by lanes 0-31 ONLY (EXEC masked
+// inside the asm: lanes 32-63 are the k-groups of the K = 128 instruction that a 32-deep k-tile does not fill, and reading for them
+// would cost the LDS as much again).  Their registers keep whatever they held; they are taken out of the product through the
+// SCALE operand instead (slot_scale: E8M0 byte 0 = 2^-127 on both sides, 2^-254 x anything an E2M3 block can sum to is 0 in fp32).
+// a0 / a1: the two 16-B chunks of the slot (their order in LDS depends on the row's chunk permutation, so two addresses).
+// Three reads (dwords 0-3, dwords 4-5, the scale dword): the MFMA operand is a 6-register tuple, and only WHOLE virtual registers
+// (a 128-bit and a 64-bit one) coalesce into it without copies.
+template <int OFF>
+__device__ __forceinline__ void ld_slot_asm(u32x4_t& s0, u32x2_t& s1, unsigned& sc, unsigned a0, unsigned a1) {
+  asm volatile("s_mov_b32 exec_hi, 0\n\tds_read_b128 %0, %3 offset:%5\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b32 %2, %4 offset:%5+8\n\t"
+               "s_mov_b32 exec_hi, -1"
+               : "=&v"(s0), "=&v"(s1), "=&v"(sc)
+               : "v"(a0), "v"(a1), "i"(OFF));
+}
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+// the operand the MFMA reads (dwords 0-5 of the 8; FP6 ignores the rest)
+__device__ __forceinline__ i32x8_t slot_operand(const u32x4_t& s0, const u32x2_t& s1) {
+  return (i32x8_t){(int)s0[0], (int)s0[1], (int)s0[2], (int)s0[3], (int)s1[0], (int)s1[1], 0, 0};
+}
+__device__ __forceinline__ void tie(u32x2_t& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void anchor(const f32x4_t& x) { asm volatile("" ::"v"(x)); }   // "x exists here": stops code sinking
+__device__ __forceinline__ void tie(unsigned& x) { asm volatile("" : "+v"(x)); }
 
 // Loop condition of the ROLLED epilogue loops.  LLVM's block-frequency estimate multiplies by ~32 per loop level, so a
 // rolled two-level epilogue loop looks "hotter" than the k-tile loop and the register allocator spills the main loop's
@@ -184,9 +217,16 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
 // ids [r G, (r + 1) G), XCD remap inside a round), bands in id order, so every workgroup gets the tall tiles in its early rounds
 // and the short ones in its last: M = 25 120 x N = 2304 is 53 + 32 bands = 765 tiles = 5 + 5 + 4 units per workgroup where 79
 // bands of 320 rows are 711 tiles = 3 rounds of 5 (-6.7 %); N = 3072: 5 + 5 + 5 + 4 instead of 4 x 5 (-5 %).
-template <int MF, bool TN, int EPI, bool F3, bool MIXED = false>
+// PROD: 0 = one product per k-tile from single planes (plain loops), 3 = fused bf16x3, 6 = f16f6 (fp16 product + one block-scaled
+// MXFP6 product per 32-deep k-tile; same stage layout and DMA as 3).
+template <int MF, bool TN, int EPI, int PROD, bool MIXED = false>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg_arg, const int nb5_arg) {
-  static_assert(!MIXED || (F3 && MF == 5 && !TN), "mixed row bands: the fused three-product NT instance with 320-row tiles");
+  constexpr bool F6 = PROD == 6;
+  constexpr bool F3 = PROD != 0;      // the fused stage layout ([A_hi | A_lo | B_hi | B_lo] x 64 B, 32-deep k-tiles)
+  constexpr bool IS_GELU = EPI == EPI_GELU || EPI == EPI_GELU_F6;
+  static_assert(!MIXED || (PROD == 3 && MF == 5 && !TN), "mixed row bands: the fused three-product NT instance with 320-row tiles");
+  static_assert(!F6 || MF == 4, "the f16f6 loop keeps 8 registers per MXFP6 slot: 256-row tiles only");
+  static_assert(EPI != EPI_GELU_F6 || F6, "f16f6 outputs are produced by the f16f6 instances only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef EGV_DIAG
   const int dbg = dbg_arg;      // `make diag` build only (tools/gemm_trace.py, tools/gemm_bench.py with EGV_GEMM_DBG)
@@ -506,7 +546,129 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
     for (int i = 0; i < MF; ++i) cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (F3) {
+    if constexpr (F6) {
+      // ---- f16f6 NT main loop (csrc/f6.h) ------------------------------------------------------------------------------------
+      // Per 32-deep k-tile and fragment pair: ONE fp16 MFMA (A_h . B_h) and ONE block-scaled MXFP6 MFMA whose k-group 0 multiplies
+      // c6(A) . l6(B) and k-group 1 l6(A) . c6(B) (groups 2, 3 = lanes 32-63: scale 0) -- 2 issue units where bf16x3 spends 3
+      // (measured: 31.3 vs 48.0 ns per fragment and k-tile, tools/mx_probe.hip).  The stage layout and the DMA are the fused
+      // loop's: "hi" rows are 32 fp16, "lo" rows the 64-byte slot pair [c6 | l6] of the block.
+      // Phase j (0..7) runs the fp16 products of B fragment j and the MXFP6 products of B slot j - 1 (one phase behind; slot 7 in
+      // a tail after the hand-over), each against the MF resident A sets.  The fp16 fragments are prefetched across k-tiles as in
+      // the fused loop; the SLOTS are fetched and consumed inside one k-tile (A slots and B slot 0 at its top, B slot j in phase
+      // j): a slot is a 6-register MFMA operand assembled from a 128-bit and a 64-bit read, and only values that are defined and
+      // dead within one loop iteration coalesce into that tuple without copies (loop-carried ones cost ~350 moves and 100 spills).
+      // Reads complete in issue order; waits count the reads issued behind the ones needed (lgkmcnt saturates at 15):
+      //   top:      A slots (3 MF), B slot 0 (3)                   [in flight from the previous k-tile: B_h(0), A_h (1 + MF)]
+      //   phase 0:  B_h(1)            | wait 15 -> the 1 + MF oldest landed | fp16(0)
+      //   phase j:  B slot j, B_h(j+1) | wait 4                             | fp16(j), mx6(j-1)          (j = 7: no B_h, wait 3)
+      //   tail:     wait 0, hand-over (barrier), B_h(0)' , mx6(7) with A_h' fetched behind its MFMAs
+      f16x8_t Ah[MF], Bh[2];
+      unsigned lmask = lane < 32 ? 0xffu : 0u;            // lanes 32-63: scale byte 0 (see ld_slot_asm)
+      asm volatile("" : "+v"(lmask));
+      // this lane's slot: row (lane & 15) of the fragment, source chunks {0, 1} (c6) or {2, 3} (l6) of the 64-B row; LDS position
+      // of source chunk s in row r is s ^ g((r >> 2) & 3).  A side: k-group 0 reads c6, k-group 1 l6; B side the other way round.
+      const int gg6 = (0x78 >> (2 * ((lane >> 2) & 3))) & 3;
+      const int kg = (lane >> 4) & 1;
+      const unsigned fah = lds0 + a_rd0, fbh = lds0 + b_rd0;
+      const unsigned fas = lds0 + F3_ALO + (wm * MF * 16 + (lane & 15)) * 64 + (((2 * kg) ^ gg6) << 4);
+      const unsigned fbs = lds0 + F3_B + F3_BLO + (wn * 128 + (lane & 15)) * 64 + (((2 * (1 - kg)) ^ gg6) << 4);
+      auto k_tile6 = [&](const int t) {
+        const bool HN = t + 1 < nt;
+        const int sb = (t & 1) * STAGE;
+        const unsigned rbh = fbh + sb, rbs = fbs + sb, ras = fas + sb;
+        char* dma_lds = smem + (STAGE - sb);
+        avo = nt_avo; bvo = nt_bvo;
+        asm volatile("" : "+v"(avo), "+v"(bvo));
+        u32x4_t As0[MF], Bs0[2];
+        u32x2_t As1[MF], Bs1[2];
+        unsigned Asc[MF], Bsc[2];
+        static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; ld_slot_asm<i * 1024>(As0[i], As1[i], Asc[i], ras, ras ^ 16u); });
+        ld_slot_asm<0>(Bs0[0], Bs1[0], Bsc[0], rbs, rbs ^ 16u);
+        auto mm_h = [&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          static_for<0, MF>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
+          });
+        };
+        auto mm_6 = [&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          const int bsc = (int)(Bsc[j & 1] & lmask);
+          const i32x8_t bop = slot_operand(Bs0[j & 1], Bs1[j & 1]);
+          static_for<0, MF>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bop, slot_operand(As0[i], As1[i]), acc[i][j], 2, 2, 0, bsc, 0,
+                                                                         (int)Asc[i]);
+          });
+        };
+        static_for<0, NFW>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          if constexpr (j > 0) ld_slot_asm<j * 1024>(Bs0[j & 1], Bs1[j & 1], Bsc[j & 1], rbs, rbs ^ 16u);
+          if constexpr (j < NFW - 1) Bh[(j + 1) & 1] = ld128h_asm<(j + 1) * 1024>(rbh);
+          if (j < 4 && loader && HN) {
+            constexpr int PP = (NP + 3) / 4;
+            static_for<j * PP, (j + 1) * PP < NP ? (j + 1) * PP : NP>([&](auto Ic) { piece(dma_lds, decltype(Ic)::value, j * PP); });
+          }
+          if constexpr (j == 0) {
+            lgkm_wait<15>();              // 3 MF + 3 + 1 reads issued behind B_h(0) and A_h: at most 15 in flight = those landed
+            tie(Bh[0]);
+            static_for<0, MF>([&](auto Ic) { tie(Ah[decltype(Ic)::value]); });
+            __builtin_amdgcn_sched_barrier(0);
+            mm_h(Jc);
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            lgkm_wait<(j < NFW - 1) ? 4 : 3>();     // everything but this phase's own reads
+            tie(Bh[j & 1]); tie(Bs0[(j - 1) & 1]); tie(Bs1[(j - 1) & 1]); tie(Bsc[(j - 1) & 1]);
+            if constexpr (j == 1) {
+              static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; tie(As0[i]); tie(As1[i]); tie(Asc[i]); });
+              static_for<0, MF>([&](auto Ic) { Asc[decltype(Ic)::value] &= lmask; });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm_h(Jc);
+            mm_6(std::integral_constant<int, j - 1>{});
+            // the finished accumulators of column j - 1 are next read a whole k-tile later: without a use HERE MachineSink moves
+            // all 8 MF block-scaled MFMAs of the k-tile into the loop latch (and keeps every B slot alive until then)
+            static_for<0, MF>([&](auto Ic) { anchor(acc[decltype(Ic)::value][j - 1]); });
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        // ---- tail: hand-over to k-tile t+1, then the MXFP6 products of B slot 7 with the next A_h fetched behind them
+        lgkm_wait<0>();
+        tie(Bs0[1]); tie(Bs1[1]); tie(Bsc[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned nah = fah + (STAGE - sb);
+        if (HN) {
+          // k-tile t+1 (this wave's DMA pieces) has landed; every read of stage t & 1 by this wave has returned
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          stage_advance();
+          Bh[0] = ld128h_asm<0>(fbh + (STAGE - sb));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          constexpr int j = NFW - 1;
+          const int bsc = (int)(Bsc[j & 1] & lmask);
+          const i32x8_t bop = slot_operand(Bs0[j & 1], Bs1[j & 1]);
+          static_for<0, MF>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bop, slot_operand(As0[i], As1[i]), acc[i][j], 2, 2, 0, bsc, 0,
+                                                                         (int)Asc[i]);
+            anchor(acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HN) Ah[i] = ld128h_asm<i * 1024>(nah);        // A_h: its last reader was the fp16 pass of phase 7
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+      };
+      if (nt > 0) {
+        // k-tile 0 has landed and every wave is past a barrier behind that: B_h(0), A_h -- what phase 0 counts on
+        Bh[0] = ld128h_asm<0>(fbh);
+        static_for<0, MF>([&](auto Ic) { Ah[decltype(Ic)::value] = ld128h_asm<decltype(Ic)::value * 1024>(fah); });
+        if ((dbg & 0xfff) == 200) ts1 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+        for (int t = 0; t < nt; ++t) k_tile6(t);
+      }
+    } else if constexpr (F3) {
       // ---- fused three-product NT main loop (see the F3 note at the top of the kernel) --------------------------------------
       // Phase j (0..7) multiplies B fragment pair j (hi, lo) with the MF resident A pairs: 3 MF MFMAs in three passes over i
       // (hi.lo, lo.hi, hi.hi -- five independent accumulators between two MFMAs on the same one).  Fetch plan (asm reads
@@ -973,12 +1135,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       } else {
         // GELU / GELU' / generic epilogues without plane outputs (test shapes): loads in the loop
 #pragma unroll 1
-        for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) {
+        for (int i = 0; EGV_COLD_LOOP(EPI != EPI_GELU_F6 && i < mfe); ++i) {
           put_i(i);
 #pragma unroll 1
           for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
             const f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5)));
-            epilogue4<EPI>(p, val, mw + 16 * i + 2 * it + rs32, n, z, ksplit);
+            if constexpr (EPI != EPI_GELU_F6) epilogue4<EPI>(p, val, mw + 16 * i + 2 * it + rs32, n, z, ksplit);
           }
         }
       }
@@ -986,9 +1148,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       // ---------------- plane layout: lane -> 8 columns (16 B of every bf16 plane), four 256-B rows per instruction ----------------
       const int n = nw + 8 * L16;
       const bool fast = (EPI == EPI_LINEAR && !p.residual && !p.out_f32) ||
-                        (EPI == EPI_GELU && !p.residual && !p.out_f32 && (!p.aux_out || p.aux_bf16)) ||
+                        (IS_GELU && !p.residual && !p.out_f32 && (!p.aux_out || p.aux_bf16)) ||
                         (EPI == EPI_GELU_BWD && pf_aux && !p.residual && !p.out_f32);
-      if ((EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_GELU_BWD) && fast) {
+      if ((EPI == EPI_LINEAR || IS_GELU || EPI == EPI_GELU_BWD) && fast) {
         f32x4_t b0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (EPI != EPI_GELU_BWD && p.bias) {
           b0 = *(const f32x4_t*)(p.bias + n);
@@ -998,13 +1160,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         const long dlo = p.out_lo ? (long)(p.out_lo - p.out_hi) : 0;      // the lo plane, at a fixed element distance from hi
         const long ld4 = 4 * p.ldoh;
         bf16_t* dz = nullptr;
-        if (EPI == EPI_GELU && p.aux_out) dz = (bf16_t*)p.aux_out + (long)(mw + rs16) * p.ldaux + n;
+        if (IS_GELU && p.aux_out) dz = (bf16_t*)p.aux_out + (long)(mw + rs16) * p.ldaux + n;
+        // f16f6 outputs: the bf16 copy for the backward at a fixed element distance from the fp16 plane (0: not wanted)
+        const long dbf = (EPI == EPI_GELU_F6 && p.out_bf) ? (long)(p.out_bf - p.out_hi) : 0;
         const long ldz4 = 4 * p.ldaux;
         const bool saved_grad = p.aux_bf16 == 2;
         auto row16 = [&](const int it, const f32x4_t zin) {
           const unsigned a0 = (r16 + it * 2048) ^ ((it & 1) << 6);
           f32x4_t v0 = *(const f32x4_t*)(smem + a0) + b0, v1 = *(const f32x4_t*)(smem + (a0 ^ 16u)) + b1;
-          if constexpr (EPI == EPI_GELU) {
+          if constexpr (IS_GELU) {
             // one evaluation of (Phi, phi) gives both the activation and -- saved in place of the pre-activation when the
             // caller asks for it (aux_bf16 == 2) -- its derivative, so that the fc2-dgrad epilogue is a plain multiply
             f32x4_t s0 = v0, s1 = v1;
@@ -1042,14 +1206,23 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
               }
             }
           }
-          uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
-          split_bf16x2(v0[0], v0[1], h0, l0);
-          split_bf16x2(v0[2], v0[3], h1, l1);
-          split_bf16x2(v1[0], v1[1], h2, l2);
-          split_bf16x2(v1[2], v1[3], h3, l3);
-          constexpr int PSITE = (EPI == EPI_GELU) ? EGV_NT_GELU_PLANES : ((EPI == EPI_GELU_BWD) ? EGV_NT_GELUBWD_PLANES : EGV_NT_GEMM_PLANES);
-          egv_store16<PSITE>(dh, (u32x4_t){h0, h1, h2, h3});
-          if (dlo) egv_store16<PSITE>(dh + dlo, (u32x4_t){l0, l1, l2, l3});
+          constexpr int PSITE = IS_GELU ? EGV_NT_GELU_PLANES : ((EPI == EPI_GELU_BWD) ? EGV_NT_GELUBWD_PLANES : EGV_NT_GEMM_PLANES);
+          if constexpr (EPI == EPI_GELU_F6) {
+            // the activation in the f16f6 operand format: the 16 lanes of a row hold its 128 columns, 8 each -- a quad = one MX block
+            const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const F6Lane o = f6_encode8(vv, el);
+            egv_store16<PSITE>(dh, o.h16);
+            if (dbf) egv_store16<PSITE>(dh + dbf, o.bf);
+            f6_store_piece<PSITE>((char*)(dh + dlo - 8 * (el & 3)), el, o.piece);
+          } else {
+            uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+            split_bf16x2(v0[0], v0[1], h0, l0);
+            split_bf16x2(v0[2], v0[3], h1, l1);
+            split_bf16x2(v1[0], v1[1], h2, l2);
+            split_bf16x2(v1[2], v1[3], h3, l3);
+            egv_store16<PSITE>(dh, (u32x4_t){h0, h1, h2, h3});
+            if (dlo) egv_store16<PSITE>(dh + dlo, (u32x4_t){l0, l1, l2, l3});
+          }
           dh += ld4;
         };
 #pragma unroll 1
@@ -1069,18 +1242,21 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) row16(it, b0);
           }
         }
-        nvm = mfe * 4 * (1 + (dlo ? 1 : 0) + (dz ? 1 : 0));
+        nvm = mfe * 4 * (1 + (dlo ? 1 : 0) + (dz ? 1 : 0) + (dbf ? 1 : 0));
       } else {
         // plane output together with fp32 side outputs / in-loop inputs (test shapes, the all-bf16x3 mode's fp32 z): rolled
+        // (never the f16f6 flavour: the launcher only accepts it with the fast path's argument set)
 #pragma unroll 1
-        for (int i = 0; EGV_COLD_LOOP(i < mfe); ++i) {
+        for (int i = 0; EGV_COLD_LOOP(EPI != EPI_GELU_F6 && i < mfe); ++i) {
           put_i(i);
 #pragma unroll 1
           for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) {
             const unsigned a0 = (r16 + it * 2048) ^ ((it & 1) << 6);
             const int m = mw + 16 * i + 4 * it + rs16;
-            epilogue4<EPI>(p, *(const f32x4_t*)(smem + a0), m, n, z, ksplit);
-            epilogue4<EPI>(p, *(const f32x4_t*)(smem + (a0 ^ 16u)), m, n + 4, z, ksplit);
+            if constexpr (EPI != EPI_GELU_F6) {
+              epilogue4<EPI>(p, *(const f32x4_t*)(smem + a0), m, n, z, ksplit);
+              epilogue4<EPI>(p, *(const f32x4_t*)(smem + (a0 ^ 16u)), m, n + 4, z, ksplit);
+            }
           }
         }
       }
@@ -1117,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   }
 }
 
-template <int MF, bool TN, int EPI, bool F3 = false, bool MIXED = false>
+template <int MF, bool TN, int EPI, int PROD = 0, bool MIXED = false>
 int launch_big(const egv_gemm_desc& p, hipStream_t s, int nb5 = 0) {
   constexpr int BM = MF * 64;
   constexpr int lds = 2 * (BM * 128 + BNB * 128);
@@ -1126,7 +1302,7 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s, int nb5 = 0) {
   const int tiles = bands * ((p.N + BNB - 1) / BNB);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   const int total = tiles * ks;
-  auto k = gemm_big_kernel<MF, TN, EPI, F3, MIXED>;
+  auto k = gemm_big_kernel<MF, TN, EPI, PROD, MIXED>;
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
@@ -1167,25 +1343,44 @@ int pick_mixed_bands(const egv_gemm_desc& p, int grid) {
   return cost < 5 * R ? nb5 : -1;
 }
 
-template <int MF, bool TN, bool F3 = false>
+template <int MF, bool TN, int PROD = 0>
 int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
-  if (p.ksplit > 1 || TN) return launch_big<MF, TN, EPI_RAW, F3>(p, s);   // split-K slab / wgrad: plain fp32 output
-  if constexpr (F3 && MF == 5 && !TN) {
+  if constexpr (PROD == 6) {
+    if (p.ksplit > 1) return EGV_ERR_ARG;
+  } else {
+    if (p.ksplit > 1 || TN) return launch_big<MF, TN, EPI_RAW, PROD>(p, s);   // split-K slab / wgrad: plain fp32 output
+  }
+  if constexpr (PROD == 3 && MF == 5 && !TN) {
     // the two multi-round forward shapes of the step (qkv: plane outputs; fc1: GELU + planes + saved gelu') with mixed row bands
     const int cap = p.grid_cap > 0 ? p.grid_cap : 256;
     const int nb5 = pick_mixed_bands(p, cap);
     if (nb5 >= 0 && p.alpha == 1.0f) {
-      if (p.act == EGV_ACT_NONE && (p.bias || p.residual || p.out_hi)) return launch_big<5, false, EPI_LINEAR, true, true>(p, s, nb5);
-      if (p.act == EGV_ACT_GELU) return launch_big<5, false, EPI_GELU, true, true>(p, s, nb5);
+      if (p.act == EGV_ACT_NONE && (p.bias || p.residual || p.out_hi)) return launch_big<5, false, EPI_LINEAR, 3, true>(p, s, nb5);
+      if (p.act == EGV_ACT_GELU) return launch_big<5, false, EPI_GELU, 3, true>(p, s, nb5);
     }
   }
-  if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
-    if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, F3>(p, s);
-    return launch_big<MF, false, EPI_LINEAR, F3>(p, s);
+  if constexpr (PROD == 6) {
+    // f16f6 instances: the epilogues the forward of the step uses (qkv: bias -> bf16 planes; proj / fc2: bias + residual -> fp32;
+    // fc1: GELU -> f16f6 planes + saved gelu'), nothing else
+    if (p.alpha != 1.0f) return EGV_ERR_ARG;
+    if (p.act == EGV_ACT_NONE && p.out_fmt == 0) return launch_big<MF, false, EPI_LINEAR, 6>(p, s);
+    if (p.act == EGV_ACT_GELU && p.out_fmt == 0) return launch_big<MF, false, EPI_GELU, 6>(p, s);
+    if (p.act == EGV_ACT_GELU && p.out_fmt == 1) {
+      if (!p.out_hi || !p.out_lo || p.residual || p.out_f32 || (p.aux_out && !p.aux_bf16) || p.ldoh % 32 != 0 || p.N % 32 != 0)
+        return EGV_ERR_ARG;
+      return launch_big<MF, false, EPI_GELU_F6, 6>(p, s);
+    }
+    return EGV_ERR_ARG;
+  } else {
+    if (p.out_fmt != 0) return EGV_ERR_ARG;
+    if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
+      if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, PROD>(p, s);
+      return launch_big<MF, false, EPI_LINEAR, PROD>(p, s);
+    }
+    if (p.alpha == 1.0f && p.act == EGV_ACT_GELU) return launch_big<MF, false, EPI_GELU, PROD>(p, s);
+    if (p.alpha == 1.0f && p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD, PROD>(p, s);
+    return launch_big<MF, false, EPI_GENERIC, PROD>(p, s);
   }
-  if (p.alpha == 1.0f && p.act == EGV_ACT_GELU) return launch_big<MF, false, EPI_GELU, F3>(p, s);
-  if (p.alpha == 1.0f && p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD, F3>(p, s);
-  return launch_big<MF, false, EPI_GENERIC, F3>(p, s);
 }
 
 }  // namespace
@@ -1230,7 +1425,8 @@ int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant) {
   static const int f3_env = getenv("EGV_GEMM_F3") ? atoi(getenv("EGV_GEMM_F3")) : 1;
   f3 = f3 && f3_env != 0;
 #endif
-  if (f3) return mf == 5 ? launch_epi<5, false, true>(p, s) : launch_epi<4, false, true>(p, s);
+  if (p.passes == 2) return launch_epi<4, false, 6>(p, s);      // f16f6: 256-row tiles (8 registers per MXFP6 slot)
+  if (f3) return mf == 5 ? launch_epi<5, false, 3>(p, s) : launch_epi<4, false, 3>(p, s);
   if (mf == 5) return launch_epi<5, false>(p, s);
   return launch_epi<4, false>(p, s);
 }

@@ -249,8 +249,9 @@ static int gemm_variant(const egv_gemm_desc& p) {
 extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const egv_gemm_desc& p = *d;
   if (!p.a_hi || !p.b_hi) return EGV_ERR_ARG;
-  if (p.passes != 1 && p.passes != 3) return EGV_ERR_ARG;
-  if (p.passes == 3 && (!p.a_lo || !p.b_lo)) return EGV_ERR_ARG;
+  if (p.passes != 1 && p.passes != 2 && p.passes != 3) return EGV_ERR_ARG;
+  if (p.passes >= 2 && (!p.a_lo || !p.b_lo)) return EGV_ERR_ARG;
+  if (p.out_fmt != 0 && p.out_fmt != 1) return EGV_ERR_ARG;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EGV_ERR_ARG;
   if (p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return EGV_ERR_ARG;
   if (!p.trans && p.K % BK != 0) return EGV_ERR_ARG;
@@ -260,6 +261,9 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const int variant = gemm_variant(p);
   if (variant < 0) return EGV_ERR_ARG;
   if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // bf16 aux: gemm_big GELU epilogues only
+  // f16f6 operands / outputs (csrc/f6.h): the big-tile NT kernel only, K and lda / ldb in whole 32-element MX blocks
+  if ((p.passes == 2 || p.out_fmt != 0) && (variant < 3 || p.trans || p.passes != 2 || p.K % 32 != 0 || p.lda % 32 != 0 || p.ldb % 32 != 0))
+    return EGV_ERR_ARG;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);

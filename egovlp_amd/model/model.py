@@ -33,7 +33,7 @@ class _ProjFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2d, w, b, relu, ec: ExecContext):
-        P = ec.fwd_passes
+        P = ec.fwd_passes_split
         M, K = x2d.shape
         N = w.shape[0]
         Np = N if N % 32 == 0 else (N + 31) // 32 * 32
@@ -62,7 +62,9 @@ class _ProjFn(torch.autograd.Function):
             ec.poll_backward()          # vid_proj: the first node of the video tower's backward on the main stream
         dy = dy.contiguous() if Np == N else F.pad(dy, (0, Np - N))
         dy_pl = ops.split_f32(dy, Pb)[0]
-        _, dW, db = _lin_bwd(dy_pl, ctx.a, None, Pb, need_dx=False, params=(w,), ec=ec)
+        # a padded (narrow) head slices dW / db below, on this stream: its wgrad must not run on the side stream (the slice copy would
+        # read dW before the side stream's GEMM has written it)
+        _, dW, db = _lin_bwd(dy_pl, ctx.a, None, Pb, need_dx=False, params=(w,), ec=ec, allow_side=(Np == N))
         dx = torch.empty((x2d.shape[0], x2d.shape[1]), dtype=torch.float32, device=dy.device)
         if Np == N:
             wt = ec.wc.get(w, need_t=True)[1]

@@ -76,7 +76,7 @@ class _TextLayerFn(torch.autograd.Function):
         B, L, H, eps, drop = geom          # drop = (attention p, attention seed, ffn p, ffn seed, device seed words | None); p = 0 outside train()
         D = x.shape[-1]
         M = B * L
-        P = ec.fwd_passes
+        P = ec.fwd_passes_split
         wc = ec.wc
         dev = x.device
         x2 = x.contiguous().view(M, D)

@@ -29,17 +29,19 @@ from ..ops import ACT_GELU, ACT_GELU_BWD, ExecContext, Planes
 _LN_DY_PLANES = os.environ.get("EGV_LN_DY_PLANES", "0") == "1"
 
 
-def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, params=(), ec: ExecContext = None):
+def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, params=(), ec: ExecContext = None, allow_side=True):
     """Backward of y = x W^T + b.  `dy` is fp32 [M,N] (split to bf16 planes here, one pass, no transpose) or
     already-split row-major Planes.  The SAME row-major planes feed both gradients: dgrad contracts over N
     (dy . W, weights cached transposed) and wgrad contracts over the M token rows with the TN kernel
     (dy^T x via the CDNA4 transpose read, bias gradient from the same pass).
     `params`: the parameters (weight, bias) the returned dW / db will be accumulated into by autograd; `ec`: the model's
-    execution context (side stream, grid cap).
+    execution context (side stream, grid cap); `allow_side=False`: the caller reads dW / db right away on ITS stream (slices of a
+    padded head), so the weight gradient stays on the current stream.
     -> (dx fp32 [M,K] | None, dW fp32 [N,K], db [N])."""
     ec = ops.DEFAULT if ec is None else ec
     if not isinstance(dy, Planes):
         dy = ops.split_f32(dy, Pb)[0]
+    x_pl = x_pl.bwd()              # an f16f6 forward operand hands over its bf16 plane
     M, K = x_pl.rows, x_pl.cols
     N = dy.cols
     dev = x_pl.hi.device
@@ -49,7 +51,7 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, pa
     # one backward per step): with a gradient already in place it enqueues `grad += dW` on the node's stream, which is not
     # ordered behind the side stream -- such wgrads (gradient accumulation, set_to_none=False) stay on the main stream.
     accumulating = any(p_ is not None and p_.grad is not None for p_ in params)
-    if ec.wgrad_side_stream and not ec.on_text_stream() and not accumulating:
+    if allow_side and ec.wgrad_side_stream and not ec.on_text_stream() and not accumulating:
         with ec.side_stream(dy.hi, dy.lo, x_pl.hi, x_pl.lo, cost=float(M) * N * K):
             dW = torch.empty((N, K), dtype=torch.float32, device=dev)
             db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec)
@@ -115,37 +117,46 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         dev = x.device
         x2 = x.contiguous().view(M, D)
         train = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward; this is the reliable signal
+        Hd = fc1_w.shape[0]
+        # 'f16f6': the LayerNorm -> qkv / fc1 and fc1 -> fc2 hand-overs are in the f16f6 operand format (one fp16 + one block-scaled
+        # MXFP6 product, big-tile kernel only); attention and the proj Linears keep split-bf16 three-product operands (Pa).  Token
+        # counts too small for the big-tile kernel (toy geometries) run the block in bf16x3.
+        if P == 2 and not (D % 32 == 0 and Hd % 32 == 0 and ops.uses_big_gemm(M, 3 * D, D) and ops.uses_big_gemm(M, Hd, D)
+                           and ops.uses_big_gemm(M, D, Hd)):
+            P = 3
+        f6 = P == 2
+        Pa = 3 if f6 else P
+        wf = "f16f6" if f6 else "bf16"
 
-        def W(p):
-            return wc.get(p, need_t=False)[0]
+        def W(p, fmt="bf16"):
+            return wc.get(p, need_t=False, fmt=fmt)[0]
 
         # ---- temporal attention branch (:166-167)
-        n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P)
-        qkv_t = ops.empty_planes(M, 3 * D, P, dev)       # qkv never exists in fp32: the attention kernels read planes
-        ops.gemm_nt(n3, W(tqkv_w), passes=P, bias=tqkv_b, out_planes=qkv_t, ec=ec)
-        a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, P)
+        n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P, want_bf=train)
+        qkv_t = ops.empty_planes(M, 3 * D, Pa, dev)      # qkv never exists in fp32: the attention kernels read planes
+        ops.gemm_nt(n3, W(tqkv_w, wf), passes=P, bias=tqkv_b, out_planes=qkv_t, ec=ec)
+        a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, Pa)
         tr = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(a_t, W(tproj_w), passes=P, bias=tproj_b, residual=x2, out_f32=tr, ec=ec)
+        ops.gemm_nt(a_t, W(tproj_w), passes=Pa, bias=tproj_b, residual=x2, out_f32=tr, ec=ec)
         # ---- spatial attention branch (:168-171)
-        n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P)
-        qkv_s = ops.empty_planes(M, 3 * D, P, dev)
-        ops.gemm_nt(n1, W(sqkv_w), passes=P, bias=sqkv_b, out_planes=qkv_s, ec=ec)
-        a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, P)
+        n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P, want_bf=train)
+        qkv_s = ops.empty_planes(M, 3 * D, Pa, dev)
+        ops.gemm_nt(n1, W(sqkv_w, wf), passes=P, bias=sqkv_b, out_planes=qkv_s, ec=ec)
+        a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, Pa)
         sr = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(a_s, W(sproj_w), passes=P, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
+        ops.gemm_nt(a_s, W(sproj_w), passes=Pa, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
         # ---- MLP (:175, Mlp.forward :46-52), exact-erf GELU fused into the fc1 epilogue
-        n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P)
-        Hd = fc1_w.shape[0]
-        h = ops.empty_planes(M, Hd, P, dev)
+        n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P, want_bf=train)
+        h = ops.empty_planes_f16f6(M, Hd, dev, want_bf=train) if f6 else ops.empty_planes(M, Hd, P, dev)
         # saved for backward: the fp32 pre-activation z in the all-bf16x3 parity mode; when backward runs single-pass bf16
         # anyway, gelu'(z) itself as bf16 -- the epilogue has Phi(z) and phi(z) in registers, the buffer is half the bytes,
         # and the fc2-dgrad epilogue becomes one multiply instead of a second erf evaluation over 77 M elements
         z_dtype = torch.bfloat16 if (ec.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D)) else torch.float32
         z = torch.empty((M, Hd), dtype=z_dtype, device=dev) if train else None
-        ops.gemm_nt(n2, W(fc1_w), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
+        ops.gemm_nt(n2, W(fc1_w, wf), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
                     aux_is_grad=z is not None and z_dtype == torch.bfloat16, ec=ec)
         out = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(h, W(fc2_w), passes=P, bias=fc2_b, residual=sr, out_f32=out, ec=ec)
+        ops.gemm_nt(h, W(fc2_w, wf), passes=P, bias=fc2_b, residual=sr, out_f32=out, ec=ec)
 
         if train:
             ctx.geom, ctx.ec, ctx.P = geom, ec, P
@@ -208,7 +219,7 @@ class _PatchTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, video, geom, ec, proj_w, proj_b, cls_token, pos_embed, temporal_embed):
         B, T, n, P_, D, T_model = geom[:6]
-        Pp = ec.fwd_passes
+        Pp = ec.fwd_passes_split
         wc = ec.wc
         mean, std = geom[6] if len(geom) > 6 else (ops.IMAGENET_MEAN, ops.IMAGENET_STD)
         aug = geom[7] if len(geom) > 7 else None

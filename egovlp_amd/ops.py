@@ -34,8 +34,12 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # the module-level names of earlier rounds (`Precision.set`, `ops.WGRAD_SIDE_STREAM = ...`, `ops.BACKWARD_POLL = ...`,
 # `ops.KERNEL_TIMER`, `ops.set_gemm_grid`) are views of DEFAULT's settings, kept for scripts and tests.  STATE (stream objects,
 # the dirty / queued flags of the wgrad stream, the weight-plane cache) is private to a context and never inherited.
-_PASSES = {"bf16x3": 3, "bf16": 1}
-_PASSES_INV = {3: "bf16x3", 1: "bf16"}
+# "f16f6" (forward only; passes code 2 = its MFMA issue units): the video tower's qkv / fc1 / fc2 Linears run as one fp16 product
+# plus one block-scaled MXFP6 correction product on operands in the f16f6 format (include/egovlp_hip.h, csrc/f6.h); attention, the
+# proj Linears, the patch embedding, the text tower and the heads stay split-bf16 three-product (tests/precision_table.py: which
+# products tolerate what).
+_PASSES = {"bf16x3": 3, "bf16": 1, "f16f6": 2}
+_PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16f6"}
 _HARD_DEFAULTS = {
     "fwd_passes": 3, "bwd_passes": 3,
     # weight-gradient GEMMs on their own HIP stream.  OFF unless the owner of the gradient hooks turns it on (bench.py and
@@ -92,13 +96,20 @@ class ExecContext:
         return self
 
     def set_precision(self, fwd: str = "bf16x3", bwd: Optional[str] = None):
-        """'bf16x3' = split-bf16, three MFMA products, fp32-grade (meets the 1e-3 parity bar); 'bf16' = single pass."""
-        return self.set(fwd_passes=_PASSES[fwd], bwd_passes=_PASSES[bwd if bwd is not None else fwd])
+        """'bf16x3' = split-bf16, three MFMA products, fp32-grade (meets the 1e-3 parity bar); 'bf16' = single pass;
+        'f16f6' (forward only, with a single-pass 'bf16' backward) = fp16 + MXFP6 correction product, ~1.3e-4 on the embeddings."""
+        bwd = bwd if bwd is not None else ("bf16" if fwd == "f16f6" else fwd)
+        if bwd == "f16f6" or (fwd == "f16f6" and bwd != "bf16"):
+            raise ValueError("'f16f6' is a forward format; it pairs with the single-pass 'bf16' backward")
+        return self.set(fwd_passes=_PASSES[fwd], bwd_passes=_PASSES[bwd])
 
     def precision_name(self):
         return _PASSES_INV[self.fwd_passes], _PASSES_INV[self.bwd_passes]
 
     fwd_passes = property(lambda self: self.get("fwd_passes"))
+    # what every forward product OUTSIDE the video blocks' qkv / fc1 / fc2 Linears runs with (patch embedding, text tower, heads,
+    # attention, proj): the f16f6 mode keeps them split-bf16 three-product
+    fwd_passes_split = property(lambda self: 3 if self.get("fwd_passes") == 2 else self.get("fwd_passes"))
     bwd_passes = property(lambda self: self.get("bwd_passes"))
     wgrad_side_stream = property(lambda self: self.get("wgrad_side_stream"))
     text_side_stream = property(lambda self: self.get("text_side_stream"))
@@ -329,10 +340,12 @@ def _need_cuda(*ts):
 
 @dataclass
 class Planes:
-    hi: torch.Tensor                 # bf16 [rows, ld]
-    lo: Optional[torch.Tensor]       # bf16 [rows, ld] or None (passes == 1)
+    hi: torch.Tensor                 # bf16 [rows, ld]                                  | fmt 'f16f6': fp16 [rows, ld]
+    lo: Optional[torch.Tensor]       # bf16 [rows, ld] or None (passes == 1)            | fmt 'f16f6': the MXFP6 slot plane, int16 [rows, ld]
     rows: int
     cols: int                        # logical columns (<= ld)
+    fmt: str = "bf16"                # 'bf16' (split planes) or 'f16f6' (include/egovlp_hip.h: egv_f16f6_encode)
+    bf: Optional[torch.Tensor] = None  # fmt 'f16f6' only: bf16(value) [rows, ld], what the single-pass backward GEMMs read
 
     @property
     def ld(self):
@@ -340,9 +353,17 @@ class Planes:
 
     def float(self):
         v = self.hi[:, : self.cols].float()
-        if self.lo is not None:
+        if self.lo is not None and self.fmt == "bf16":
             v = v + self.lo[:, : self.cols].float()
         return v
+
+    def bwd(self):
+        """The operand view the backward GEMMs take: the planes themselves, or the bf16 copy of an f16f6 operand."""
+        if self.fmt == "bf16":
+            return self
+        if self.bf is None:
+            raise ValueError("this f16f6 operand was produced without its bf16 plane (forward outside a training step)")
+        return Planes(self.bf, None, self.rows, self.cols)
 
 
 def empty_planes(rows, cols, passes, device, ld=None, zero=False):
@@ -351,6 +372,40 @@ def empty_planes(rows, cols, passes, device, ld=None, zero=False):
     hi = mk((rows, ld), dtype=torch.bfloat16, device=device)
     lo = mk((rows, ld), dtype=torch.bfloat16, device=device) if passes == 3 else None
     return Planes(hi, lo, rows, cols)
+
+
+def empty_planes_f16f6(rows, cols, device, want_bf=False):
+    """Uninitialised f16f6 operand planes [rows, cols] (cols % 32 == 0)."""
+    if cols % 32:
+        raise ValueError("f16f6 operands come in whole 32-element MX blocks")
+    hi = torch.empty((rows, cols), dtype=torch.float16, device=device)
+    lo = torch.empty((rows, cols), dtype=torch.int16, device=device)
+    bf = torch.empty((rows, cols), dtype=torch.bfloat16, device=device) if want_bf else None
+    return Planes(hi, lo, rows, cols, "f16f6", bf)
+
+
+def f16f6_encode(x2d: torch.Tensor, want_bf=False) -> Planes:
+    """fp32 [rows, cols] -> f16f6 operand planes (egv_f16f6_encode)."""
+    _need_cuda(x2d)
+    rows, cols = x2d.shape
+    pl = empty_planes_f16f6(rows, cols, x2d.device, want_bf)
+    check(_lib.lib().egv_f16f6_encode(_p(x2d), x2d.stride(0), rows, cols, _p(pl.hi), _p(pl.lo), _p(pl.bf), pl.ld, _stream(x2d)),
+          "egv_f16f6_encode")
+    return pl
+
+
+def f16f6_encode_multi(jobs):
+    """One launch for many weights.  jobs: (x2d [rows, cols] fp32, h16 address, slots address, ldo)."""
+    n = len(jobs)
+    if n == 0:
+        return
+    vp, i64, i32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+    for j in jobs:
+        _need_cuda(j[0])
+    check(_lib.lib().egv_f16f6_encode_multi(n, vp(*[j[0].data_ptr() for j in jobs]), i64(*[j[0].stride(0) for j in jobs]),
+                                            i32(*[j[0].shape[0] for j in jobs]), i32(*[j[0].shape[1] for j in jobs]),
+                                            vp(*[j[1] for j in jobs]), vp(*[j[2] for j in jobs]), i64(*[j[3] for j in jobs]),
+                                            _stream(jobs[0][0])), "egv_f16f6_encode_multi")
 
 
 def zeros(shape, dtype=torch.float32, device="cuda"):
@@ -406,6 +461,11 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     ec = DEFAULT if ec is None else ec
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
+    if (a.fmt == "f16f6") != (passes == 2) or a.fmt != b.fmt:
+        raise ValueError(f"gemm_nt: operand formats {a.fmt} / {b.fmt} do not go with passes = {passes}")
+    out_fmt = 0
+    if out_planes is not None and out_planes.fmt == "f16f6":
+        out_fmt = 1
     if ksplit is None:
         ksplit = auto_ksplit_nt(M, N, K)
     aux = aux_in if aux_in is not None else aux_out
@@ -425,7 +485,8 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
                  _p(out_f32), (out_f32.stride(0) if out_f32 is not None else 0),
                  _p(out_planes.hi) if out_planes is not None else None, _p(out_planes.lo) if out_planes is not None else None,
                  out_planes.ld if out_planes is not None else 0,
-                 ksplit, 0, _p(partial), 0, aux_bf16, None, ec.gemm_grid, 0)
+                 ksplit, 0, _p(partial), 0, aux_bf16, None, ec.gemm_grid, out_fmt,
+                 _p(out_planes.bf) if out_fmt else None)
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * K,
@@ -488,7 +549,7 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
     d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, Kd, passes, 1.0, ACT_NONE, None,
                  None, 0, None, None, 0, _p(out_f32), out_f32.stride(0), None, None, 0,
-                 ksplit, 0, _p(partial), 1, 0, _p(cs), ec.gemm_grid, 0)
+                 ksplit, 0, _p(partial), 1, 0, _p(cs), ec.gemm_grid, 0, None)
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * Kd,
@@ -564,14 +625,24 @@ def relu_split(x2d: torch.Tensor, passes) -> Planes:
 
 # --------------------------------------------------------------------------------------------- LayerNorm
 def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, want_f32=False, want_planes=True,
-                  rows=None, ldx=None):
+                  rows=None, ldx=None, want_bf=False):
     """rows of x2d (optionally x2d + x_add) -> (Planes | None, y_f32 | None, mean, rstd, sum | None).
-    `rows`/`ldx` allow strided row selection (e.g. only the CLS row of every clip)."""
+    `rows`/`ldx` allow strided row selection (e.g. only the CLS row of every clip).
+    passes == 2: the output is written in the f16f6 operand format (`want_bf`: with the bf16 plane the backward reads)."""
     _need_cuda(x2d, gamma, beta)
     cols = x2d.shape[-1]
     rows = x2d.shape[0] if rows is None else rows
     ldx = x2d.stride(0) if ldx is None else ldx
     dev = x2d.device
+    if passes == 2:
+        if x_add is not None or want_sum or want_f32 or not want_planes:
+            raise ValueError("layernorm_fwd: the f16f6 form writes operand planes only")
+        pl = empty_planes_f16f6(rows, cols, dev, want_bf)
+        mean = torch.empty(rows, dtype=torch.float32, device=dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+        check(_lib.lib().egv_layernorm_fwd_f16f6(_p(x2d), ldx, _p(gamma), _p(beta), float(eps), rows, cols, _p(pl.hi), _p(pl.lo),
+                                                 _p(pl.bf), pl.ld, _p(mean), _p(rstd), _stream(x2d)), "egv_layernorm_fwd_f16f6")
+        return pl, None, mean, rstd, None
     pl = empty_planes(rows, cols, passes, dev) if want_planes else None
     yf = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_f32 else None
     mean = torch.empty(rows, dtype=torch.float32, device=dev)

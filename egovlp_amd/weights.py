@@ -22,10 +22,12 @@ def bump_epoch():
 
 
 class _Entry:
-    __slots__ = ("params", "ver", "pl", "tp", "ok_token", "ok_epoch", "ok_vers")
+    __slots__ = ("params", "ver", "pl", "p6", "tp", "ok_token", "ok_epoch", "ok_vers")
 
     def __init__(self, params):
-        self.params, self.ver, self.pl, self.tp = params, None, None, None
+        # pl: split-bf16 planes W[N,K]; p6: the same weight in the f16f6 operand format (forward of the f16f6 mode); tp: split-bf16
+        # W^T[K,N] (dgrad).  An entry owns whichever of the three its callers have asked for so far.
+        self.params, self.ver, self.pl, self.p6, self.tp = params, None, None, None, None
         self.ok_token, self.ok_epoch, self.ok_vers = -1, -1, None
 
     def mark_valid(self, token):
@@ -49,7 +51,13 @@ class _Entry:
     def shapes_ok(self):
         n = sum(p.shape[0] for p in self.params)
         k = self.params[0][0].numel() if self.params[0].dim() > 1 else 1
-        return self.pl is not None and (self.pl.rows, self.pl.cols) == (n, k)
+        own = [x for x in (self.pl, self.p6) if x is not None]
+        if self.tp is not None and (self.tp.rows, self.tp.cols) != (k, n):
+            return False
+        return (bool(own) or self.tp is not None) and all((x.rows, x.cols) == (n, k) for x in own)
+
+    def has(self, need_t, fmt):
+        return (self.p6 if fmt == "f16f6" else self.pl) is not None and (self.tp is not None or not need_t)
 
 
 class WeightCache:
@@ -60,10 +68,10 @@ class WeightCache:
 
     # -- one launch for every stale entry that already owns its planes
     def _refresh_all(self):
-        jobs, done = [], []
+        jobs, jobs6, done = [], [], []
         for ent in self._c.values():
             ver = ent.version()
-            if ent.ver == ver or ent.pl is None or not ent.shapes_ok():
+            if ent.ver == ver or not ent.shapes_ok():
                 continue
             off = 0
             for i, p in enumerate(ent.params):
@@ -71,25 +79,33 @@ class WeightCache:
                 if not w2.is_contiguous():
                     w2 = w2.contiguous()
                 n_i, last = w2.shape[0], i == len(ent.params) - 1
-                hi = ent.pl.hi.data_ptr() + off * ent.pl.ld * 2
-                lo = ent.pl.lo.data_ptr() + off * ent.pl.ld * 2
-                if ent.tp is not None:
-                    thi, tlo = ent.tp.hi.data_ptr() + off * 2, ent.tp.lo.data_ptr() + off * 2
-                    ldt, tcols = ent.tp.ld, (ent.tp.ld - off if last else n_i)
-                else:
-                    thi = tlo = None
-                    ldt, tcols = 0, n_i
-                jobs.append((w2, hi, lo, ent.pl.ld, thi, tlo, ldt, tcols))
+                if ent.pl is not None or ent.tp is not None:
+                    hi = lo = None
+                    ldo = 0
+                    if ent.pl is not None:
+                        hi = ent.pl.hi.data_ptr() + off * ent.pl.ld * 2
+                        lo = ent.pl.lo.data_ptr() + off * ent.pl.ld * 2
+                        ldo = ent.pl.ld
+                    if ent.tp is not None:
+                        thi, tlo = ent.tp.hi.data_ptr() + off * 2, ent.tp.lo.data_ptr() + off * 2
+                        ldt, tcols = ent.tp.ld, (ent.tp.ld - off if last else n_i)
+                    else:
+                        thi = tlo = None
+                        ldt, tcols = 0, n_i
+                    jobs.append((w2, hi, lo, ldo, thi, tlo, ldt, tcols))
+                if ent.p6 is not None:
+                    jobs6.append((w2, ent.p6.hi.data_ptr() + off * ent.p6.ld * 2, ent.p6.lo.data_ptr() + off * ent.p6.ld * 2, ent.p6.ld))
                 off += n_i
             done.append((ent, ver))
         ops.split_f32_multi(jobs)
+        ops.f16f6_encode_multi(jobs6)
         for ent, ver in done:
             ent.ver = ver
 
     def refresh(self):
         """Bring every cached plane set up to date NOW, on the current stream (callers that are about to fork work onto a
         second stream do this first, so that no stream finds a stale entry and refreshes the cache under the other one)."""
-        if any(ent.pl is not None and ent.ver != ent.version() and ent.shapes_ok() for ent in self._c.values()):
+        if any(ent.ver != ent.version() and ent.shapes_ok() for ent in self._c.values()):
             self._refresh_all()
 
     def begin_step(self):
@@ -99,38 +115,49 @@ class WeightCache:
         self.refresh()
         self._token += 1
         for ent in self._c.values():
-            if ent.pl is not None and ent.ver == ent.version():
+            if ent.ver is not None and ent.ver == ent.version():
                 ent.mark_valid(self._token)
 
-    def _get(self, params, need_t: bool):
+    def _get(self, params, need_t: bool, fmt: str = "bf16"):
         key = id(params[0]) if len(params) == 1 else tuple(id(p) for p in params)
         ent = self._c.get(key)
+        out = lambda: (ent.p6 if fmt == "f16f6" else ent.pl, ent.tp)
         if ent is None:
             ent = self._c[key] = _Entry(list(params))
-        elif (ent.tp is not None or not need_t) and ent.still_valid(self._token):
-            return ent.pl, ent.tp
-        if ent.ver == ent.version() and (ent.tp is not None or not need_t):
+        elif ent.has(need_t, fmt) and ent.still_valid(self._token):
+            return out()
+        if ent.ver == ent.version() and ent.has(need_t, fmt):
             ent.mark_valid(self._token)
-            return ent.pl, ent.tp
-        if ent.pl is not None and ent.shapes_ok() and (ent.tp is not None or not need_t):
+            return out()
+        if ent.has(need_t, fmt) and ent.shapes_ok():
             self._refresh_all()                 # stale after an optimizer step: refresh the whole cache in one launch
-            return ent.pl, ent.tp
-        # first use (or the transposed planes are wanted for the first time): allocate and fill this entry alone
+            return out()
+        # first use (or another form of this weight is wanted for the first time): allocate what is missing, fill this entry alone
         w2 = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], dim=0) if len(params) > 1 \
             else params[0].detach().reshape(params[0].shape[0], -1)
-        # planes always carry lo; single-pass GEMMs simply ignore it
-        ent.pl, ent.tp, _ = ops.split_f32(w2, 3, want_rowmajor=True, want_transposed=need_t or ent.tp is not None)
+        if not ent.shapes_ok():
+            ent.pl = ent.p6 = ent.tp = None
+        want_pl = fmt == "bf16" or ent.pl is not None
+        want_t = need_t or ent.tp is not None
+        if want_pl or want_t:
+            # planes always carry lo; single-pass GEMMs simply ignore it
+            pl, tp, _ = ops.split_f32(w2, 3, want_rowmajor=want_pl, want_transposed=want_t)
+            ent.pl = pl if want_pl else None
+            ent.tp = tp
+        if fmt == "f16f6" or ent.p6 is not None:
+            ent.p6 = ops.f16f6_encode(w2.contiguous())
         ent.ver = ent.version()
-        return ent.pl, ent.tp
+        return out()
 
-    def get(self, param: torch.Tensor, need_t: bool):
-        """-> (Planes [N,K], Planes [K,N] | None).  `param` is [N, ...] (conv weights are flattened to [N, K])."""
-        return self._get((param,), need_t)
+    def get(self, param: torch.Tensor, need_t: bool, fmt: str = "bf16"):
+        """-> (Planes [N,K], Planes [K,N] | None).  `param` is [N, ...] (conv weights are flattened to [N, K]).
+        fmt 'f16f6': the [N,K] planes in the f16f6 operand format (the transposed planes are split-bf16 either way)."""
+        return self._get((param,), need_t, fmt)
 
-    def get_cat(self, params, need_t: bool):
+    def get_cat(self, params, need_t: bool, fmt: str = "bf16"):
         """Planes of the row-wise concatenation of several [N_i, K] weights (DistilBERT's q/k/v projections run as ONE
         [3*768, 768] GEMM) -> (Planes [sum N_i, K], Planes [K, sum N_i] | None)."""
-        return self._get(tuple(params), need_t)
+        return self._get(tuple(params), need_t, fmt)
 
     def get_bias_cat(self, biases):
         """The concatenation of several bias vectors (DistilBERT's fused q/k/v projection), rebuilt only when one of them
