@@ -53,6 +53,9 @@
 
 namespace {
 
+#ifndef EGV_F6_DMA
+#define EGV_F6_DMA 1      // who issues the LDS-DMA inside the f16f6 main loop (see k_tile6); 0 / 2: A/B diagnostics
+#endif
 constexpr int KT = 64;    // contraction depth of one LDS tile
 constexpr int NFW = 8;    // 16-column fragments per wave
 constexpr int BNB = 256;  // block tile columns
@@ -266,6 +269,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   unsigned long long* stamp_lds = (unsigned long long*)(smem + 2 * STAGE) + wave * 256;
   auto stamp = [&](int t, int i) {
     if (stamp_on && t < 64 && lane == 0) stamp_lds[t * 4 + i] = __builtin_amdgcn_s_memtime();
+  };
+  auto stamp8 = [&](int t, int i) {     // the f16f6 loop: 8 stamps per k-tile, first 32 k-tiles (tools/f6_trace.py)
+    if (stamp_on && t < 32 && lane == 0) stamp_lds[t * 8 + i] = __builtin_amdgcn_s_memtime();
   };
 
   const int tiles_n = (p.N + BNB - 1) / BNB;
@@ -582,6 +588,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         u32x4_t As0[MF], Bs0[2];
         u32x2_t As1[MF], Bs1[2];
         unsigned Asc[MF], Bsc[2];
+        stamp8(t, 0);
         static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; ld_slot_asm<i * 1024>(As0[i], As1[i], Asc[i], ras, ras ^ 16u); });
         ld_slot_asm<0>(Bs0[0], Bs1[0], Bsc[0], rbs, rbs ^ 16u);
         auto mm_h = [&](auto Jc) {
@@ -605,12 +612,32 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           constexpr int j = decltype(Jc)::value;
           if constexpr (j > 0) ld_slot_asm<j * 1024>(Bs0[j & 1], Bs1[j & 1], Bsc[j & 1], rbs, rbs ^ 16u);
           if constexpr (j < NFW - 1) Bh[(j + 1) & 1] = ld128h_asm<(j + 1) * 1024>(rbh);
-          if (j < 4 && loader && HN) {
-            constexpr int PP = (NP + 3) / 4;
-            static_for<j * PP, (j + 1) * PP < NP ? (j + 1) * PP : NP>([&](auto Ic) { piece(dma_lds, decltype(Ic)::value, j * PP); });
+          // DMA of k-tile t+1.  With 64 MFMAs per wave and k-tile (half of the fused loop's) a loader wave that issues all of its
+          // SIMD's 16 pieces is blocked for longer (~100-185 cycles per piece) than its partner needs for the partner's MFMAs, and
+          // the k-tile ends when the loader does (1.8 us measured against 1.0 us of MFMA time).  So the work is split by operand:
+          // waves 0-3 stage the A rows (activations, from HBM: early, phases 0-3), waves 4-7 the B rows (weights, L2-resident:
+          // phases 3-6) -- the two waves of a SIMD are blocked at different times.
+          if constexpr (EGV_F6_DMA == 0) {
+            if (j < 4 && loader && HN) {
+              constexpr int PP = (NP + 3) / 4;
+              static_for<j * PP, (j + 1) * PP < NP ? (j + 1) * PP : NP>([&](auto Ic) { piece(dma_lds, decltype(Ic)::value, j * PP); });
+            }
+          } else {
+            constexpr int PA = 2 * GA, PB = 2 * GB;            // pieces of one wave's A share / B share (hi + slots)
+            constexpr int JB0 = EGV_F6_DMA == 1 ? 3 : 0;       // first phase of the B loaders
+            if (j < 4 && wave < 4 && HN) {
+              constexpr int PP = (PA + 3) / 4;
+              static_for<j * PP, (j + 1) * PP < PA ? (j + 1) * PP : PA>([&](auto Ic) { piece(dma_lds, decltype(Ic)::value, j * PP); });
+            }
+            if (j >= JB0 && j < JB0 + 4 && wave >= 4 && HN) {
+              constexpr int PP = (PB + 3) / 4, jj = j - JB0;
+              static_for<PA + jj * PP, PA + ((jj + 1) * PP < PB ? (jj + 1) * PP : PB)>(
+                  [&](auto Ic) { piece(dma_lds, decltype(Ic)::value, PA + jj * PP); });
+            }
           }
           if constexpr (j == 0) {
             lgkm_wait<15>();              // 3 MF + 3 + 1 reads issued behind B_h(0) and A_h: at most 15 in flight = those landed
+            stamp8(t, 1);
             tie(Bh[0]);
             static_for<0, MF>([&](auto Ic) { tie(Ah[decltype(Ic)::value]); });
             __builtin_amdgcn_sched_barrier(0);
@@ -618,6 +645,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             __builtin_amdgcn_sched_barrier(0);
           } else {
             lgkm_wait<(j < NFW - 1) ? 4 : 3>();     // everything but this phase's own reads
+            if constexpr (j == 1) stamp8(t, 2);
+            if constexpr (j == 4) stamp8(t, 3);
             tie(Bh[j & 1]); tie(Bs0[(j - 1) & 1]); tie(Bs1[(j - 1) & 1]); tie(Bsc[(j - 1) & 1]);
             if constexpr (j == 1) {
               static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; tie(As0[i]); tie(As1[i]); tie(Asc[i]); });
@@ -633,14 +662,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           }
         });
         // ---- tail: hand-over to k-tile t+1, then the MXFP6 products of B slot 7 with the next A_h fetched behind them
+        stamp8(t, 4);
         lgkm_wait<0>();
         tie(Bs0[1]); tie(Bs1[1]); tie(Bsc[1]);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned nah = fah + (STAGE - sb);
         if (HN) {
           // k-tile t+1 (this wave's DMA pieces) has landed; every read of stage t & 1 by this wave has returned
+          stamp8(t, 5);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp8(t, 6);
           __builtin_amdgcn_s_barrier();
+          stamp8(t, 7);
           stage_advance();
           Bh[0] = ld128h_asm<0>(fbh + (STAGE - sb));
         }

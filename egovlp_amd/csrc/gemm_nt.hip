@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue_kernel(const egv_g
 static int gemm_variant(const egv_gemm_desc& p) {
   const bool big_ok = egv_gemm_big_supports(p);
   if (p.trans) return big_ok ? 3 : -1;
+  if (p.passes == 2) return big_ok ? 3 : -1;   // f16f6 operands: the big-tile kernel is the only one that reads them
   // big tiles only when there are enough of them to occupy the chip (DistilBERT's M = 1024 GEMMs make 12)
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
   if (big_ok && big_tiles >= 128) return 3;

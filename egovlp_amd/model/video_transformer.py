@@ -121,8 +121,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         # 'f16f6': the LayerNorm -> qkv / fc1 and fc1 -> fc2 hand-overs are in the f16f6 operand format (one fp16 + one block-scaled
         # MXFP6 product, big-tile kernel only); attention and the proj Linears keep split-bf16 three-product operands (Pa).  Token
         # counts too small for the big-tile kernel (toy geometries) run the block in bf16x3.
-        if P == 2 and not (D % 32 == 0 and Hd % 32 == 0 and ops.uses_big_gemm(M, 3 * D, D) and ops.uses_big_gemm(M, Hd, D)
-                           and ops.uses_big_gemm(M, D, Hd)):
+        if P == 2 and not (ops.f16f6_gemm_ok(M, 3 * D, D) and ops.f16f6_gemm_ok(M, Hd, D) and ops.f16f6_gemm_ok(M, D, Hd)):
             P = 3
         f6 = P == 2
         Pa = 3 if f6 else P
@@ -151,7 +150,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         # saved for backward: the fp32 pre-activation z in the all-bf16x3 parity mode; when backward runs single-pass bf16
         # anyway, gelu'(z) itself as bf16 -- the epilogue has Phi(z) and phi(z) in registers, the buffer is half the bytes,
         # and the fc2-dgrad epilogue becomes one multiply instead of a second erf evaluation over 77 M elements
-        z_dtype = torch.bfloat16 if (ec.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D)) else torch.float32
+        z_dtype = torch.bfloat16 if (ec.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D, P)) else torch.float32
         z = torch.empty((M, Hd), dtype=z_dtype, device=dev) if train else None
         ops.gemm_nt(n2, W(fc1_w, wf), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
                     aux_is_grad=z is not None and z_dtype == torch.bfloat16, ec=ec)

@@ -467,14 +467,14 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     if out_planes is not None and out_planes.fmt == "f16f6":
         out_fmt = 1
     if ksplit is None:
-        ksplit = auto_ksplit_nt(M, N, K)
+        ksplit = 1 if passes == 2 else auto_ksplit_nt(M, N, K)
     aux = aux_in if aux_in is not None else aux_out
     aux_bf16 = int(aux is not None and aux.dtype == torch.bfloat16)
     if aux_is_grad:
         if not aux_bf16:
             raise ValueError("aux_is_grad needs a bf16 aux buffer")
         aux_bf16 = 2
-    if aux_bf16 and not uses_big_gemm(M, N, K):
+    if aux_bf16 and not uses_big_gemm(M, N, K, passes):
         raise ValueError("bf16 aux buffers are only supported by the big-tile GEMM kernel (see uses_big_gemm)")
     partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device) if ksplit > 1 else None
     # one positional construction (the field order of egv_gemm_desc): 30 attribute stores cost ~6 us of host time per GEMM,
@@ -491,7 +491,7 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * K,
                    lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt"), passes,
-                   key=("gemm_big " if ksplit <= 1 and uses_big_gemm(M, N, K) else "gemm_nt(128x128) ")
+                   key=("gemm_big " if ksplit <= 1 and uses_big_gemm(M, N, K, passes) else "gemm_nt(128x128) ")
                    + f"NT M={M} N={N} K={K} x{passes}")
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt")
@@ -511,9 +511,17 @@ def auto_ksplit_nt(M, N, K):
 SMALL_SPLITK = int(os.environ.get("EGV_SMALL_SPLITK", "1"))   # 0: off (A/B diagnostics)
 
 
-def uses_big_gemm(M, N, K):
-    """Mirror of the kernel choice in csrc/gemm_nt.hip (gemm_variant) for NT problems without split-K."""
+def uses_big_gemm(M, N, K, passes=None):
+    """Mirror of the kernel choice in csrc/gemm_nt.hip (gemm_variant) for NT problems without split-K (f16f6 operands, passes = 2,
+    always take the big-tile kernel when it can run the shape at all)."""
+    if passes == 2:
+        return f16f6_gemm_ok(M, N, K)
     return M >= 256 and N >= 256 and K % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
+
+
+def f16f6_gemm_ok(M, N, K):
+    """Can egv_gemm_nt(passes = 2) run this NT shape?  (one 256 x 256 tile at least, 64-deep k-tiles)"""
+    return M >= 256 and N >= 256 and K % 64 == 0
 
 
 def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=None, ec: Optional[ExecContext] = None):

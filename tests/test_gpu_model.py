@@ -22,6 +22,9 @@ from egovlp_amd.synth import synth_batch, synth_state_dict  # noqa: E402
 from oracle import egovlp_oracle as O  # noqa: E402
 
 PARITY = 1e-3
+# The f16f6 forward (fp16 + MXFP6 correction product in the video blocks' qkv / fc1 / fc2 Linears) is held to HALF the
+# bar: tests/precision_table.py predicts 1.3e-4 .. 1.7e-4 on the embeddings (ViT-L, the worst case), a 2x margin is asserted.
+F6_BAR = 5e-4
 
 
 def rel(a, b):
@@ -153,6 +156,51 @@ def test_full_model_golden_in_the_benchmarked_mixed_mode(full, golden_dir):
                 print("  mixed grad %-55s slice rel %.2e norm rel %.2e" % (name, r1, r2))
                 assert r1 < MIXED_GRAD and r2 < MIXED_GRAD, name
         print("full B=4 mixed: worst sentinel-gradient rel %.2e" % worst)
+    finally:
+        Precision.set("bf16x3")
+        for p_ in m.parameters():
+            p_.grad = None
+        m.train()
+
+
+def test_full_model_golden_in_the_f16f6_mode(full, golden_dir):
+    """The f16f6 forward (+ single-pass bf16 backward) against the reference's golden vectors at B = 4 (M = 3140 tokens: every
+    qkv / fc1 / fc2 GEMM of the 12 blocks runs the fp16 + MXFP6 product): embeddings and losses inside F6_BAR, gradients inside
+    MIXED_GRAD (the backward is the mixed mode's)."""
+    from egovlp_amd import ops
+    from egovlp_amd.model.loss import EgoNCE, NormSoftmaxLoss
+    from egovlp_amd.ops import Precision
+    m, sd = full
+    g = np.load(os.path.join(golden_dir, "full_b4.npz"))
+    batch = synth_batch(4, T=4, L=32, seed=1234, ragged=True)
+    assert ops.f16f6_gemm_ok(4 * 785, 2304, 768) and ops.f16f6_gemm_ok(4 * 785, 768, 3072)
+    try:
+        Precision.set("f16f6")
+        assert Precision.name() == ("f16f6", "bf16")
+        m.eval()
+        d = to_dev(batch)
+        te, ve = m(d)
+        r_t, r_v = rel(te, g["text_embeds"]), rel(ve, g["video_embeds"])
+        ego = EgoNCE().fused(te, ve, d["noun_vec"], d["verb_vec"])
+        nce = NormSoftmaxLoss().fused(te, ve)
+        r_e, r_n = abs(float(ego) - float(g["egonce"])) / abs(float(g["egonce"])), abs(float(nce) - float(g["infonce"])) / abs(float(g["infonce"]))
+        print("full B=4 f16f6: text rel %.2e video rel %.2e egonce rel %.2e infonce rel %.2e" % (r_t, r_v, r_e, r_n))
+        assert r_t < F6_BAR and r_v < F6_BAR and r_e < F6_BAR and r_n < F6_BAR
+        te.retain_grad(); ve.retain_grad()
+        ego.backward()
+        assert rel(te.grad, g["grad_text_embeds"]) < PARITY and rel(ve.grad, g["grad_video_embeds"]) < PARITY
+        params = dict(m.named_parameters())
+        worst = 0.0
+        for key in g.files:
+            if key.startswith("grad:"):
+                name = key[5:]
+                gr = params[name].grad
+                g2 = gr.reshape(gr.shape[0], -1) if gr.dim() > 1 else gr.reshape(1, -1)
+                r1 = rel(g2[:8, :64], g[key])
+                r2 = abs(float(gr.norm()) / float(g["gradnorm:" + name]) - 1)
+                worst = max(worst, r1)
+                assert r1 < MIXED_GRAD and r2 < MIXED_GRAD, (name, r1, r2)
+        print("full B=4 f16f6: worst sentinel-gradient rel %.2e" % worst)
     finally:
         Precision.set("bf16x3")
         for p_ in m.parameters():
@@ -382,8 +430,12 @@ def test_full_size_train_step_matches_oracle_on_the_whole_batch(full):
     dev = to_dev(batch)
     params = dict(m.named_parameters())
     try:
-        for mode, gbound in (("bf16x3", 3 * PARITY), ("mixed", MIXED_GRAD)):
-            Precision.set("bf16x3", "bf16" if mode == "mixed" else "bf16x3")
+        for mode, gbound in (("bf16x3", 3 * PARITY), ("mixed", MIXED_GRAD), ("f16f6", MIXED_GRAD)):
+            if mode == "f16f6":
+                Precision.set("f16f6")
+            else:
+                Precision.set("bf16x3", "bf16" if mode == "mixed" else "bf16x3")
+            fbar = F6_BAR if mode == "f16f6" else PARITY
             for p_ in m.parameters():
                 p_.grad = None
             te, ve = m(dev)
@@ -393,7 +445,7 @@ def test_full_size_train_step_matches_oracle_on_the_whole_batch(full):
             r_t, r_v, r_l = rel(te, rt), rel(ve, rv), abs(float(loss) - float(rl)) / abs(float(rl))
             print("B=32 %s: text rel %.2e video rel %.2e loss rel %.2e | d_text %.2e d_video %.2e" % (
                 mode, r_t, r_v, r_l, rel(te.grad, rt.grad), rel(ve.grad, rv.grad)))
-            assert r_t < PARITY and r_v < PARITY and r_l < PARITY
+            assert r_t < fbar and r_v < fbar and r_l < fbar
             assert rel(te.grad, rt.grad) < PARITY and rel(ve.grad, rv.grad) < PARITY      # the contrastive head is fp32 in every mode
             for name in sentinels:
                 r = rel(params[name].grad, sdo[name].grad)
@@ -405,14 +457,18 @@ def test_full_size_train_step_matches_oracle_on_the_whole_batch(full):
             p_.grad = None
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16f6"])
 @pytest.mark.parametrize("name,arch,T,model_frames", [("config4_T16", "base_patch16_224", 16, 16), ("config5_vitl14", "large_patch14_224", 4, 4)])
-def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T, model_frames):
+def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T, model_frames, mode, request):
     """BASELINE configs 4 (16 frames) and 5 (ViT-L/14) through the FULL dual encoder + EgoNCE at B = 2: embeddings, loss,
-    embedding gradients and two weight gradients vs the CPU oracle, parity mode."""
+    embedding gradients and two weight gradients vs the CPU oracle, in the parity mode (1e-3 / 3e-3) and in the f16f6 mode
+    (forward inside F6_BAR -- ViT-L's 24 blocks are the format's worst case --, gradients inside MIXED_GRAD)."""
     from egovlp_amd.model.loss import EgoNCE
     from egovlp_amd.model.model import FrozenInTime
     from egovlp_amd.ops import Precision
-    Precision.set("bf16x3")
+    Precision.set(mode)
+    request.addfinalizer(lambda: Precision.set("bf16x3"))
+    fbar, gbar = (F6_BAR, MIXED_GRAD) if mode == "f16f6" else (PARITY, 3 * PARITY)
     m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": arch, "num_frames": model_frames,
                                    "pretrained": True, "time_init": "rand"},
                      text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
@@ -439,13 +495,13 @@ def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T
     rl.backward()
     errs = {"text": rel(te, rt), "video": rel(ve, rv), "loss": abs(float(loss) - float(rl)) / abs(float(rl)),
             "d_text": rel(te.grad, rt.grad), "d_video": rel(ve.grad, rv.grad)}
-    print(name, {k: "%.2e" % v for k, v in errs.items()})
-    assert all(v < PARITY for v in errs.values()), errs
+    print(name, mode, {k: "%.2e" % v for k, v in errs.items()})
+    assert all(errs[k] < fbar for k in ("text", "video", "loss")) and errs["d_text"] < PARITY and errs["d_video"] < PARITY, errs
     params = dict(m.named_parameters())
     for w in watch:
         r = rel(params[w].grad, sdo[w].grad)
-        print("  %s grad %-45s rel %.2e" % (name, w, r))
-        assert r < 3 * PARITY, (w, r)
+        print("  %s %s grad %-45s rel %.2e" % (name, mode, w, r))
+        assert r < gbar, (w, r)
 
 
 @pytest.mark.parametrize("which", ["wgrad", "text", "both"])
@@ -548,9 +604,10 @@ def test_adamw_overlapped_with_backward_is_bit_identical(full):
         m.eval()
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16f6"])
 @pytest.mark.parametrize("name,arch,T,model_frames", [("config4_T16_B16", "base_patch16_224", 16, 16),
                                                       ("config5_vitl14_B16", "large_patch14_224", 4, 4)])
-def test_other_baseline_configs_at_full_size_match_oracle_rows_and_their_halves(name, arch, T, model_frames):
+def test_other_baseline_configs_at_full_size_match_oracle_rows_and_their_halves(name, arch, T, model_frames, mode, request):
     """BASELINE configs 4 (T = 16: M = 16 x 3137 = 50 192 tokens) and 5 (ViT-L/14: M = 16 x 1025 = 16 400 tokens, the 640-deep
     zero-padded patch GEMM at its full 16 384 rows) at the BENCHMARKED batch B = 16 -- the tile counts, quantisation and split-K
     factors bench.py really runs (round-2 verdict, weak #2: these configs were compared with the oracle at B = 1..2 only).
@@ -559,7 +616,9 @@ def test_other_baseline_configs_at_full_size_match_oracle_rows_and_their_halves(
     loss on the device embeddings' oracle counterparts for the checked rows' sub-batch."""
     from egovlp_amd.model.model import FrozenInTime
     from egovlp_amd.ops import Precision
-    Precision.set("bf16x3")
+    Precision.set(mode)
+    request.addfinalizer(lambda: Precision.set("bf16x3"))
+    fbar = F6_BAR if mode == "f16f6" else PARITY
     m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": arch, "num_frames": model_frames,
                                    "pretrained": True, "time_init": "rand"},
                      text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
@@ -589,11 +648,12 @@ def test_other_baseline_configs_at_full_size_match_oracle_rows_and_their_halves(
             ref_t.append(rt); ref_v.append(rv)
             e = max(rel(te[r:r + 1], rt), rel(ve[r:r + 1], rv))
             worst = max(worst, e)
-            assert e < PARITY, (name, r, e)
+            assert e < fbar, (name, mode, r, e)
     # the contrastive head on those rows: device embeddings vs oracle embeddings through the same oracle loss
     idx = torch.tensor(rows)
     l_dev, _ = O.egoclip_loss(te[idx].cpu(), ve[idx].cpu(), batch["noun_vec"][idx], batch["verb_vec"][idx])
     l_ref, _ = O.egoclip_loss(torch.cat(ref_t), torch.cat(ref_v), batch["noun_vec"][idx], batch["verb_vec"][idx])
     r_l = abs(float(l_dev) - float(l_ref)) / abs(float(l_ref))
-    print("%s: rows vs oracle worst rel %.2e | halves text %.2e video %.2e | loss rel %.2e" % (name, worst, r_ht, r_hv, r_l))
-    assert r_ht < 1e-4 and r_hv < 1e-4 and r_l < PARITY
+    print("%s %s: rows vs oracle worst rel %.2e | halves text %.2e video %.2e | loss rel %.2e" % (name, mode, worst, r_ht, r_hv, r_l))
+    # other tile counts: summation order only in bf16x3 (~2e-5); f16f6 has no batch-dependent rounding either (blocks run along k)
+    assert r_ht < 1e-4 and r_hv < 1e-4 and r_l < fbar
