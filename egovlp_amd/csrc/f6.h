@@ -7,13 +7,15 @@
 // HBM / LDS layout.  An operand [rows, K] (K % 32 == 0) is TWO planes of 2 bytes per element each -- the same sizes and leading
 // dimensions as the split-bf16 (hi, lo) pair it replaces, so the LDS-DMA staging of gemm_big is unchanged:
 //   plane 0 ("hi")   : fp16 [rows, ld]
-//   plane 1 ("slots"): per row and per 32-element block b, 64 bytes at byte offset (row * ld + 32 b) * 2:
-//        [ c6: 24 B codes | scale byte | 7 B pad ][ l6: 24 B codes | scale byte | 7 B pad ]
-//     codes: element i of the block at bits [6 i, 6 i + 6) little-endian (the register image the MFMA reads, 6 dwords);
+//   plane 1 ("slots"): per row and per 32-element block b, 64 bytes at byte offset (row * ld + 32 b) * 2, four 16-byte chunks:
+//        chunk 0: c6 codes bytes 0-15 | chunk 1: l6 codes bytes 0-15 | chunk 2: c6 codes bytes 16-23, c6 scale byte, 7 B pad |
+//        chunk 3: l6 codes bytes 16-23, l6 scale byte, 7 B pad
+//     codes: element i of the block at bits [6 i, 6 i + 6) little-endian of the 24 bytes (the register image the MFMA reads);
 //     scale byte e (E8M0): element value = code value x 2^(e - 127), e = ceil(log2(amax / 7.5)) + 127 (no saturation).
-// A lane of the MFMA (row = lane & 15, k-group g = lane >> 4) fetches ONE 32-byte slot with two ds_read_b128: dwords 0-5 are the
-// operand, byte 0 of dword 6 is its scale (op_sel 0).  Per 32-deep k-tile only groups 0 and 1 carry data (c6.l6 and l6.c6); lanes
-// 32-63 hold zeros.
+// A lane of the MFMA (row = lane & 15, k-group g = lane >> 4) fetches ONE slot (c6 or l6) with two ds_read_b128 -- chunks (0, 2) or
+// (1, 3): k-group g reading chunk g first is the access pattern the 64-byte-row LDS image of gemm_big is conflict-free for --
+// dwords 0-5 of the 8 are the operand, byte 0 of dword 6 its scale (op_sel 0).  Per 32-deep k-tile only groups 0 and 1 carry data
+// (c6.l6 and l6.c6); lanes 32-63 are switched off through their scale.
 //
 // E2M3 codes come from the hardware fp32 -> E4M3 converter: the four lowest binades of OCP E4M3 (subnormals and exponents 1-3:
 // spacings 2^-9, 2^-9, 2^-8, 2^-7 from 0 to 7.5 x 2^-6) are E2M3's grid (spacings 1/8, 1/8, 1/4, 1/2 from 0 to 7.5) scaled by 2^-6, so
@@ -67,12 +69,12 @@ __device__ __forceinline__ void f6_codes8(const float (&y)[8], float pre, unsign
 //   h16  : 8 x fp16 (16 B at element offset of v[0] in plane 0)
 //   bf   : 8 x bf16 of v (the single-pass operand of the backward GEMMs), 16 B
 //   piece: this lane's share of the 64-byte slot pair -- even lanes hold c6 codes, odd lanes l6 codes, of THEIR lane pair
-//          (16 elements = 96 bits = dwords 0..2); dword 3 = the scale byte.  Byte offset inside the slot pair: f6_piece_offset(lane);
-//          lanes 0, 1 of a quad store 12 bytes (dwords 0..2), lanes 2, 3 store all 16 (their dword 3 lands on slot byte 24).
+//          (16 elements = 96 bits = dwords 0..2); dword 3 = the scale byte.  f6_store_piece puts it where the layout above wants it:
+//          lanes 0, 1 of a quad own code bytes 0-11 (chunk 0 / 1), lanes 2, 3 code bytes 12-15 (end of chunk 0 / 1) and 16-23 +
+//          the scale (start of chunk 2 / 3).
 struct F6Lane {
   u32x4_t h16, bf, piece;
 };
-__device__ __forceinline__ int f6_piece_offset(int lane) { return ((lane & 1) << 5) + ((lane & 2) ? 12 : 0); }
 
 __device__ __forceinline__ F6Lane f6_encode8(const float (&v)[8], int lane) {
   F6Lane o;
@@ -108,10 +110,13 @@ __device__ __forceinline__ F6Lane f6_encode8(const float (&v)[8], int lane) {
   return o;
 }
 
-// store a lane's piece: 12 bytes from lanes 0, 1 of the quad, 16 bytes (with the scale dword) from lanes 2, 3
 template <int SITE>
 __device__ __forceinline__ void f6_store_piece(char* slot_pair, int lane, const u32x4_t& piece) {
-  char* d = slot_pair + f6_piece_offset(lane);
-  if (lane & 2) egv_store<SITE>(d, piece);
-  else egv_store<SITE>(d, (u32x3_t){piece[0], piece[1], piece[2]});
+  char* d = slot_pair + ((lane & 1) << 4);
+  if (lane & 2) {
+    egv_store<SITE>(d + 12, piece[0]);
+    egv_store<SITE>(d + 32, (u32x3_t){piece[1], piece[2], piece[3]});
+  } else {
+    egv_store<SITE>(d, (u32x3_t){piece[0], piece[1], piece[2]});
+  }
 }

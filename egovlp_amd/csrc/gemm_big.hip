@@ -131,19 +131,18 @@ __device__ __forceinline__ f16x8_t ld128h_asm(unsigned addr) {
 // would cost the LDS as much again).  Their registers keep whatever they held; they are taken out of the product through the
 // SCALE operand instead (slot_scale: E8M0 byte 0 = 2^-127 on both sides, 2^-254 x anything an E2M3 block can sum to is 0 in fp32).
 // a0 / a1: the two 16-B chunks of the slot (their order in LDS depends on the row's chunk permutation, so two addresses).
-// Three reads (dwords 0-3, dwords 4-5, the scale dword): the MFMA operand is a 6-register tuple, and only WHOLE virtual registers
-// (a 128-bit and a 64-bit one) coalesce into it without copies.
+// Two 16-byte reads (chunks s and s + 2 of the row, csrc/f6.h); the MFMA operand is the 8-register tuple of the two results side by
+// side (FP6 reads its first 6 dwords), which the register coalescer forms without copies from two whole 128-bit values as long
+// as they are defined and dead inside one loop iteration.
 template <int OFF>
-__device__ __forceinline__ void ld_slot_asm(u32x4_t& s0, u32x2_t& s1, unsigned& sc, unsigned a0, unsigned a1) {
-  asm volatile("s_mov_b32 exec_hi, 0\n\tds_read_b128 %0, %3 offset:%5\n\tds_read_b64 %1, %4 offset:%5\n\tds_read_b32 %2, %4 offset:%5+8\n\t"
-               "s_mov_b32 exec_hi, -1"
-               : "=&v"(s0), "=&v"(s1), "=&v"(sc)
+__device__ __forceinline__ void ld_slot_asm(u32x4_t& s0, u32x4_t& s1, unsigned a0, unsigned a1) {
+  asm volatile("s_mov_b32 exec_hi, 0\n\tds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_mov_b32 exec_hi, -1"
+               : "=&v"(s0), "=&v"(s1)
                : "v"(a0), "v"(a1), "i"(OFF));
 }
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
-// the operand the MFMA reads (dwords 0-5 of the 8; FP6 ignores the rest)
-__device__ __forceinline__ i32x8_t slot_operand(const u32x4_t& s0, const u32x2_t& s1) {
-  return (i32x8_t){(int)s0[0], (int)s0[1], (int)s0[2], (int)s0[3], (int)s1[0], (int)s1[1], 0, 0};
+__device__ __forceinline__ i32x8_t slot_operand(const u32x4_t& s0, const u32x4_t& s1) {
+  return __builtin_bit_cast(i32x8_t, __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ void tie(u32x2_t& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void anchor(const f32x4_t& x) { asm volatile("" ::"v"(x)); }   // "x exists here": stops code sinking
@@ -557,27 +556,30 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       // Per 32-deep k-tile and fragment pair: ONE fp16 MFMA (A_h . B_h) and ONE block-scaled MXFP6 MFMA whose k-group 0 multiplies
       // c6(A) . l6(B) and k-group 1 l6(A) . c6(B) (groups 2, 3 = lanes 32-63: scale 0) -- 2 issue units where bf16x3 spends 3
       // (measured: 31.3 vs 48.0 ns per fragment and k-tile, tools/mx_probe.hip).  The stage layout and the DMA are the fused
-      // loop's: "hi" rows are 32 fp16, "lo" rows the 64-byte slot pair [c6 | l6] of the block.
-      // Phase j (0..7) runs the fp16 products of B fragment j and the MXFP6 products of B slot j - 1 (one phase behind; slot 7 in
-      // a tail after the hand-over), each against the MF resident A sets.  The fp16 fragments are prefetched across k-tiles as in
-      // the fused loop; the SLOTS are fetched and consumed inside one k-tile (A slots and B slot 0 at its top, B slot j in phase
-      // j): a slot is a 6-register MFMA operand assembled from a 128-bit and a 64-bit read, and only values that are defined and
-      // dead within one loop iteration coalesce into that tuple without copies (loop-carried ones cost ~350 moves and 100 spills).
-      // Reads complete in issue order; waits count the reads issued behind the ones needed (lgkmcnt saturates at 15):
-      //   top:      A slots (3 MF), B slot 0 (3)                   [in flight from the previous k-tile: B_h(0), A_h (1 + MF)]
-      //   phase 0:  B_h(1)            | wait 15 -> the 1 + MF oldest landed | fp16(0)
-      //   phase j:  B slot j, B_h(j+1) | wait 4                             | fp16(j), mx6(j-1)          (j = 7: no B_h, wait 3)
-      //   tail:     wait 0, hand-over (barrier), B_h(0)' , mx6(7) with A_h' fetched behind its MFMAs
+      // loop's: "hi" rows are 32 fp16, "lo" rows the 64-byte slot pair of the block.
+      // Phase j (0..7) runs the fp16 products of B fragment j and the MXFP6 products of B slot j - 2 (two phases behind; slots 6, 7
+      // in a tail that overlaps the hand-over), each against the MF resident A sets.  The fp16 fragments are prefetched across
+      // k-tiles as in the fused loop; the SLOTS are fetched and consumed inside one k-tile: a slot is an MFMA operand tuple
+      // assembled from two reads, and only values that are defined and dead within one loop iteration coalesce into that tuple
+      // without copies (loop-carried ones cost ~350 moves and 100 spills).  A k-tile of this loop has half the MFMA work of the
+      // fused loop's, so what it cannot afford is the burst of LDS reads all eight waves issue right behind the k-tile barrier
+      // with the matrix pipes idle (first version: 470-750 of 4150 cycles per k-tile, profiles/r04c_f6_ktile_stamps_*.txt):
+      // the A slots are fetched one behind each fp16 MFMA of phase 0 and first used in phase 2.
+      // Reads complete in issue order; waits count the reads issued behind the ones needed:
+      //   phase 0:  B slot 0 (2), B_h(1)   | wait 3  -> B_h(0), A_h (in flight from the previous tail) | fp16(0) + A slot i behind MFMA i
+      //   phase 1:  B slot 1, B_h(2)       | wait 11 -> B_h(1)                                         | fp16(1)
+      //   phase j:  B slot j, B_h(j+1)     | wait 3  -> B_h(j), B slot j-2, (j = 2: the A slots)       | fp16(j), mx6(j-2)      (j = 7: wait 2)
+      //   tail:     wait 0, hand-over (barrier), B_h(0)', mx6(6) with A_h' fetched behind its MFMAs, mx6(7)
       f16x8_t Ah[MF], Bh[2];
       unsigned lmask = lane < 32 ? 0xffu : 0u;            // lanes 32-63: scale byte 0 (see ld_slot_asm)
       asm volatile("" : "+v"(lmask));
-      // this lane's slot: row (lane & 15) of the fragment, source chunks {0, 1} (c6) or {2, 3} (l6) of the 64-B row; LDS position
+      // this lane's slot: row (lane & 15) of the fragment, chunks (s, s + 2) of the 64-B row with s = 0 (c6) or 1 (l6); LDS position
       // of source chunk s in row r is s ^ g((r >> 2) & 3).  A side: k-group 0 reads c6, k-group 1 l6; B side the other way round.
       const int gg6 = (0x78 >> (2 * ((lane >> 2) & 3))) & 3;
       const int kg = (lane >> 4) & 1;
       const unsigned fah = lds0 + a_rd0, fbh = lds0 + b_rd0;
-      const unsigned fas = lds0 + F3_ALO + (wm * MF * 16 + (lane & 15)) * 64 + (((2 * kg) ^ gg6) << 4);
-      const unsigned fbs = lds0 + F3_B + F3_BLO + (wn * 128 + (lane & 15)) * 64 + (((2 * (1 - kg)) ^ gg6) << 4);
+      const unsigned fas = lds0 + F3_ALO + (wm * MF * 16 + (lane & 15)) * 64 + ((kg ^ gg6) << 4);
+      const unsigned fbs = lds0 + F3_B + F3_BLO + (wn * 128 + (lane & 15)) * 64 + (((1 - kg) ^ gg6) << 4);
       auto k_tile6 = [&](const int t) {
         const bool HN = t + 1 < nt;
         const int sb = (t & 1) * STAGE;
@@ -585,38 +587,24 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         char* dma_lds = smem + (STAGE - sb);
         avo = nt_avo; bvo = nt_bvo;
         asm volatile("" : "+v"(avo), "+v"(bvo));
-        u32x4_t As0[MF], Bs0[2];
-        u32x2_t As1[MF], Bs1[2];
-        unsigned Asc[MF], Bsc[2];
+        u32x4_t As0[MF], As1[MF], Bs0[3], Bs1[3];
+        int Asc[MF];
         stamp8(t, 0);
-        static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; ld_slot_asm<i * 1024>(As0[i], As1[i], Asc[i], ras, ras ^ 16u); });
-        ld_slot_asm<0>(Bs0[0], Bs1[0], Bsc[0], rbs, rbs ^ 16u);
-        auto mm_h = [&](auto Jc) {
-          constexpr int j = decltype(Jc)::value;
-          static_for<0, MF>([&](auto Ic) {
-            constexpr int i = decltype(Ic)::value;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
-          });
+        auto mm_h = [&](auto Jc, auto Ic) {
+          constexpr int j = decltype(Jc)::value, i = decltype(Ic)::value;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
         };
-        auto mm_6 = [&](auto Jc) {
-          constexpr int j = decltype(Jc)::value;
-          const int bsc = (int)(Bsc[j & 1] & lmask);
-          const i32x8_t bop = slot_operand(Bs0[j & 1], Bs1[j & 1]);
-          static_for<0, MF>([&](auto Ic) {
-            constexpr int i = decltype(Ic)::value;
-            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bop, slot_operand(As0[i], As1[i]), acc[i][j], 2, 2, 0, bsc, 0,
-                                                                         (int)Asc[i]);
-          });
+        auto mm_6 = [&](auto Jc, const int bsc, auto Ic) {
+          constexpr int j = decltype(Jc)::value, i = decltype(Ic)::value;
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(slot_operand(Bs0[j % 3], Bs1[j % 3]), slot_operand(As0[i], As1[i]),
+                                                                       acc[i][j], 2, 2, 0, bsc, 0, Asc[i]);
         };
         static_for<0, NFW>([&](auto Jc) {
           constexpr int j = decltype(Jc)::value;
-          if constexpr (j > 0) ld_slot_asm<j * 1024>(Bs0[j & 1], Bs1[j & 1], Bsc[j & 1], rbs, rbs ^ 16u);
+          ld_slot_asm<j * 1024>(Bs0[j % 3], Bs1[j % 3], rbs, rbs ^ 32u);
           if constexpr (j < NFW - 1) Bh[(j + 1) & 1] = ld128h_asm<(j + 1) * 1024>(rbh);
-          // DMA of k-tile t+1.  With 64 MFMAs per wave and k-tile (half of the fused loop's) a loader wave that issues all of its
-          // SIMD's 16 pieces is blocked for longer (~100-185 cycles per piece) than its partner needs for the partner's MFMAs, and
-          // the k-tile ends when the loader does (1.8 us measured against 1.0 us of MFMA time).  So the work is split by operand:
-          // waves 0-3 stage the A rows (activations, from HBM: early, phases 0-3), waves 4-7 the B rows (weights, L2-resident:
-          // phases 3-6) -- the two waves of a SIMD are blocked at different times.
+          // DMA of k-tile t+1, split by operand: waves 0-3 stage the A rows (activations, from HBM: early, phases 0-3), waves 4-7 the
+          // B rows (weights, L2-resident: phases 3-6) -- the two waves of a SIMD are blocked by their pieces at different times
           if constexpr (EGV_F6_DMA == 0) {
             if (j < 4 && loader && HN) {
               constexpr int PP = (NP + 3) / 4;
@@ -635,36 +623,44 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
                   [&](auto Ic) { piece(dma_lds, decltype(Ic)::value, PA + jj * PP); });
             }
           }
-          if constexpr (j == 0) {
-            lgkm_wait<15>();              // 3 MF + 3 + 1 reads issued behind B_h(0) and A_h: at most 15 in flight = those landed
-            stamp8(t, 1);
-            tie(Bh[0]);
-            static_for<0, MF>([&](auto Ic) { tie(Ah[decltype(Ic)::value]); });
-            __builtin_amdgcn_sched_barrier(0);
-            mm_h(Jc);
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
-            lgkm_wait<(j < NFW - 1) ? 4 : 3>();     // everything but this phase's own reads
-            if constexpr (j == 1) stamp8(t, 2);
-            if constexpr (j == 4) stamp8(t, 3);
-            tie(Bh[j & 1]); tie(Bs0[(j - 1) & 1]); tie(Bs1[(j - 1) & 1]); tie(Bsc[(j - 1) & 1]);
-            if constexpr (j == 1) {
-              static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; tie(As0[i]); tie(As1[i]); tie(Asc[i]); });
-              static_for<0, MF>([&](auto Ic) { Asc[decltype(Ic)::value] &= lmask; });
+          lgkm_wait<(j == 1) ? 2 * MF + 3 : ((j == NFW - 1) ? 2 : 3)>();
+          if constexpr (j == 0) stamp8(t, 1);
+          if constexpr (j == 2) stamp8(t, 2);
+          if constexpr (j == 4) stamp8(t, 3);
+          tie(Bh[j & 1]);
+          if constexpr (j == 0) static_for<0, MF>([&](auto Ic) { tie(Ah[decltype(Ic)::value]); });
+          int bsc = 0;
+          if constexpr (j >= 2) {
+            tie(Bs0[(j - 2) % 3]); tie(Bs1[(j - 2) % 3]);
+            bsc = (int)(Bs1[(j - 2) % 3][2] & lmask);
+            if constexpr (j == 2) {
+              static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; tie(As0[i]); tie(As1[i]); });
+              static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; Asc[i] = (int)(As1[i][2] & lmask); });
             }
-            __builtin_amdgcn_sched_barrier(0);
-            mm_h(Jc);
-            mm_6(std::integral_constant<int, j - 1>{});
-            // the finished accumulators of column j - 1 are next read a whole k-tile later: without a use HERE MachineSink moves
-            // all 8 MF block-scaled MFMAs of the k-tile into the loop latch (and keeps every B slot alive until then)
-            static_for<0, MF>([&](auto Ic) { anchor(acc[decltype(Ic)::value][j - 1]); });
-            __builtin_amdgcn_sched_barrier(0);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, MF>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            mm_h(Jc, Ic);
+            if constexpr (j == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              ld_slot_asm<i * 1024>(As0[i], As1[i], ras, ras ^ 32u);     // first read by mx6(0) in phase 2
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          });
+          if constexpr (j >= 2) {
+            static_for<0, MF>([&](auto Ic) { mm_6(std::integral_constant<int, j - 2>{}, bsc, Ic); });
+            // the finished accumulators of column j - 2 are next read a whole k-tile later: without a use HERE MachineSink moves
+            // all 8 MF block-scaled MFMAs of the k-tile into the loop latch (and keeps every B slot alive until then)
+            static_for<0, MF>([&](auto Ic) { anchor(acc[decltype(Ic)::value][j - 2]); });
+          }
+          __builtin_amdgcn_sched_barrier(0);
         });
-        // ---- tail: hand-over to k-tile t+1, then the MXFP6 products of B slot 7 with the next A_h fetched behind them
+        // ---- tail: hand-over to k-tile t+1 under the MXFP6 products of B slots 6 and 7; the next A_h is fetched behind them
         stamp8(t, 4);
         lgkm_wait<0>();
-        tie(Bs0[1]); tie(Bs1[1]); tie(Bsc[1]);
+        tie(Bs0[0]); tie(Bs1[0]); tie(Bs0[1]); tie(Bs1[1]);
+        const int bsc6 = (int)(Bs1[6 % 3][2] & lmask), bsc7 = (int)(Bs1[7 % 3][2] & lmask);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned nah = fah + (STAGE - sb);
         if (HN) {
@@ -678,20 +674,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           Bh[0] = ld128h_asm<0>(fbh + (STAGE - sb));
         }
         __builtin_amdgcn_sched_barrier(0);
-        {
-          constexpr int j = NFW - 1;
-          const int bsc = (int)(Bsc[j & 1] & lmask);
-          const i32x8_t bop = slot_operand(Bs0[j & 1], Bs1[j & 1]);
-          static_for<0, MF>([&](auto Ic) {
-            constexpr int i = decltype(Ic)::value;
-            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bop, slot_operand(As0[i], As1[i]), acc[i][j], 2, 2, 0, bsc, 0,
-                                                                         (int)Asc[i]);
-            anchor(acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (HN) Ah[i] = ld128h_asm<i * 1024>(nah);        // A_h: its last reader was the fp16 pass of phase 7
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
+        static_for<0, MF>([&](auto Ic) {
+          constexpr int i = decltype(Ic)::value;
+          mm_6(std::integral_constant<int, 6>{}, bsc6, Ic);
+          anchor(acc[i][6]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (HN) Ah[i] = ld128h_asm<i * 1024>(nah);        // A_h: its last reader was the fp16 pass of phase 7
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        static_for<0, MF>([&](auto Ic) { mm_6(std::integral_constant<int, 7>{}, bsc7, Ic); anchor(acc[decltype(Ic)::value][7]); });
+        __builtin_amdgcn_sched_barrier(0);
       };
       if (nt > 0) {
         // k-tile 0 has landed and every wave is past a barrier behind that: B_h(0), A_h -- what phase 0 counts on

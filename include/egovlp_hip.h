@@ -102,8 +102,9 @@ int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, in
  * per 32 k-elements (2 issue units where split-bf16 spends 3), product error ~2^-14 (embeddings 1.3e-4 against the 1e-3 bar).
  * An operand [rows, cols] (cols % 32 == 0) is two planes of 2 bytes per element, leading dimension ld (elements, % 32 == 0):
  *   h16   fp16 [rows, ld];
- *   slots per row and 32-element block b, 64 bytes at byte offset (row * ld + 32 b) * 2:
- *         [c6: 24 B of 6-bit codes, element i at bits 6i.. | scale byte | 7 B pad][l6: the same];  value = code x 2^(scale - 127).
+ *   slots per row and 32-element block b, 64 bytes at byte offset (row * ld + 32 b) * 2, as four 16-byte chunks:
+ *         [c6 code bytes 0-15][l6 code bytes 0-15][c6 code bytes 16-23, c6 scale byte, 7 B pad][l6 code bytes 16-23, l6 scale, pad];
+ *         a plane's 24 code bytes hold element i of the block at bits 6i .. 6i+5;  value = code x 2^(scale - 127).
  * bf (optional): bf16(x) [rows, ld], the operand of single-pass backward GEMMs.  Replaces nothing in the reference (fp32 there);
  * producers: this converter (weights, tests), egv_layernorm_fwd_f16f6, the EGV_ACT_GELU epilogue with out_fmt = 1.            */
 int egv_f16f6_encode(const float* x, int64_t ldx, int32_t rows, int32_t cols, uint16_t* h16, uint16_t* slots, egv_bf16* bf,

@@ -57,8 +57,11 @@ def encode(x: torch.Tensor):
 
 
 def unpack_slots(raw: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
-    """The slot plane as the device stores it (int16 / uint8 tensor of rows * cols * 2 bytes) -> uint8 [rows, cols // 32, 2, 32]."""
-    return raw.contiguous().view(torch.uint8).reshape(rows, cols // 32, 2, 32)
+    """The slot plane as the device stores it (int16 / uint8 tensor of rows * cols * 2 bytes; per block four 16-byte chunks:
+    c6 bytes 0-15 | l6 bytes 0-15 | c6 bytes 16-23, scale, pad | l6 bytes 16-23, scale, pad) -> uint8 [rows, cols // 32, 2, 32]
+    with [.., 0, :] the c6 slot and [.., 1, :] the l6 slot (24 code bytes, scale byte, pad)."""
+    ch = raw.contiguous().view(torch.uint8).reshape(rows, cols // 32, 4, 16)
+    return torch.stack([torch.cat([ch[:, :, 0], ch[:, :, 2]], dim=-1), torch.cat([ch[:, :, 1], ch[:, :, 3]], dim=-1)], dim=2)
 
 
 def decode_slots(slots: torch.Tensor):
