@@ -515,12 +515,21 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
   __shared__ int cnt[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // pass 1: number of valid rows (the gradient scale), then pass 2: losses and gradients
-  int nvalid = 0;
-  for (int r = threadIdx.x; r < rows; r += 256) nvalid += (target[r] != ignore_index);
+  // A label outside [0, cols) that is not ignore_index is an ERROR (torch raises a device assert): it must neither be skipped
+  // silently nor inflate the mean's denominator -- the loss comes back NaN (and the gradient of every row with it).
+  __shared__ int bad[4];
+  int nvalid = 0, nbad = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const long long t = target[r];
+    nvalid += (t != ignore_index);
+    nbad += (t != ignore_index && (t < 0 || t >= cols));
+  }
   nvalid = (int)wave_sum((float)nvalid);
-  if (lane == 0) cnt[wave] = nvalid;
+  nbad = (int)wave_sum((float)nbad);
+  if (lane == 0) { cnt[wave] = nvalid; bad[wave] = nbad; }
   __syncthreads();
   const int valid = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  const bool any_bad = (bad[0] + bad[1] + bad[2] + bad[3]) > 0;
   const float inv = valid > 0 ? 1.0f / (float)valid : 0.f;
   float acc = 0.f;
   for (int r = wave; r < rows; r += 4) {
@@ -537,12 +546,13 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     if (on) acc += lse - x[t];
     if (dlogits) {
       float* d = dlogits + (long)r * ldd;
-      for (int c = lane; c < cols; c += 64) d[c] = on ? (__expf(x[c] - lse) - (c == (int)t ? 1.f : 0.f)) * inv : 0.f;
+      for (int c = lane; c < cols; c += 64)
+        d[c] = any_bad ? __builtin_nanf("") : (on ? (__expf(x[c] - lse) - (c == (int)t ? 1.f : 0.f)) * inv : 0.f);
     }
   }
   if (lane == 0) part[wave] = acc;      // every lane of a wave holds the same acc
   __syncthreads();
-  if (threadIdx.x == 0) loss[0] = valid > 0 ? (part[0] + part[1] + part[2] + part[3]) * inv : __builtin_nanf("");
+  if (threadIdx.x == 0) loss[0] = (valid > 0 && !any_bad) ? (part[0] + part[1] + part[2] + part[3]) * inv : __builtin_nanf("");
 }
 }  // namespace
 

@@ -123,7 +123,8 @@ class GraphedTrainStep:
         self.max_graphs = max_graphs
         self._graphs = {}
         self._scalars = None       # device: per group {lr, step_size} floats, then the dropout seed word (int64 view)
-        self._host = None          # pinned staging copy
+        self._host = None          # ring of pinned staging copies, each with the event of the H2D copy that last read it
+        self._host_i = 0
         self.stats = {"eager": 0, "captures": 0, "replays": 0}
 
     # ---- device-resident step scalars ----------------------------------------------------------------------------------
@@ -132,7 +133,9 @@ class GraphedTrainStep:
             return
         ng = len(self.opt.param_groups)
         n32 = 2 * ng + (2 * ng) % 2 + 2                       # group floats, pad to 8 bytes, one int64
-        self._host = torch.zeros(n32, dtype=torch.float32).pin_memory()
+        # A ring, not one buffer: the host may run several replays ahead of the GPU (nothing in a timed loop synchronises), and a
+        # single staging buffer would be overwritten with step n + k's scalars before the queued copy of step n has read it.
+        self._host = [[torch.zeros(n32, dtype=torch.float32).pin_memory(), None] for _ in range(4)]
         self._scalars = torch.zeros(n32, dtype=torch.float32, device=device)
         self._seed_off = (2 * ng + (2 * ng) % 2)
         self.opt._graph_hyper = {id(g): self._scalars[2 * i: 2 * i + 2] for i, g in enumerate(self.opt.param_groups)}
@@ -147,13 +150,20 @@ class GraphedTrainStep:
 
     def _push_scalars(self, seed_word):
         from .optim import adamw_step_size
-        h = self._host
+        slot = self._host[self._host_i]
+        self._host_i = (self._host_i + 1) % len(self._host)
+        if slot[1] is not None:
+            slot[1].synchronize()          # the copy that read this staging buffer four steps ago has executed
+        h = slot[0]
         for i, g in enumerate(self.opt.param_groups):
             b1, b2 = g["betas"]
             h[2 * i] = g["lr"]
             h[2 * i + 1] = adamw_step_size(g["lr"], b1, b2, self._next_step_of(g), g["correct_bias"])
         h[self._seed_off: self._seed_off + 2].view(torch.int64)[0] = seed_word
         self._scalars.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        slot[1] = ev
 
     def _seed_word(self):
         tm = self.model.text_model
@@ -227,4 +237,4 @@ class GraphedTrainStep:
                 if s and "step" in s:
                     s["step"] += 1
         weights.bump_epoch()
-        return ent["loss"]
+        return ent["loss"].clone()        # the graph's static loss tensor is overwritten by the next replay (egoclip_step returns a fresh one)

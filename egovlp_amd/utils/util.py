@@ -52,19 +52,46 @@ class _Placeholder:
         return cfg[name]
 
 
-# Globals the lenient unpickler resolves for real: what tensors, optimizer state, numpy scalars / arrays and plain containers
-# are made of.  EVERYTHING else -- the reference's ConfigParser, loggers, and whatever a hostile file names (os.system,
-# builtins.eval, ...) -- becomes an inert _Placeholder class: it is constructed and given its state, it never runs code.
-_ALLOWED_MODULE_PREFIXES = ("torch", "collections", "numpy", "pathlib", "_codecs")
+# Globals the lenient unpickler resolves for real: an EXACT (module, name) allow-list -- what tensors, optimizer state, numpy
+# scalars / arrays and plain containers are made of: torch's own `weights_only` table plus the numpy reconstructors and a few
+# inert value types.  EVERYTHING else -- the reference's ConfigParser, loggers, and whatever a hostile file names (os.system,
+# builtins.eval, but also torch.hub.load, torch.load, numpy.load, torch.utils.cpp_extension.load: REDUCE may call any global it
+# is handed, so a module-prefix rule is not an allow-list) -- becomes an inert _Placeholder class: it is constructed and given
+# its state, it never runs code.
 _ALLOWED_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
                      "slice", "range", "object"}
+_NUMPY_NAMES = {"ndarray", "dtype", "bool_", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float16",
+                "float32", "float64", "complex64", "complex128"}
+_EXTRA_ALLOWED = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "Counter"), ("collections", "deque"),
+                  ("_codecs", "encode"), ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"), ("pathlib", "Path"), ("pathlib", "PurePath"),
+                  ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+                  ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar")} | {("numpy", n) for n in _NUMPY_NAMES}
+_TORCH_TABLE = None
+
+
+def _torch_safe_globals():
+    """torch's `weights_only=True` allow-list ("module.name" -> object): rebuild functions, storages, dtypes, OrderedDict, ..."""
+    global _TORCH_TABLE
+    if _TORCH_TABLE is None:
+        try:
+            from torch._weights_only_unpickler import _get_allowed_globals
+            _TORCH_TABLE = dict(_get_allowed_globals())
+        except Exception:        # pragma: no cover  (a torch without the private table: only the explicit names below)
+            _TORCH_TABLE = {}
+        import torch._utils as tu
+        for n in ("_rebuild_tensor_v2", "_rebuild_parameter", "_rebuild_tensor", "_rebuild_parameter_with_state"):
+            if hasattr(tu, n):
+                _TORCH_TABLE.setdefault("torch._utils." + n, getattr(tu, n))
+    return _TORCH_TABLE
 
 
 class _LenientUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        allowed = (module == "builtins" and name in _ALLOWED_BUILTINS) or \
-            any(module == p_ or module.startswith(p_ + ".") for p_ in _ALLOWED_MODULE_PREFIXES)
-        if allowed:
+        key = f"{module}.{name}"
+        table = _torch_safe_globals()
+        if key in table:
+            return table[key]
+        if (module == "builtins" and name in _ALLOWED_BUILTINS) or (module, name) in _EXTRA_ALLOWED:
             try:
                 return super().find_class(module, name)
             except (ImportError, AttributeError):

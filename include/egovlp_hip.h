@@ -253,6 +253,7 @@ int egv_maxmargin_fwd_bwd(const float* x, const float* weight, int32_t n, float 
  * defaults) on the [rows, cols] scores of FrozenInTime(video_only=True) (trainer/trainer_oscc.py:335-338).
  *   loss = mean over rows with target != ignore_index of (logsumexp(x_r) - x_r[target_r]);  NaN when no row is valid (as torch);
  *   dlogits (optional, [rows, ldd]) = (softmax(x_r) - onehot(target_r)) / #valid rows, 0 for ignored rows.
+ *   A target outside [0, cols) that is not ignore_index is an error (torch: device assert): loss and dlogits come back NaN.
  * Deterministic (fixed summation order).  rows <= 2^20, cols <= 65536.                                                     */
 int egv_cross_entropy_fwd_bwd(const float* logits, int64_t ld, const int64_t* target, int32_t rows, int32_t cols,
                               int64_t ignore_index, float* loss, float* dlogits, int64_t ldd, void* stream);

@@ -147,6 +147,38 @@ def test_lenient_unpickler_never_resolves_code_carrying_globals(tmp_path):
     assert not (tmp_path / "pwned").exists()
 
 
+def test_lenient_unpickler_allow_list_is_exact_not_a_module_prefix(tmp_path):
+    """Globals that live UNDER allowed packages but run code when called (torch.hub.load, torch.load, numpy.load,
+    torch.utils.cpp_extension.load) are placeholders too: the allow-list is (module, name) pairs, not `torch.*` / `numpy.*`;
+    tensors, parameters, numpy arrays / scalars, OrderedDict and Paths still round-trip."""
+    import io
+    import pickle
+    from collections import OrderedDict
+    import numpy as np
+    from egovlp_amd.utils.util import _LenientUnpickler, _Placeholder
+    seen = []
+
+    def reducer(fn, *args):
+        class R:
+            def __reduce__(self):
+                return (fn, args)
+        return R()
+    import torch.hub
+    import torch.utils.cpp_extension
+    evil = {"hub": reducer(torch.hub.load, "someone/repo", "model"), "tl": reducer(torch.load, str(tmp_path / "x.pt")),
+            "npl": reducer(np.load, str(tmp_path / "x.npy")), "ext": reducer(torch.utils.cpp_extension.load, "m", ["a.cpp"])}
+    out = _LenientUnpickler(io.BytesIO(pickle.dumps(evil))).load()
+    assert all(isinstance(v, _Placeholder) for v in out.values()), out
+    good = {"sd": OrderedDict(w=torch.arange(6.).view(2, 3), p=torch.nn.Parameter(torch.ones(2))), "arr": np.arange(4, dtype=np.float32),
+            "scalar": np.float64(2.5), "step": 7, "path": __import__("pathlib").PurePosixPath("/a/b")}
+    path = tmp_path / "good.pth"
+    torch.save(good, path)
+    from egovlp_amd.utils.util import _LenientPickle
+    back = torch.load(path, weights_only=False, pickle_module=_LenientPickle)
+    assert torch.equal(back["sd"]["w"], good["sd"]["w"]) and torch.equal(back["sd"]["p"], good["sd"]["p"])
+    assert np.array_equal(back["arr"], good["arr"]) and float(back["scalar"]) == 2.5 and back["step"] == 7 and str(back["path"]) == "/a/b"
+
+
 def test_eval_token_padding_for_graph_replay():
     """`_pad_tokens` (EgoMCQ validation with args.graph_eval): captions are right-padded to a multiple of 8 tokens with [PAD]
     ids and masked positions, so a handful of captured graphs covers every caption length; shorter-than-multiple inputs keep

@@ -43,10 +43,28 @@ def test_cross_entropy_all_ignored_is_nan_like_torch():
     assert torch.isnan(CrossEntropy()(x, t)) and torch.isnan(torch.nn.CrossEntropyLoss()(x.cpu(), t.cpu()))
 
 
+def test_cross_entropy_out_of_range_label_is_flagged_not_skipped():
+    """A label outside [0, classes) that is not ignore_index: torch raises a device assert; the kernel must not silently skip the
+    row while still counting it in the mean -- loss and gradient come back NaN."""
+    from egovlp_amd.model.loss import CrossEntropy
+    x = torch.randn(6, 3).cuda().requires_grad_(True)
+    t = torch.tensor([0, 2, 1, 7, -100, 1]).cuda()
+    loss = CrossEntropy()(x, t)
+    loss.backward()
+    assert torch.isnan(loss) and bool(torch.isnan(x.grad).all())
+    t[3] = 2
+    x2 = x.detach().clone().requires_grad_(True)
+    ok = CrossEntropy()(x2, t)
+    assert abs(float(ok) - float(torch.nn.CrossEntropyLoss()(x.detach().cpu(), t.cpu()))) < 1e-5
+
+
+@pytest.mark.parametrize("side", [False, True])
 @pytest.mark.parametrize("classes", [2, 17])
-def test_oscc_pnr_head_train_step_matches_oracle(classes):
+def test_oscc_pnr_head_train_step_matches_oracle(classes, side):
     """configs/ft/oscc.json / pnr.json: FrozenInTime(projection_dim = classes), `model(data, video_only=True)` scores,
-    CrossEntropy, backward -- against the oracle's video encoder + a linear head + torch's cross-entropy on the CPU."""
+    CrossEntropy, backward -- against the oracle's video encoder + a linear head + torch's cross-entropy on the CPU.
+    `side`: with the weight-gradient side stream on, as the trainer and bench.py run (the padded head slices its dW / db on the
+    main stream: its wgrad must stay there, round-3 advisor finding)."""
     from egovlp_amd.model.loss import CrossEntropy
     from egovlp_amd.model.model import FrozenInTime
     from egovlp_amd.ops import Precision
@@ -58,6 +76,7 @@ def test_oscc_pnr_head_train_step_matches_oracle(classes):
     sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=21)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
+    m.exec_ctx.set(wgrad_side_stream=side)
     B, T = 6, 4
     g = torch.Generator().manual_seed(8)
     video = torch.randn(B, T, 3, 224, 224, generator=g)
