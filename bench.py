@@ -251,8 +251,6 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 20-step loss / parameter drift comparison of the "
                     "benchmarked precision mode against the all-bf16x3 (fp32-grade gradient) run")
-    ap.add_argument("--ddp", action="store_true", help="N>1: use torch DistributedDataParallel (fp32 buckets) instead of "
-                    "egovlp_amd.dist.Bf16GradSync (A/B of the gradient exchange)")
     ap.add_argument("--gemm-grid", type=int, default=0, help="persistent workgroups of the big GEMM (default: 256 at N=1, "
                     "248 at N>1 so that the overlapped RCCL kernels find free CUs)")
     ap.add_argument("--wgrad-side", type=int, default=int(os.environ.get("EGV_WGRAD_SIDE", "1")),
@@ -265,16 +263,11 @@ def main():
     ap.add_argument("--graph", type=int, default=int(os.environ.get("EGV_GRAPH_STEP", "0")),
                     help="1: the whole step (forward, loss, backward, AdamW; all three streams) is captured into a HIP graph once and "
                          "replayed (egovlp_amd.graph.GraphedTrainStep; single GPU): one launch per step instead of ~840")
-    ap.add_argument("--adamw-overlap", type=int, default=int(os.environ.get("EGV_ADAMW_OVERLAP", "0")),
-                    help="1: AdamW updates enqueued from grad-ready hooks on a side stream under the rest of backward "
-                         "(single GPU only; bit-identical results)")
     ap.add_argument("--rccl-channels", type=int, default=0, help="N>1: cap RCCL at this many channels (= workgroups) via "
                     "NCCL_MAX_NCHANNELS, e.g. 8 to match the CUs the 248-workgroup GEMM grid leaves free (default: RCCL's choice)")
     ap.add_argument("--grad-exchange", default=os.environ.get("EGV_GRAD_EXCHANGE", "direct"), choices=["direct", "allreduce"],
                     help="N>1: how a bf16 gradient bucket travels -- direct (default): all-to-all of bucket slices over all xGMI "
                          "links, fp32 slice sum, all-gather; allreduce: RCCL's stock all_reduce of the bf16 bucket")
-    ap.add_argument("--grad-sync-hooks", type=int, default=0, help="N>1: 1 = launch the gradient buckets from autograd "
-                    "grad-ready hooks; 0 (default) = hook-free, from the block-boundary poll")
     ap.add_argument("--no-grad-sync", action="store_true", help="diagnostics: process group and embedding gather, but no "
                     "gradient exchange (what does the distributed environment itself cost?)")
     ap.add_argument("--force-dist", action="store_true",
@@ -337,25 +330,18 @@ def main():
     set_precision(args.precision)
     net = model
     grad_sync = None
-    if use_dist and args.ddp:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=100,
-                                                        gradient_as_bucket_view=True)
-    elif use_dist and not args.no_grad_sync:
+    if use_dist and not args.no_grad_sync:
+        # hook-free gradient exchange: buckets launched from the polls of the video tower's backward (ExecContext.backward_poll).
+        # (The grad-ready-hook variant and the DistributedDataParallel A/B leg of rounds 2-3 measured slower -- 3.2 % / 9 % against
+        # 1.7 % at world size 1, profiles/r02_d_dp_overhead.txt -- and live in tools/ddp_ab.py now.)
         from egovlp_amd.dist import Bf16GradSync
-        if args.grad_sync_hooks:
-            grad_sync = Bf16GradSync(model.parameters(), stream_of=model.gradient_stream_of, exec_ctx=ec, exchange=args.grad_exchange)
-        else:     # hook-free: buckets launched from the polls of the video tower's backward (ExecContext.backward_poll)
-            grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
-                                     exchange=args.grad_exchange)
-            ec.set(backward_poll=grad_sync.poll)
+        grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
+                                 exchange=args.grad_exchange)
+        ec.set(backward_poll=grad_sync.poll)
     grid = args.gemm_grid or (248 if world > 1 else 256)
     ec.set(gemm_grid=grid)
-    if args.ddp:
-        args.wgrad_side = 0      # DDP's reducer hooks read the weight gradients during backward and know nothing of the side stream
     ec.set(wgrad_side_stream=bool(args.wgrad_side), text_side_stream=bool(args.text_side))
     opt = AdamW(model.parameters(), lr=3e-5)
-    if args.adamw_overlap and grad_sync is None and not args.ddp:
-        opt.overlap_backward(stream_of=model.gradient_stream_of, exec_ctx=ec)
     loss_fn = EgoNCE()
     batch = synth_batch(B, T=T, L=L, seed=1234, rank=rank)
     data = {"video": batch["video"].cuda(), "text": {k: v.cuda() for k, v in batch["text"].items()},
@@ -484,7 +470,9 @@ def main():
                    "parallelism": f"dp{world}", "precision": "/".join(ec.precision_name()),
                    "text_dropout": args.text_dropout,
                    "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
-                               "adamw_overlapped_with_backward": bool(args.adamw_overlap and grad_sync is None and not args.ddp),
+                               # what differs between the N = 1 and the N > 1 step: one wgrad stream and a 248-workgroup
+                               # GEMM grid under a process group, two wgrad streams and 256 workgroups without
+                               "wgrad_streams": (ops._wgrad_stream_count() if args.wgrad_side else 0), "gemm_grid": grid,
                                "main_stream_high_priority": bool(args.main_priority),
                                "step_replayed_from_hip_graph": bool(args.graph and world == 1 and not use_dist)}},
         "loss": round(loss_val, 5),
@@ -516,7 +504,7 @@ def main():
         allr = torch.stack(allr).cpu()
         out["comm"] = {"rccl_ranks": world, "backend": dist.get_backend(), "gemm_grid": grid,
                        "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS", "default"),
-                       "gradient_exchange": "DDP fp32 buckets" if args.ddp else (
+                       "gradient_exchange": (
                            "Bf16GradSync direct (bf16 buckets: all-to-all of slices over all links, fp32 slice sum, all-gather; launched from "
                            "the backward polls on a private stream)" if args.grad_exchange == "direct" else
                            "Bf16GradSync allreduce (bf16 buckets, async RCCL all-reduce launched from the backward polls)"),

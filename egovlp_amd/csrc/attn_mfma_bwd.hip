@@ -457,8 +457,7 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NF * 16 * ATT_ROW_BYTES + 2 * NF * 16 * sizeof(float);
   if constexpr (MODE == MODE_SPACE && NF == 14) {     // ViT-B/16: streaming dQ kernel (measured), then the dK/dV kernel
-    static const int stream_on = getenv("EGV_ATTN_STREAM") ? atoi(getenv("EGV_ATTN_STREAM")) : 1;   // A/B: 0 = all-keys dQ kernel
-    if (stream_on && gr.oh != nullptr) {
+    if (gr.oh != nullptr) {
       const size_t lds1 = (size_t)planes * NF * 16 * ATT_ROW_BYTES + NF * 16 * sizeof(float);
       if (passes == 3) {
         auto k1 = attn_bwd_dq_stream_kernel<NF, 3>;
@@ -494,7 +493,7 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
     auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
     (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const int nthr = getenv("EGV_ATTN_BWD_THREADS") ? atoi(getenv("EGV_ATTN_BWD_THREADS")) : 512;   // 8 waves per group (A/B: 256)
+    constexpr int nthr = 512;   // 8 waves per group
     EGV_LAUNCH(k1, dim3(ngroups), dim3(nthr), lds, s, g, gr);
     EGV_CHECK_LAUNCH();
     EGV_LAUNCH(k2, dim3(ngroups), dim3(nthr), lds, s, g, gr);

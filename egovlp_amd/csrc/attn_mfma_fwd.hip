@@ -291,8 +291,7 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NKF * 16 * ATT_ROW_BYTES + NKF * 16 * sizeof(float);
   if constexpr (MODE == MODE_SPACE && NKF == 14) {   // measured on ViT-B/16 (13 query tiles on 16 waves): 137 -> 130 us
-    static const int stream_on = getenv("EGV_ATTN_STREAM") ? atoi(getenv("EGV_ATTN_STREAM")) : 1;   // A/B: 0 = the all-keys kernel
-    if (passes == 3 && ol != nullptr && stream_on) {
+    if (passes == 3 && ol != nullptr) {
       auto kern = attn_fwd_stream3_kernel<NKF>;
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       EGV_LAUNCH(kern, dim3(ngroups), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws);
@@ -309,7 +308,7 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
   } else {
     auto kern = attn_fwd_kernel<MODE, NKF, 1>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const int nthr = getenv("EGV_ATTN_FWD_THREADS") ? atoi(getenv("EGV_ATTN_FWD_THREADS")) : 512;   // A/B diagnostics
+    constexpr int nthr = 512;
     EGV_LAUNCH(kern, dim3(ngroups), dim3(nthr), lds, s, g, oh, nullptr, ostride, lse, cls_ws);
   }
   EGV_CHECK_LAUNCH();

@@ -129,29 +129,40 @@ __global__ __launch_bounds__(256) void attn_time_fwd_kernel(const bf16_t* __rest
   ldp<CPL>(qh, ql, base, qc);
   ldp<CPL>(qh, ql, base + HD, kc);
   ldp<CPL>(qh, ql, base + 2 * HD, vc);
-  float q[TMAX][CPL], k[TMAX][CPL], v[TMAX][CPL];
+  // T <= 4: q, k, v of the location all live in registers.  T = 8 / 16 with four heads per wave (8-byte lanes): k and v stay
+  // resident (2 x T x 4 registers), the queries are STREAMED through a two-deep register ring (the next query's load is in
+  // flight while the current one is multiplied) -- 3 x 16 x 4 resident values would not fit two waves per SIMD.
+  constexpr bool QS = TMAX > 4 && CPL >= 4;
+  float q[QS ? 2 : TMAX][CPL], k[TMAX][CPL], v[TMAX][CPL];
 #pragma unroll
   for (int f = 0; f < TMAX; ++f) {
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) q[f][c] = k[f][c] = v[f][c] = 0.f;
+    for (int c = 0; c < CPL; ++c) k[f][c] = v[f][c] = 0.f;
+    if (!QS) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) q[QS ? 0 : f][c] = 0.f;
+    }
     if (f < T) {
       const long p = base + (1 + (long)f * n + i) * ts;
-      ldp<CPL>(qh, ql, p, q[f]);
+      if (!QS) ldp<CPL>(qh, ql, p, q[QS ? 0 : f]);
       ldp<CPL>(qh, ql, p + HD, k[f]);
       ldp<CPL>(qh, ql, p + 2 * HD, v[f]);
     }
   }
+  if (QS) ldp<CPL>(qh, ql, base + (1 + (long)i) * ts, q[0]);
 #pragma unroll
   for (int f = 0; f < TMAX; ++f) {
     if (f < T) {
+      if (QS && f + 1 < T) ldp<CPL>(qh, ql, base + (1 + (long)(f + 1) * n + i) * ts, q[(f + 1) & 1]);
+      const float (&qf)[CPL] = q[QS ? (f & 1) : f];
       float s[TMAX + 1];
-      s[0] = redh<LPH>(dotc<CPL>(q[f], kc)) * 0.125f;
+      s[0] = redh<LPH>(dotc<CPL>(qf, kc)) * 0.125f;
       float m = s[0];
 #pragma unroll
       for (int j = 0; j < TMAX; ++j) {
         s[j + 1] = -3e38f;
         if (j < T) {
-          s[j + 1] = redh<LPH>(dotc<CPL>(q[f], k[j])) * 0.125f;
+          s[j + 1] = redh<LPH>(dotc<CPL>(qf, k[j])) * 0.125f;
           m = fmaxf(m, s[j + 1]);
         }
       }
@@ -648,14 +659,21 @@ int launch_time_fwd(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int
     }
   }
   if (done) {
-  } else if (H % 4 == 0 && TMAX <= 4) {
-    const long ngroups = (long)B * n * (H / 4);
-    EGV_LAUNCH((attn_time_fwd_kernel<TMAX, 4>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
-               oh, ol, lse, ws);
   } else {
-    const long ngroups = (long)B * n * H;
-    EGV_LAUNCH((attn_time_fwd_kernel<TMAX, 1>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
-               oh, ol, lse, ws);
+    bool four = false;
+    {
+      if (H % 4 == 0) {
+        const long ngroups = (long)B * n * (H / 4);
+        EGV_LAUNCH((attn_time_fwd_kernel<TMAX, 4>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
+                   oh, ol, lse, ws);
+        four = true;
+      }
+    }
+    if (!four) {
+      const long ngroups = (long)B * n * H;
+      EGV_LAUNCH((attn_time_fwd_kernel<TMAX, 1>), dim3((unsigned)((ngroups + 3) / 4)), dim3(256), 0, s, qh, ql, B, T, n, H,
+                 oh, ol, lse, ws);
+    }
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;
@@ -666,28 +684,27 @@ int launch_time_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const
                     const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s) {
   const int chunks = (n + 15) / 16;
   // four heads per wave = 8-byte lanes, one full 128-B line per head and store instruction (which is what lets the outputs
-  // stream, csrc/common.h EGV_NT_TIME_BWD): 128 -> 99 us per call at B=32 (profiles/r02_tb_time_attention_bwd.txt);
-  // EGV_TIME_HPW=2 selects the 4-byte-lane kernel for A/B
-  static const int want4 = getenv("EGV_TIME_HPW") ? atoi(getenv("EGV_TIME_HPW")) == 4 : 1;
-  // default 8 waves x 2 locations (isolated, B = 32: 95 us at 4 x 4, 80-84 at 8 x 2, 87 at 16 x 1; profiles/r03_attention_time_bwd_ab.txt);
-  // EGV_TIME_BWD_WPB=4 / 16 select the other shapes for A/B
-  static const int wpb = getenv("EGV_TIME_BWD_WPB") ? atoi(getenv("EGV_TIME_BWD_WPB")) : 8;
-  if (H % 4 == 0 && TMAX <= 4 && want4 && wpb == 16) {
-    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4, 16>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(1024), 0, s, qh, ql, doh, dol,
-               lse, delta, B, T, n, H, gh, gl, dcls);
-  } else if (H % 4 == 0 && TMAX <= 4 && want4 && wpb == 8) {
-    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4, 8>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(512), 0, s, qh, ql, doh, dol,
-               lse, delta, B, T, n, H, gh, gl, dcls);
-  } else if (H % 4 == 0 && TMAX <= 4 && want4) {
-    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
-               lse, delta, B, T, n, H, gh, gl, dcls);
-  } else if (H % 2 == 0 && TMAX <= 8) {
-    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 2>), dim3((unsigned)(B * (H / 2) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
-               lse, delta, B, T, n, H, gh, gl, dcls);
-  } else {
-    EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 1>), dim3((unsigned)(B * H * chunks)), dim3(256), 0, s, qh, ql, doh, dol, lse,
-               delta, B, T, n, H, gh, gl, dcls);
+  // stream, csrc/common.h EGV_NT_TIME_BWD): 128 -> 99 us per call at B=32 (profiles/r02_tb_time_attention_bwd.txt); 8 waves x 2
+  // locations per workgroup (isolated, B = 32: 95 us at 4 x 4, 80-84 at 8 x 2, 87 at 16 x 1; profiles/r03_attention_time_bwd_ab.txt).
+  // Only the instances that are dispatched exist (`if constexpr`: the T = 8 / 16 forms of the four-heads kernel spilled).
+  if constexpr (TMAX <= 4) {
+    if (H % 4 == 0) {
+      EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 4, 8>), dim3((unsigned)(B * (H / 4) * chunks)), dim3(512), 0, s, qh, ql, doh, dol,
+                 lse, delta, B, T, n, H, gh, gl, dcls);
+      EGV_CHECK_LAUNCH();
+      return EGV_OK;
+    }
   }
+  {
+    if (H % 2 == 0) {
+      EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 2>), dim3((unsigned)(B * (H / 2) * chunks)), dim3(256), 0, s, qh, ql, doh, dol,
+                 lse, delta, B, T, n, H, gh, gl, dcls);
+      EGV_CHECK_LAUNCH();
+      return EGV_OK;
+    }
+  }
+  EGV_LAUNCH((attn_time_bwd_kernel<TMAX, 1>), dim3((unsigned)(B * H * chunks)), dim3(256), 0, s, qh, ql, doh, dol, lse,
+             delta, B, T, n, H, gh, gl, dcls);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

@@ -1353,8 +1353,7 @@ int launch_big(const egv_gemm_desc& p, hipStream_t s, int nb5 = 0) {
 // tiling is at least as good.  Same number of rounds R as the uniform tiling; as many bands as R rounds of `grid` workgroups can
 // take; cost = 5 per round that still contains a 320-row tile + 4 per round of 256-row tiles only.
 int pick_mixed_bands(const egv_gemm_desc& p, int grid) {
-  static const int off = getenv("EGV_GEMM_MIXED") ? atoi(getenv("EGV_GEMM_MIXED")) == 0 : 0;     // A/B: EGV_GEMM_MIXED=0
-  if (off || p.M < 640 || grid < 8) return -1;
+  if (p.M < 640 || grid < 8) return -1;
   const int tn = (p.N + BNB - 1) / BNB;
   const int tiles5 = ((p.M + 319) / 320) * tn;
   const int R = (tiles5 + grid - 1) / grid;

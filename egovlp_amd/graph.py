@@ -112,8 +112,6 @@ class GraphedTrainStep:
         from .optim import AdamW
         if not isinstance(optimizer, AdamW):
             raise TypeError("GraphedTrainStep needs egovlp_amd.optim.AdamW (its step-dependent scalars must be device-resident)")
-        if optimizer._ov is not None:
-            raise RuntimeError("GraphedTrainStep and AdamW.overlap_backward() are exclusive")
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.world_size, self.rank, self.grad_sync = world_size, rank, grad_sync
         if warmup < 1:

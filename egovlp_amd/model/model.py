@@ -162,7 +162,7 @@ class FrozenInTime(BaseModel):
     def gradient_stream_of(self, param):
         """The HIP stream `param`'s gradient is produced on: the text tower's stream for DistilBERT and txt_proj when the towers
         run on two streams (ops.TEXT_SIDE_STREAM), else None (= the stream backward() is called on).  For code that
-        registers gradient hooks (egovlp_amd.dist.Bf16GradSync, AdamW.overlap_backward)."""
+        registers gradient hooks (egovlp_amd.dist.Bf16GradSync in hook mode)."""
         if not self.exec_ctx.text_side_stream or not param.is_cuda:
             return None
         ids = getattr(self, "_text_param_ids", None)

@@ -14,7 +14,6 @@ from __future__ import annotations
 
 from functools import partial
 
-import os
 
 import torch
 from torch import nn
@@ -23,10 +22,9 @@ from .. import ops
 from ..ops import ACT_GELU, ACT_GELU_BWD, ExecContext, Planes
 
 
-# The dgrad GEMMs that feed LayerNorm-backward write fp32: handing dy over as bf16 planes instead halves those bytes but
-# measured 0.5 ms/step SLOWER on MI355X (A/B in one session: 39.5 vs 39.0 ms) -- the split epilogue's VALU work and 8-byte
-# stores / loads cost more than the bytes they save.  EGV_LN_DY_PLANES=1 re-enables the plane hand-over (diagnostics).
-_LN_DY_PLANES = os.environ.get("EGV_LN_DY_PLANES", "0") == "1"
+# The dgrad GEMMs that feed LayerNorm-backward write fp32: handing dy over as bf16 planes instead halves those bytes but measured
+# 0.5 ms/step SLOWER in round 2 and within noise in round 3 (the split epilogue's VALU work and 8-byte stores / loads cost what the
+# bytes save; profiles/r03_stream_ab.txt) -- the switch is gone, egv_layernorm_bwd still accepts planes (tests).
 
 
 def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, params=(), ec: ExecContext = None, allow_side=True):
@@ -189,18 +187,18 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D,
                     aux_is_grad=z.dtype == torch.bfloat16, ec=ec)
         _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False, params=(fc2_w,), ec=ec)
-        d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, dx_planes=_LN_DY_PLANES, params=(fc1_w,), ec=ec)   # LayerNorm backward reads planes
+        d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, params=(fc1_w,), ec=ec)   # LayerNorm backward reads planes
         # d_sr = G + LN2'(d_n2)
         d_sr, d_n2w, d_n2b, d_sr_pl = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G, planes_passes=Pb)
         # ---- spatial attention backward
         d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb, dx_planes=True, params=(sproj_w,), ec=ec)
         d_qkv_s = ops.divided_attn_bwd(qkv_s, a_s, d_as, lse_s, B, T, n, H, 0, Pb)
-        d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb, dx_planes=_LN_DY_PLANES, params=(sqkv_w,), ec=ec)
+        d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb, params=(sqkv_w,), ec=ec)
         d_tr, d_n1w, d_n1b, d_tr_pl = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1, planes_passes=Pb)
         # ---- temporal attention backward
         d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb, dx_planes=True, params=(tproj_w,), ec=ec)
         d_qkv_t = ops.divided_attn_bwd(qkv_t, a_t, d_at, lse_t, B, T, n, H, 1, Pb)
-        d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb, dx_planes=_LN_DY_PLANES, params=(tqkv_w,), ec=ec)
+        d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb, params=(tqkv_w,), ec=ec)
         # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
         d_x, d_n3w, d_n3b, d_x_pl = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr,
                                                        planes_passes=Pb)

@@ -31,14 +31,14 @@ def _run(cmd, env):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("exchange", ["bf16sync", "bf16sync-allreduce", "ddp"])
+@pytest.mark.parametrize("exchange", ["bf16sync", "bf16sync-allreduce"])
 def test_bench_under_rccl_world1_matches_single_process(exchange):
     common = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-fast-mode",
               "--no-kernel-timing", "--precision", "bf16x3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     plain = _run([sys.executable] + common, env)
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                 "--master-port", str(_free_port())] + common + ["--force-dist"] + (["--ddp"] if exchange == "ddp" else []) +
+                 "--master-port", str(_free_port())] + common + ["--force-dist"] +
                 (["--grad-exchange", "allreduce"] if exchange == "bf16sync-allreduce" else []), env)
     assert dist["n_gpus"] == 1 and dist["config"]["parallelism"] == "dp1"
     assert dist["comm"]["rccl_ranks"] == 1 and dist["comm"]["backend"] == "nccl"

@@ -1,7 +1,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egovlp_amd import ops
-B, T, n, H = 32, 4, 196, 12
+B, T, n, H = (int(os.environ.get(k, d)) for k, d in (("ATT_B", 32), ("ATT_T", 4), ("ATT_N", 196), ("ATT_H", 12)))
+print("B=%d T=%d n=%d H=%d" % (B, T, n, H))
 S = 1 + T * n
 for passes in (3, 1):
     qkv = ops.split_f32(torch.randn(B * S, 3 * H * 64, device="cuda"), passes)[0]
