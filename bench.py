@@ -72,6 +72,8 @@ def cpu_baseline(B=8, T=4, L=32, reps=3):
     ts = sorted(one(B) for _ in range(reps))
     dt = ts[len(ts) // 2]
     return {"value": round(B / dt, 4), "unit": "clip-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "config": {"workload": f"the same EgoClip step (fwd + EgoNCE + bwd, no optimizer) at B={B} (BASELINE configs[0]); the GPU line "
+                                   f"runs B=32", "batch": B, "frames": T, "text_tokens": L, "dtype": "f32"},
             "sample": f"median of {reps} fwd+EgoNCE+bwd steps of the CPU oracle at B={B} (T={T}, L={L}) after one warm-up: "
                       f"{dt:.1f} s [{ts[0]:.1f} .. {ts[-1]:.1f}], {torch.get_num_threads()} of {os.cpu_count()} logical cpus",
             "why_port": "/root/reference does not exist on the GPU box, so the reference itself cannot be timed there; the "
@@ -248,6 +250,7 @@ def main():
                     "(HF default 0.1 = what the reference trains with; 0 = the deterministic parity configuration)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the secondary single-pass bf16 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the secondary with_h2d_uint8 measurement")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 20-step loss / parameter drift comparison of the "
                     "benchmarked precision mode against the all-bf16x3 (fp32-grade gradient) run")
@@ -431,15 +434,18 @@ def main():
                  for k, v in shapes[:14]]
         # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 --pmc passes (they cannot be read from
         # inside this process), so the number comes from the committed summary of such a pass of THIS command, if present
-        traffic, traffic_src = None, None
+        # (`traffic` itself is therefore null in THIS line: it is not a measurement of this run; the committed number is quoted
+        # under `traffic_reference` with its origin)
+        traffic_ref = None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            traffic_ref = {"from": "profiles/gemm_traffic.json (separate rocprofv3 --pmc passes of this command on a builder box): "
+                                   + str(tj.get("source")), "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")}
         roof = {"bound": "mfma", "kernel": "gemm_big_kernel (every launch of the step: NT forward / dgrad, TN wgrad incl. its split-K reduce)",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_reference": traffic_ref,
                 "launches_per_step": g["launches"] // 2,
                 "avg_launch_us": round(g["seconds"] / g["launches"] * 1e6, 2),
                 "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 3),
@@ -452,7 +458,7 @@ def main():
                 "note": "achieved = algorithmic 2*M*N*K of the gemm_big launches of a step / their summed HIP-event time "
                         "(events on the launch stream around each C-ABI call); bf16x3 launches issue 3 MFMA passes per "
                         "algorithmic product (mfma_issue_tflops counts them); traffic = (FETCH_SIZE x 2 + WRITE_SIZE) per "
-                        "launch from a separate rocprofv3 --pmc pass (profiles/), null if that summary is absent"}
+                        "launch can only come from separate rocprofv3 --pmc passes: null here, the committed summary is quoted in traffic_reference"}
     key = (args.arch, T)
     step_frac = None
     if key in FWD_GFLOP_PER_PAIR:
@@ -533,6 +539,39 @@ def main():
                                  "step_mfma_frac": None if key not in FWD_GFLOP_PER_PAIR else round(
                                      B * args.steps / dt2 * FWD_GFLOP_PER_PAIR[key] * 3e9 / (PEAK_BF16_TFLOPS * 1e12), 4)}
         set_precision(args.precision)
+    if world == 1 and not args.no_h2d_leg:
+        # secondary, clearly labelled figure: the step WITH the input hand-over the reference's step has (trainer/trainer_egoclip.py:
+        # 114-121 moves every batch to the device before the step).  Decoded uint8 frames in pinned host memory (the loader's
+        # output format; x / 255 and Normalize run inside the patch gather on the device), copied on a private copy stream one
+        # batch ahead of the compute stream (egovlp_amd.trainer.trainer_egoclip._prefetched, what Multi_Trainer_dist._train_epoch
+        # does).  `value` above stays the HBM-resident number.
+        from egovlp_amd.trainer.trainer_egoclip import _prefetched
+        mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+        std = torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+        u8 = ((batch["video"] * std + mean).clamp(0, 1) * 255).round().to(torch.uint8).pin_memory()
+        host = {"video": u8, "text": {k: v.pin_memory() for k, v in batch["text"].items()},
+                "noun_vec": batch["noun_vec"].pin_memory(), "verb_vec": batch["verb_vec"].pin_memory()}
+        nh = args.steps + 3
+
+        def host_batches():
+            for i in range(nh):
+                yield i, 0, host
+        feed = _prefetched(host_batches(), torch.device("cuda", local_rank))
+        t0h, lossh = None, None
+        for bi, _, dev_batch in feed:
+            if bi is None:
+                break
+            if bi == 3:                      # three warm-up steps (first use of the uint8 gather), then the clock
+                torch.cuda.synchronize()
+                t0h = time.perf_counter()
+            lossh = egoclip_step(net, loss_fn, opt, dev_batch, world, rank, grad_sync=grad_sync)
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t0h
+        out["with_h2d_uint8"] = {"value": round(B * args.steps / dth, 2), "unit": "clip-pairs/s", "ms_per_step": round(dth / args.steps * 1e3, 3),
+                                 "host_bytes_per_step": int(u8.numel() + sum(v.numel() * v.element_size() for v in batch["text"].values())
+                                                            + 4 * (batch["noun_vec"].numel() + batch["verb_vec"].numel())),
+                                 "input": "decoded uint8 frames + token ids / masks / noun-verb vectors in pinned host memory, copied one "
+                                          "batch ahead on a copy stream; normalisation fused into the patch gather", "loss": round(float(lossh), 5)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

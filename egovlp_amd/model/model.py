@@ -100,7 +100,9 @@ class FrozenInTime(BaseModel):
         if not text_params['pretrained']:
             raise NotImplementedError("Huggingface text models require pretrained init.")       # :27-28
         if self.text_params['model'].startswith('distilbert'):
-            self.text_model = DistilBertModel()
+            # `text_params['config']` (extension, tests): DistilBertConfig overrides for toy-sized towers
+            from .text_transformer import DistilBertConfig
+            self.text_model = DistilBertModel(DistilBertConfig(**text_params['config']) if text_params.get('config') else None)
         else:
             raise NotImplementedError(f"{text_params['model']}: only distilbert is on the EgoClip hot path")
         self.text_model.train()
@@ -118,6 +120,10 @@ class FrozenInTime(BaseModel):
                 model = SpaceTimeTransformer(patch_size=14, embed_dim=1024, depth=24, num_heads=16,
                                              num_frames=num_frames, time_init=time_init,
                                              attention_style=attention_style)
+                vit_path = None
+            elif arch_config == 'custom':                     # extension (tests): SpaceTimeTransformer(**video_params['arch_kwargs'])
+                model = SpaceTimeTransformer(num_frames=num_frames, time_init=time_init, attention_style=attention_style,
+                                             **video_params['arch_kwargs'])
                 vit_path = None
             else:
                 raise NotImplementedError                                                        # :53

@@ -113,6 +113,56 @@ def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_he
     return loss.detach()
 
 
+def _to_device_async(data, device, stream):
+    """Host batch -> device on `stream`: tensors go through pinned staging copies (a pageable source makes the copy synchronous);
+    -> (device batch, event of the last copy).  Keys that are not tensors are passed through."""
+    out = {}
+
+    def put(t):
+        if not torch.is_tensor(t) or t.device.type != 'cpu' or torch.device(device).type != 'cuda':
+            return t.to(device) if torch.is_tensor(t) else t
+        src = t if t.is_pinned() else t.contiguous().pin_memory()
+        return src.to(device, non_blocking=True)
+    if torch.device(device).type == 'cuda':
+        with torch.cuda.stream(stream):
+            for k, v in data.items():
+                out[k] = {kk: put(vv) for kk, vv in v.items()} if isinstance(v, dict) or hasattr(v, 'items') else put(v)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return out, ev
+    for k, v in data.items():
+        out[k] = {kk: put(vv) for kk, vv in v.items()} if isinstance(v, dict) or hasattr(v, 'items') else put(v)
+    return out, None
+
+
+def _prefetched(host_iter, device):
+    """Yield (batch_idx, dl_idx, device batch) with the copy of batch i + 1 in flight on a copy stream while batch i is consumed;
+    ends with (None, None, None)."""
+    cuda = torch.device(device).type == 'cuda'
+    stream = torch.cuda.Stream() if cuda else None
+    it = iter(host_iter)
+
+    def start():
+        try:
+            bi, di, data = next(it)
+        except StopIteration:
+            return None
+        dev, ev = _to_device_async(data, device, stream)
+        return bi, di, dev, ev
+    nxt = start()
+    while nxt is not None:
+        bi, di, dev, ev = nxt
+        nxt = start()                    # the next batch's host work + copy start BEFORE this batch's step is enqueued
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            for v in dev.values():       # the tensors were allocated on the copy stream: tell the allocator who uses them
+                for t in (v.values() if isinstance(v, dict) else [v]):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(torch.cuda.current_stream())
+        yield bi, di, dev
+    yield None, None, None
+
+
 class Multi_Trainer_dist(Multi_BaseTrainer_dist):
     """Drop-in for the reference's trainer class (trainer/trainer_egoclip.py:29-275): same constructor, `train()` /
     checkpointing from the base class (egovlp_amd.base.Multi_BaseTrainer_dist == base/base_trainer.py:239-480), the
@@ -143,6 +193,23 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
         self.n_gpu = self.args.world_size
         self.allgather = AllGather_multi.apply
 
+    def _host_batches(self):
+        """(batch_idx, dl_idx, data on the HOST) in the reference's order and with its stopping rules (:104-108,158-159)."""
+        for batch_idx, data_li in enumerate(zip(*self.data_loader)):
+            if (batch_idx + 1) * self.total_batch_sum > self.max_samples_per_epoch:
+                break
+            for dl_idx, data in enumerate(data_li):
+                if 'video_neg' in data.keys():                              # :109-113, scene-aware negatives: B -> 2B
+                    data['text'] = data['text'] + data['text_neg']
+                    data['video'] = torch.cat((data['video'], data['video_neg']), axis=0)
+                    data['noun_vec'] = torch.cat((data['noun_vec'], data['noun_vec_neg']), axis=0)
+                    data['verb_vec'] = torch.cat((data['verb_vec'], data['verb_vec_neg']), axis=0)
+                if self.tokenizer is not None:
+                    data['text'] = self.tokenizer(data['text'], return_tensors='pt', padding=True, truncation=True)
+                yield batch_idx, dl_idx, data
+            if batch_idx == self.len_epoch:
+                break
+
     def _adjust_learning_rate(self, optimizer, epoch, args):
         lr = args.learning_rate1                                            # :75-80
         for milestone in args.schedule:
@@ -156,31 +223,21 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
         for loader in self.data_loader:
             if hasattr(loader, 'train_sampler'):
                 loader.train_sampler.set_epoch(epoch)                       # :101-102
-        for batch_idx, data_li in enumerate(zip(*self.data_loader)):
-            if (batch_idx + 1) * self.total_batch_sum > self.max_samples_per_epoch:
+        # The reference moves every batch to the device with blocking `.to(device)` calls on the compute stream right before the
+        # step (:115-121).  Here the NEXT batch is prepared (negatives concatenated, captions tokenised), staged in pinned host
+        # memory and copied on a private copy stream while the current step runs; the step only waits for the copy's event.
+        feed = _prefetched(self._host_batches(), self.device)
+        for batch_idx, dl_idx, data in feed:
+            if batch_idx is None:
                 break
-            for dl_idx, data in enumerate(data_li):
-                if 'video_neg' in data.keys():                              # :109-113, scene-aware negatives: B -> 2B
-                    data['text'] = data['text'] + data['text_neg']
-                    data['video'] = torch.cat((data['video'], data['video_neg']), axis=0)
-                    data['noun_vec'] = torch.cat((data['noun_vec'], data['noun_vec_neg']), axis=0)
-                    data['verb_vec'] = torch.cat((data['verb_vec'], data['verb_vec_neg']), axis=0)
-                if self.tokenizer is not None:
-                    data['text'] = self.tokenizer(data['text'], return_tensors='pt', padding=True, truncation=True)
-                data['text'] = {k: v.to(self.device) for k, v in data['text'].items()}
-                data['video'] = data['video'].to(self.device)
-                data['noun_vec'] = data['noun_vec'].to(self.device)
-                data['verb_vec'] = data['verb_vec'].to(self.device)
-                loss = egoclip_step(self.model, self.loss, self.optimizer, data, self.n_gpu, self.args.rank,
-                                    grad_sync=self.grad_sync)
-                total_loss[dl_idx] += loss      # stays on the device: no per-step .item() sync (reference :148,150)
-                if self.writer is not None and self.args.rank == 0 and batch_idx % self.log_step == 0:
-                    total = int(self.data_loader[dl_idx].n_samples / self.n_gpu) if hasattr(self.data_loader[dl_idx], 'n_samples') else 0
-                    current = batch_idx * self.data_loader[dl_idx].batch_size
-                    final_total = (epoch - 1) * total + current
-                    self.writer.add_scalar(f'Loss_training/loss_{dl_idx}', float(loss), final_total)   # :143-148
-            if batch_idx == self.len_epoch:
-                break
+            loss = egoclip_step(self.model, self.loss, self.optimizer, data, self.n_gpu, self.args.rank,
+                                grad_sync=self.grad_sync)
+            total_loss[dl_idx] += loss      # stays on the device: no per-step .item() sync (reference :148,150)
+            if self.writer is not None and self.args.rank == 0 and batch_idx % self.log_step == 0:
+                total = int(self.data_loader[dl_idx].n_samples / self.n_gpu) if hasattr(self.data_loader[dl_idx], 'n_samples') else 0
+                current = batch_idx * self.data_loader[dl_idx].batch_size
+                final_total = (epoch - 1) * total + current
+                self.writer.add_scalar(f'Loss_training/loss_{dl_idx}', float(loss), final_total)   # :143-148
         log = {f'loss_{dl_idx}': float(total_loss[dl_idx]) / self.len_epoch for dl_idx in range(len(self.data_loader))}   # :162-164
         if self.writer is not None and self.args.rank == 0:
             for dl_idx in range(len(self.data_loader)):

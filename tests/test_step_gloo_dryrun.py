@@ -40,7 +40,13 @@ def _digest(tensors):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, out, exchange):
+TINY_VIDEO = {"model": "SpaceTimeTransformer", "arch_config": "custom", "num_frames": 4, "pretrained": True, "time_init": "rand",
+              "arch_kwargs": dict(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2)}
+TINY_TEXT = {"model": "distilbert-base-uncased", "pretrained": True, "input": "text",
+             "config": dict(vocab_size=30522, dim=128, n_layers=2, n_heads=2, hidden_dim=256)}
+
+
+def _worker(rank, world, port, out, exchange, tiny=False, B=2):
     for p in (HERE, os.path.dirname(HERE)):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -56,21 +62,37 @@ def _worker(rank, world, port, out, exchange):
     from egovlp_amd.synth import synth_batch
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
     torch.manual_seed(100 + rank)                         # different initial weights per rank: the broadcast must fix that
-    model = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 4,
-                                       "pretrained": True, "time_init": "rand"},
-                         text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
-                         projection="minimal", load_checkpoint="").train()
+    if tiny:
+        model = FrozenInTime(video_params=dict(TINY_VIDEO), text_params=dict(TINY_TEXT), projection="minimal", load_checkpoint="").train()
+    else:
+        model = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 4,
+                                           "pretrained": True, "time_init": "rand"},
+                             text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
+                             projection="minimal", load_checkpoint="").train()
     model.text_model.seed_rank = rank
     ec = model.exec_ctx
     sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
-                        exchange=exchange, pack_fn=_pack, unpack_fn=_unpack, slice_sum_fn=_slice_sum)
+                        exchange=exchange, pack_fn=_pack, unpack_fn=_unpack, slice_sum_fn=_slice_sum,
+                        **({"bucket_mb": 1.0} if tiny else {}))
     w0 = _digest(p for p in model.parameters())
     ec.set(backward_poll=sync.poll, gemm_grid=248)
     ec.set_precision("bf16x3", "bf16")
     opt = AdamW(model.parameters(), lr=3e-5)
-    b = synth_batch(2, T=2, L=16, seed=3, rank=rank)
+    b = synth_batch(B, T=2, L=16, seed=3, rank=rank, **({"res": 32} if tiny else {}))
     data = {"video": b["video"], "text": b["text"], "noun_vec": b["noun_vec"], "verb_vec": b["verb_vec"]}
     steps = []
+    gathered = []
+    if tiny:    # what the loss sees after the fused gather: record the shapes egv_egonce_fwd_bwd is called with
+        from egovlp_amd import ops as _ops
+        _orig = _ops.egonce_fwd_bwd
+
+        def spy(text, video, noun, verb, *a, **k):
+            gathered.append((tuple(text.shape), tuple(video.shape), tuple(noun.shape), tuple(verb.shape)))
+            return _orig(text, video, noun, verb, *a, **k)
+        _ops.egonce_fwd_bwd = spy
+        import egovlp_amd.model.loss as _loss_mod
+        if hasattr(_loss_mod, "ops"):
+            _loss_mod.ops.egonce_fwd_bwd = spy
     with mock_hip() as calls:
         for step in range(2):
             calls.clear()
@@ -87,7 +109,8 @@ def _worker(rank, world, port, out, exchange):
                           "grads": _digest(p.grad for p in model.parameters()),
                           "first": float(next(model.parameters()).grad.reshape(-1)[0]),
                           "gemm_calls": calls.count("egv_gemm_nt"), "adamw": calls.count("egv_adamw_multi")})
-    torch.save({"w0": w0, "steps": steps}, os.path.join(out, f"rank{rank}.pt"))
+    torch.save({"w0": w0, "steps": steps, "gathered": gathered, "slices": [int(x) for x in getattr(sync, "slice_elems", [])]},
+               os.path.join(out, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -110,3 +133,24 @@ def test_multi_rank_step_on_the_real_model(tmp_path, exchange, world):
         for x in (y["steps"][step] for y in r):
             assert x["during"] >= x["buckets"] - 1, x                 # only the tail bucket may be left to finish()
             assert x["gemm_calls"] == 12 * 18 + 2 + 6 * 12 + 2 * 3 and x["adamw"] >= 1
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_step_on_a_toy_model(tmp_path):
+    """World size 8 (the node the metric is quoted on) -- on a toy dual encoder so that eight CPU processes fit: the fused
+    embedding gather hands the loss the GLOBAL batch (n = 8 x 32 = 256 rows of each of the four gathered tensors: the size
+    egv_egonce_fwd_bwd runs at on the 8-GPU node), the direct exchange cuts every bucket into 8 slices (slice alignment), all
+    ranks issue the same collectives in the same order (else: hang -> timeout) and end with bit-identical gradients."""
+    world, B = 8, 32
+    mp.spawn(_worker, args=(world, 29699, str(tmp_path), "direct", True, B), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"rank{i}.pt"), weights_only=False) for i in range(world)]
+    assert all(x["w0"] == r[0]["w0"] for x in r)
+    for step in range(2):
+        a = r[0]["steps"][step]
+        for x in r[1:]:
+            assert x["steps"][step]["grads"] == a["grads"] and x["steps"][step]["buckets"] == a["buckets"] >= 2
+        # mean over the eight ranks of (rank + 1 + s/4 + i%7) = 4.5 + s/4 + i%7: exact in bf16
+        assert abs((a["first"] % 1.0) - (0.5 + 0.25 * step) % 1.0) < 1e-6, a["first"]
+    for x in r:
+        assert x["gathered"] and all(g[0][0] == world * B and g[1][0] == world * B and g[2][0] == world * B and g[3][0] == world * B
+                                     for g in x["gathered"]), x["gathered"][:1]

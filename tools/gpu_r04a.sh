@@ -6,7 +6,7 @@ O=$GRAFT_REPO_ROOT/gpurun_out/r04a; mkdir -p $O
 ( timeout 1500 python -m pytest tests/test_gpu_model.py -m gpu -q -s -k "f16f6 or full_size_train_step" 2>&1 | grep -v "amdgpu\|^$" | tail -150 ) > $O/t_model.txt 2>&1
 for rep in 1 2; do
 for prec in mixed f16f6; do
-  ( timeout 600 python bench.py --precision $prec --steps 20 --warmup 5 --no-trajectory --no-fast-mode --no-cpu-baseline > $O/bench_${prec}_$rep.json 2> $O/bench_${prec}_$rep.err )
+  ( timeout 600 python bench.py --precision $prec --steps 20 --warmup 5 --no-trajectory --no-h2d-leg --no-fast-mode --no-cpu-baseline > $O/bench_${prec}_$rep.json 2> $O/bench_${prec}_$rep.err )
 done; done
 grep -h "passed\|failed\|error" $O/t_f16f6.txt $O/t_model.txt | tail; for f in $O/bench_*.json; do python - $f <<'PY'
 import json,sys
