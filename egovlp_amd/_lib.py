@@ -41,7 +41,6 @@ class GemmDesc(C.Structure):
         ("colsum", c_p),
         ("grid_cap", i32), ("out_fmt", i32),
         ("out_bf", c_p),
-        ("tickets", c_p),
     ]
 
 

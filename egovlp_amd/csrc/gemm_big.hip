@@ -148,27 +148,6 @@ __device__ __forceinline__ void tie(u32x2_t& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void anchor(const f32x4_t& x) { asm volatile("" ::"v"(x)); }   // "x exists here": stops code sinking
 __device__ __forceinline__ void tie(unsigned& x) { asm volatile("" : "+v"(x)); }
 
-// Write-through ("sc1": system-coherent level 1 = past this XCD's L2) stores and loads of the split-K slabs that another workgroup,
-// possibly on another XCD, reads inside the same launch.  The alternative publish -- plain stores + an agent-scope RELEASE fence --
-// writes back every dirty line of the XCD's L2, i.e. also what the kernels of the other streams have just produced: measured
-// 1.3 ms per step SLOWER than the separate reduce launch it was meant to replace (profiles/r04h_splitk_in_kernel_ab.txt).
-__device__ __forceinline__ void st16_sc1(float* p, const f32x4_t& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st4_sc1(float* p, float v) {
-  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ f32x4_t ld16_sc1(const float* p) {      // the caller waits (s_waitcnt vmcnt) before using the value
-  f32x4_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ float ld4_sc1(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
 // Loop condition of the ROLLED epilogue loops.  LLVM's block-frequency estimate multiplies by ~32 per loop level, so a
 // rolled two-level epilogue loop looks "hotter" than the k-tile loop and the register allocator spills the main loop's
 // A / B fragments to keep epilogue temporaries in registers; a 50 % back-edge probability tells it the truth.
@@ -1173,8 +1152,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
               f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5)));
               if (EPI == EPI_LINEAR) val += bias4;
-              if (TN && EPI == EPI_RAW && ksplit > 1 && p.tickets != nullptr) st16_sc1(d, val);   // read by the last-arriving slice
-              else egv_store16<EGV_NT_GEMM_F32>(d, val);
+              egv_store16<EGV_NT_GEMM_F32>(d, val);
               d += ld2;
             }
           }
@@ -1313,78 +1291,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         const int m = mw + i * 16 + (el & 15);
-        if (ksplit > 1 && p.tickets != nullptr) st4_sc1(p.partial + (long)ksplit * p.M * p.N + (long)z * p.M + m, cs[i][0]);
-        else if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
+        if (ksplit > 1) p.partial[(long)ksplit * p.M * p.N + (long)z * p.M + m] = cs[i][0];
         else p.colsum[m] = cs[i][0];
       }
     }
-    // ---- split-K without a second launch (TN weight gradients): the LAST-ARRIVING k-slice of an output tile sums the slabs.
-    // Every slice has written its fp32 partial tile (and partial column sums) above with write-through stores; once they have
-    // left the CU (vmcnt 0, workgroup barrier) one lane draws a ticket from the tile's counter (relaxed, agent scope); the
-    // workgroup that draws ksplit - 1 reads all slabs with sc1 loads and adds them in slice order 0 .. ksplit - 1 (the order of the
-    // separate reduce kernel: bit-identical results), while they are still in the Infinity Cache.  Placement-independent
-    // (cdna_hip_programming.md Guideline 16, the write-through form: no fence); nobody waits for anybody.  Counters: p.tickets[tiles],
-    // zeroed by the launcher's memset node on the stream.
-    if constexpr (TN) {
-      if (ksplit > 1 && p.tickets != nullptr) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int tq = (wave << 6) | el;                    // == threadIdx.x, rebuilt from what is live anyway
-        int* const sflag = (int*)(smem + STAGE);            // this tile's staging rows: every wave has read its own back (lgkmcnt(0) above)
-        const int tile_id = v - z * nwg;
-        if (tq == 0) *sflag = __hip_atomic_fetch_add(p.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const bool last_arriver = *(volatile int*)sflag == ksplit - 1;
-        if (last_arriver) {
-          // 256 x 256 fp32 tile, one workgroup: a wave owns rows wave, wave + 8, ...; TWO rows x FOUR slabs (8 loads of 1 KiB per
-          // wave, 64 KiB per workgroup) are in flight per wait -- the reduction is a dependent-latency chain on one CU
-          const long slab = (long)p.M * p.N;
-          const int cc = el * 4;
-#pragma unroll 1
-          for (int r0 = wave; r0 < BM; r0 += 16) {
-            f32x4_t sum0, sum1;
-            const float* src0 = p.partial + (long)(m0 + r0) * p.N + n0 + cc;
-            const float* src1 = src0 + 8 * (long)p.N;
-#pragma unroll 1
-            for (int z0 = 0; z0 < ksplit; z0 += 4) {
-              f32x4_t b0[4], b1[4];
-              static_for<0, 4>([&](auto Qc) {
-                constexpr int q = decltype(Qc)::value;
-                b0[q] = b1[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                if (z0 + q < ksplit) {
-                  b0[q] = ld16_sc1(src0 + (long)(z0 + q) * slab);
-                  b1[q] = ld16_sc1(src1 + (long)(z0 + q) * slab);
-                }
-              });
-              asm volatile("s_waitcnt vmcnt(0)"
-                           : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3])::"memory");
-              static_for<0, 4>([&](auto Qc) {
-                constexpr int q = decltype(Qc)::value;
-                if (z0 + q == 0) { sum0 = b0[q]; sum1 = b1[q]; }
-                else if (z0 + q < ksplit) { sum0 += b0[q]; sum1 += b1[q]; }
-              });
-            }
-            egv_store16<EGV_NT_WGRAD>(p.out_f32 + (long)(m0 + r0) * p.ldo + n0 + cc, sum0);
-            egv_store16<EGV_NT_WGRAD>(p.out_f32 + (long)(m0 + r0 + 8) * p.ldo + n0 + cc, sum1);
-          }
-          if (p.colsum != nullptr && tn == 0 && tq < BM) {
-            const float* csrc = p.partial + (long)ksplit * slab + m0 + tq;
-            float cs_sum = ld4_sc1(csrc);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs_sum)::"memory");
-#pragma unroll 1
-            for (int zz = 1; zz < ksplit; ++zz) {
-              float c2 = ld4_sc1(csrc + (long)zz * p.M);
-              asm volatile("s_waitcnt vmcnt(0)" : "+v"(c2)::"memory");
-              cs_sum += c2;
-            }
-            p.colsum[m0 + tq] = cs_sum;
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // the flag word is staging space of the next tile
-      }
-    }
+    // (Summing the split-K slabs of a weight gradient inside this launch -- last-arriving k-slice, write-through slabs, relaxed
+    // ticket -- was built in round 4, bit-identical to the separate reduce kernel, and measured 0.6 % SLOWER in the step: the reduce
+    // launches hide in the gaps of the side streams, the serial tail of one workgroup does not.  profiles/r04h_splitk_in_kernel_ab.txt)
 #ifdef EGV_DIAG
     if ((dbg & 0xfff) == 200 && tid == 0) {
       unsigned long long* tsb = (unsigned long long*)p.aux_out + (long)v * 4;

@@ -261,11 +261,6 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   if (p.grid_cap != 0 && (p.grid_cap < 8 || p.grid_cap > 256 || p.grid_cap % 8 != 0)) return EGV_ERR_ARG;
   const int variant = gemm_variant(p);
   if (variant < 0) return EGV_ERR_ARG;
-  if (p.tickets != nullptr) {
-    if (!p.trans || p.ksplit <= 1 || p.accumulate || !p.out_f32 || !p.partial) return EGV_ERR_ARG;
-    const int tk_tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (hipMemsetAsync(p.tickets, 0, sizeof(int32_t) * tk_tiles, (hipStream_t)stream) != hipSuccess) return EGV_ERR_LAUNCH;
-  }
   if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // bf16 aux: gemm_big GELU epilogues only
   // f16f6 operands / outputs (csrc/f6.h): the big-tile NT kernel only, K and lda / ldb in whole 32-element MX blocks
   if ((p.passes == 2 || p.out_fmt != 0) && (variant < 3 || p.trans || p.passes != 2 || p.K % 32 != 0 || p.lda % 32 != 0 || p.ldb % 32 != 0))
@@ -289,8 +284,6 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
     const long mn4 = (long)p.M * p.N / 4;
     EGV_LAUNCH(splitk_reduce_epilogue_kernel, dim3((int)((mn4 + 255) / 256)), dim3(256), 0, s, p, ks);
     EGV_CHECK_LAUNCH();
-  } else if (ks > 1 && p.tickets != nullptr) {
-    // the slabs were summed by the last-arriving k-slice of every tile inside the GEMM launch (gemm_big.hip)
   } else if (ks > 1) {
     if (!p.out_f32 || p.ldo != p.N) return EGV_ERR_ARG;
     const long mn = (long)p.M * p.N;

@@ -486,7 +486,7 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
                  _p(out_planes.hi) if out_planes is not None else None, _p(out_planes.lo) if out_planes is not None else None,
                  out_planes.ld if out_planes is not None else 0,
                  ksplit, 0, _p(partial), 0, aux_bf16, None, ec.gemm_grid, out_fmt,
-                 _p(out_planes.bf) if out_fmt else None, None)
+                 _p(out_planes.bf) if out_fmt else None)
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * K,
@@ -554,16 +554,10 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         div = _WGRAD_KSPLIT_DIV or ((3 if ec._side["extra"] else 2) if ec.on_side_stream() else 1)
         ksplit = max(1, min(ec.gemm_grid // max(tiles, 1) // div, nkt // 2))
     cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
-    # k-slice slabs + per-slice column sums + (behind them) one arrival counter per output tile: the slice that arrives last at a
-    # tile sums the slabs inside the GEMM launch (egv_gemm_desc.tickets) -- no separate reduce kernel
-    tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    nslab = ksplit * (M * N + M)
-    in_kernel = ksplit > 1 and SPLITK_IN_KERNEL and out_f32.stride(0) == N
-    partial = torch.empty(nslab + (tiles if in_kernel else 0), dtype=torch.float32, device=dev) if ksplit > 1 else None
-    tickets = partial.data_ptr() + 4 * nslab if in_kernel else None
+    partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
     d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, Kd, passes, 1.0, ACT_NONE, None,
                  None, 0, None, None, 0, _p(out_f32), out_f32.stride(0), None, None, 0,
-                 ksplit, 0, _p(partial), 1, 0, _p(cs), ec.gemm_grid, 0, None, tickets)
+                 ksplit, 0, _p(partial), 1, 0, _p(cs), ec.gemm_grid, 0, None)
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * Kd,
@@ -572,9 +566,6 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt(trans)")
     return cs
-
-
-SPLITK_IN_KERNEL = os.environ.get("EGV_SPLITK_IN_KERNEL", "1") == "1"    # 0: slabs + the separate reduce launch (A/B, tests)
 
 
 def pick_ksplit(M, N, K):

@@ -76,10 +76,6 @@ typedef struct egv_gemm_desc {
                        out_lo = MXFP6 slot plane; EGV_ACT_GELU of a passes == 2 product only: fc1 -> fc2 of the forward).           */
   egv_bf16* out_bf; /* out_fmt == 1, optional: bf16(value) as a third plane [M, ldoh] -- the single-pass operand the backward GEMMs
                        (wgrad) read, since an fp16 plane cannot share an MFMA with bf16 gradients.                               */
-  int32_t* tickets; /* trans == 1 with ksplit > 1, optional: [tiles = ceil(M / 256) * ceil(N / 256)] int32 arrival counters (zeroed by the
-                       call itself).  When given, the k-slice of a tile that arrives LAST sums the fp32 slabs in `partial` into out_f32
-                       (and the column sums) inside the GEMM launch -- in slice order, bit-identical to the separate reduce kernel,
-                       which is then not launched.  accumulate must be 0.                                                       */
 } egv_gemm_desc;
 int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
 /* ---- format kernels (HBM-bound) -----------------------------------------------------------------

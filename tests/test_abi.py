@@ -42,10 +42,10 @@ def test_gemm_desc_layout_matches_header(tmp_path):
     import shutil
     import subprocess
     from egovlp_amd._lib import GemmDesc
-    assert ctypes.sizeof(GemmDesc) == 216
+    assert ctypes.sizeof(GemmDesc) == 208
     assert GemmDesc.M.offset == 48 and GemmDesc.bias.offset == 72 and GemmDesc.partial.offset == 168
     assert GemmDesc.trans.offset == 176 and GemmDesc.aux_bf16.offset == 180 and GemmDesc.colsum.offset == 184 and GemmDesc.grid_cap.offset == 192
-    assert GemmDesc.out_fmt.offset == 196 and GemmDesc.out_bf.offset == 200 and GemmDesc.tickets.offset == 208
+    assert GemmDesc.out_fmt.offset == 196 and GemmDesc.out_bf.offset == 200
     if shutil.which("gcc") is None:
         pytest.skip("no host C compiler")
     fields = [f[0] for f in GemmDesc._fields_]

@@ -249,29 +249,6 @@ def test_gemm_tn_wgrad(ops, passes, Mtok, N, K, ksplit):
     assert torch.equal(dw, dw2)
 
 
-@pytest.mark.parametrize("Mtok,N,K,ksplit", [(25120, 768, 768, 9), (25120, 2304, 768, 3), (6280, 768, 3072, 2), (3140, 300 * 8, 264, 5),
-                                              (25120, 3072, 768, None)])
-def test_gemm_tn_in_kernel_splitk_reduce_is_bit_identical(ops, Mtok, N, K, ksplit):
-    """The last-arriving k-slice of a tile sums the slabs inside the GEMM launch (egv_gemm_desc.tickets): same slabs, same order as
-    the separate reduce kernel -> the same bits, weight gradient and bias gradient, incl. shifted (overlapping) last tiles and many
-    repetitions (the arrival counters are re-zeroed by every call)."""
-    g = torch.Generator().manual_seed(Mtok + N + K)
-    dy, x = torch.randn(Mtok, N, generator=g), torch.randn(Mtok, K, generator=g) + 0.25
-    dyp, xp = planes_from(ops, dy, 1), planes_from(ops, x, 1)
-    assert ops.SPLITK_IN_KERNEL
-    try:
-        ops.SPLITK_IN_KERNEL = False
-        ref = torch.empty(N, K, device="cuda")
-        ref_b = ops.gemm_tn(dyp, xp, passes=1, out_f32=ref, want_colsum=True, ksplit=ksplit)
-    finally:
-        ops.SPLITK_IN_KERNEL = True
-    for rep in range(4):
-        dw = torch.full((N, K), float("nan"), device="cuda")
-        db = ops.gemm_tn(dyp, xp, passes=1, out_f32=dw, want_colsum=True, ksplit=ksplit)
-        assert torch.equal(dw, ref) and torch.equal(db, ref_b), rep
-    assert rel(ref, dy.to(torch.bfloat16).double().t() @ x.to(torch.bfloat16).double()) < 1e-5
-
-
 # ---------------------------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("cols", [64, 768, 1024])
 def test_layernorm_fwd_bwd(ops, cols):
