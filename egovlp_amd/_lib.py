@@ -44,6 +44,30 @@ class GemmDesc(C.Structure):
     ]
 
 
+class BlockGeom(C.Structure):
+    """egv_block_geom."""
+    _fields_ = [("B", i32), ("T", i32), ("n", i32), ("H", i32), ("D", i32), ("Hd", i32),
+                ("fwd_passes", i32), ("bwd_passes", i32), ("train", i32), ("z_bf16", i32), ("eps", f32), ("grid_cap", i32)]
+
+
+class BlockParams(C.Structure):
+    """egv_block_params."""
+    _fields_ = [("n3w", c_p), ("n3b", c_p), ("n1w", c_p), ("n1b", c_p), ("n2w", c_p), ("n2b", c_p),
+                ("bias", c_p * 6),
+                ("w_hi", c_p * 6), ("w_lo", c_p * 6), ("ldw", i64 * 6),
+                ("wt_hi", c_p * 6), ("wt_lo", c_p * 6), ("ldwt", i64 * 6)]
+
+
+class BlockBwdIO(C.Structure):
+    """egv_block_bwd_io."""
+    _fields_ = [("g_out", c_p), ("g_hi", c_p), ("g_lo", c_p),
+                ("x", c_p), ("fwd_arena", c_p), ("bwd_arena", c_p),
+                ("d_x", c_p), ("dx_hi", c_p), ("dx_lo", c_p),
+                ("grads", c_p),
+                ("side_stream", c_p * 6), ("side_event", c_p * 6),
+                ("wgrad_ksplit", i32 * 6)]
+
+
 # name -> (restype, argtypes); mirrors include/egovlp_hip.h one to one (tests/test_abi.py checks it)
 PROTOTYPES = {
     "egv_gemm_nt": (i32, [C.POINTER(GemmDesc), c_p]),
@@ -85,6 +109,12 @@ PROTOTYPES = {
     "egv_f16f6_encode": (i32, [c_p, i64, i32, i32, c_p, c_p, c_p, i64, c_p]),
     "egv_f16f6_encode_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_layernorm_fwd_f16f6": (i32, [c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
+    "egv_block_fwd_arena_bytes": (i64, [C.POINTER(BlockGeom)]),
+    "egv_block_fwd_offsets": (i32, [C.POINTER(BlockGeom), c_p]),
+    "egv_block_fwd": (i32, [C.POINTER(BlockGeom), C.POINTER(BlockParams), c_p, c_p, c_p, c_p]),
+    "egv_block_bwd_arena_bytes": (i64, [C.POINTER(BlockGeom), c_p]),
+    "egv_block_grad_layout": (i32, [C.POINTER(BlockGeom), c_p, c_p]),
+    "egv_block_bwd": (i32, [C.POINTER(BlockGeom), C.POINTER(BlockParams), C.POINTER(BlockBwdIO), c_p]),
     "egv_diag_mfma_peak": (i32, [i32, i32, c_p, c_p]),
     "egv_diag_traffic_calib": (i32, [i32, c_p, c_p, i64, c_p]),
 }

@@ -209,6 +209,177 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
                 d_n2w, d_n2b, d_fc1_w.view_as(fc1_w), d_fc1_b, d_fc2_w.view_as(fc2_w), d_fc2_b)
 
 
+# ---------------------------------------------------------------------------------------------- one C call per block
+# The same block through egv_block_fwd / egv_block_bwd (csrc/block.hip): the C side enqueues the block's kernels with pointers into
+# one workspace arena per direction.  What stays in Python is policy: which precision, which stream each weight gradient goes to,
+# how many k-slices it gets, the gradient-plane hand-over between blocks, the backward poll of the gradient exchange.
+_BLOCK_CACHE = {}      # geometry -> (forward arena bytes, gradient offsets, gradient floats)
+_BLOCK_BWD_BYTES = {}  # (geometry, k-slices) -> backward arena bytes
+_W_ORDER = ("tqkv", "tproj", "sqkv", "sproj", "fc1", "fc2")
+
+
+def block_calls_ok(ec: ExecContext, M, D, Hd):
+    """May this block run through the C block calls?  (split-bf16 / bf16 precision, no per-kernel timer attached, every GEMM of
+    the block un-split and at least one 256-wide tile: the per-kernel path covers the toy shapes and the f16f6 mode)"""
+    if not ec.block_calls or ec.kernel_timer is not None or ec.fwd_passes not in (1, 3) or ec.bwd_passes > ec.fwd_passes:
+        return False
+    if D < 256 or Hd < 256 or D % 64 or Hd % 64 or M < 256:
+        return False
+    return all(ops.auto_ksplit_nt(*sh) == 1 for sh in ((M, 3 * D, D), (M, D, D), (M, Hd, D), (M, D, Hd), (M, D, 3 * D)))
+
+
+def _block_geom(B, T, n, H, D, Hd, P, Pb, train, z_bf16, eps, grid):
+    from .._lib import BlockGeom
+    return BlockGeom(B, T, n, H, D, Hd, P, Pb, int(train), int(z_bf16), float(eps), int(grid))
+
+
+_BLOCK_PARAMS = {}     # device addresses of a block's parameters and weight planes -> the egv_block_params built from them
+
+
+def _block_params(wc, ln, biases, weights, need_t):
+    """egv_block_params from the parameter tensors: LayerNorm affine (n3w, n3b, n1w, n1b, n2w, n2b), the six biases and the
+    cached operand planes of the six weights (W^T planes too when `need_t`).  The planes are refreshed IN PLACE after an optimizer
+    step, so the addresses -- and with them the struct -- stay the same from step to step: it is built once per block and direction."""
+    import ctypes as C
+    from .._lib import BlockParams
+    P6, L6 = C.c_void_p * 6, C.c_int64 * 6
+    pls = [wc.get(w, need_t=need_t) for w in weights]
+    key = (need_t,) + tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in biases) \
+        + tuple(p.hi.data_ptr() for p, _ in pls) + (tuple(t.hi.data_ptr() for _, t in pls) if need_t else ())
+    hit = _BLOCK_PARAMS.get(key)
+    if hit is not None:
+        return hit
+    if len(_BLOCK_PARAMS) > 4096:
+        _BLOCK_PARAMS.clear()
+    whi, wlo, ldw = P6(*[p.hi.data_ptr() for p, _ in pls]), P6(*[p.lo.data_ptr() for p, _ in pls]), L6(*[p.ld for p, _ in pls])
+    if need_t:
+        thi, tlo, ldt = P6(*[t.hi.data_ptr() for _, t in pls]), P6(*[t.lo.data_ptr() for _, t in pls]), L6(*[t.ld for _, t in pls])
+    else:
+        thi, tlo, ldt = P6(), P6(), L6()
+    prm = _BLOCK_PARAMS[key] = BlockParams(*[t.data_ptr() for t in ln], P6(*[b.data_ptr() for b in biases]), whi, wlo, ldw, thi, tlo, ldt)
+    return prm
+
+
+class _SpaceTimeBlockCFn(torch.autograd.Function):
+    """SpaceTimeBlock.forward / backward as ONE C-ABI call each (see _SpaceTimeBlockFn for the arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, x, geom, ec: ExecContext,
+                n3w, n3b, tqkv_w, tqkv_b, tproj_w, tproj_b,
+                n1w, n1b, sqkv_w, sqkv_b, sproj_w, sproj_b,
+                n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
+        import ctypes as C
+        from .. import _lib
+        B, T, n, H, eps = geom
+        S = 1 + T * n
+        D = x.shape[-1]
+        M = B * S
+        Hd = fc1_w.shape[0]
+        P, Pb = ec.fwd_passes, ec.bwd_passes
+        dev = x.device
+        x2 = x.contiguous().view(M, D)
+        train = any(ctx.needs_input_grad)
+        z_bf16 = Pb == 1 and ops.uses_big_gemm(M, Hd, D)
+        key = (B, T, n, H, D, Hd, P, Pb, train, z_bf16)
+        g = _block_geom(*key, eps, ec.gemm_grid)
+        ent = _BLOCK_CACHE.get(key)
+        if ent is None:
+            off, tot = (C.c_int64 * 18)(), C.c_int64()
+            nb = int(_lib.lib().egv_block_fwd_arena_bytes(C.byref(g)))
+            _lib.check(_lib.lib().egv_block_grad_layout(C.byref(g), off, C.byref(tot)), "egv_block_grad_layout")
+            if nb <= 0:
+                raise _lib.EgovlpHipError("egv_block_fwd_arena_bytes: unsupported block geometry")
+            ent = _BLOCK_CACHE[key] = (nb, tuple(int(o) for o in off), int(tot.value))
+        arena = torch.empty(ent[0], dtype=torch.uint8, device=dev)
+        out = torch.empty((M, D), dtype=torch.float32, device=dev)
+        ln = (n3w, n3b, n1w, n1b, n2w, n2b)
+        biases = (tqkv_b, tproj_b, sqkv_b, sproj_b, fc1_b, fc2_b)
+        weights = (tqkv_w, tproj_w, sqkv_w, sproj_w, fc1_w, fc2_w)
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=False)
+        _lib.check(_lib.lib().egv_block_fwd(C.byref(g), C.byref(prm), x2.data_ptr(), out.data_ptr(), arena.data_ptr(), ops._stream(x2)),
+                   "egv_block_fwd")
+        if train:
+            ctx.key, ctx.eps, ctx.ec, ctx.arena, ctx.sizes = key, eps, ec, arena, ent
+            ctx.save_for_backward(x2, *ln, *biases, *weights)
+        return out.view(B, S, D)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes as C
+        from .. import _lib
+        from .._lib import BlockBwdIO
+        saved = ctx.saved_tensors
+        x2, ln, biases, weights = saved[0], saved[1:7], saved[7:13], saved[13:19]
+        B, T, n, H, D, Hd, P, Pb, train, z_bf16 = ctx.key
+        ec = ctx.ec
+        ec.poll_backward()              # gradients of the blocks behind this one are final: the data-parallel exchange may start
+        Pb_now = ec.bwd_passes
+        if Pb_now != Pb:
+            raise RuntimeError("the backward precision changed between this block's forward and its backward")
+        S = 1 + T * n
+        M = B * S
+        dev = x2.device
+        G = g_out.contiguous().view(M, D)
+        # the gradient-plane hand-over of the block behind this one (see _attach_grad_planes)
+        g_hi = g_lo = None
+        ent = getattr(g_out, "_egv_planes", None)
+        if ent is not None:
+            try:
+                del g_out._egv_planes
+            except AttributeError:
+                pass
+            if ent[0] == Pb and ent[2] == g_out._version and ent[1].rows == M and ent[1].cols == D:
+                PLANE_HANDOFF["hit"] += 1
+                g_pl = ent[1]
+                g_hi, g_lo = g_pl.hi.data_ptr(), (g_pl.lo.data_ptr() if g_pl.lo is not None else None)
+        if g_hi is None:
+            PLANE_HANDOFF["miss"] += 1
+        # weight gradients in the order the C side enqueues them (fc2, fc1, attn.proj, attn.qkv, timeattn.proj, timeattn.qkv): stream,
+        # event and k-slices of each -- the policy of _lin_bwd / ops.gemm_tn
+        shapes = [(w.shape[0], w[0].numel()) for w in weights]
+        order = (5, 4, 3, 2, 1, 0)
+        side_ok = ec.wgrad_side_stream and not ec.on_text_stream()
+        use = [side_ok and weights[i].grad is None for i in range(6)]
+        deal = ec.assign_side_streams([float(M) * shapes[i][0] * shapes[i][1] for i in order if use[i]]) if any(use) else []
+        streams, events = [None] * 6, [None] * 6
+        it = iter(deal)
+        for i in order:
+            if use[i]:
+                streams[i], events[i] = next(it)
+        ks = [ops.wgrad_ksplit(shapes[i][0], shapes[i][1], M, ec, use[i]) for i in range(6)]
+        g = _block_geom(*ctx.key, ctx.eps, ec.gemm_grid)
+        bkey = (ctx.key, tuple(ks))
+        nb = _BLOCK_BWD_BYTES.get(bkey)
+        if nb is None:
+            nb = _BLOCK_BWD_BYTES[bkey] = int(_lib.lib().egv_block_bwd_arena_bytes(C.byref(g), (C.c_int32 * 6)(*ks)))
+        barena = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _, goff, gtot = ctx.sizes
+        grads = torch.empty(gtot, dtype=torch.float32, device=dev)
+        d_x = torch.empty((M, D), dtype=torch.float32, device=dev)
+        dx_pl = ops.empty_planes(M, D, Pb, dev)
+        for st in {s_ for s_ in streams if s_ is not None}:      # the side streams read / write these allocations of the main stream
+            for t in (ctx.arena, barena, grads) + ((g_pl.hi,) if g_hi is not None else ()):
+                t.record_stream(st)
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=True)
+        P6 = C.c_void_p * 6
+        io = BlockBwdIO(G.data_ptr(), g_hi, g_lo, x2.data_ptr(), ctx.arena.data_ptr(), barena.data_ptr(),
+                        d_x.data_ptr(), dx_pl.hi.data_ptr(), dx_pl.lo.data_ptr() if dx_pl.lo is not None else None, grads.data_ptr(),
+                        P6(*[s_.cuda_stream if s_ is not None else None for s_ in streams]),
+                        P6(*[e.cuda_event if e is not None else None for e in events]), (C.c_int32 * 6)(*ks))
+        _lib.check(_lib.lib().egv_block_bwd(C.byref(g), C.byref(prm), C.byref(io), ops._stream(x2)), "egv_block_bwd")
+        ctx.arena = None
+
+        sizes = [goff[i + 1] - goff[i] for i in range(17)] + [gtot - goff[17]]
+        parts = grads.split_with_sizes(sizes)                 # 18 views of the one buffer (the layout is back to back)
+        dW = [parts[i].view(weights[i].shape) for i in range(6)]
+        db = parts[6:12]
+        dln = parts[12:18]                                  # norm3 g/b, norm1 g/b, norm2 g/b
+        return (_attach_grad_planes(d_x.view(B, S, D), Pb, dx_pl), None, None,
+                dln[0], dln[1], dW[0], db[0], dW[1], db[1],
+                dln[2], dln[3], dW[2], db[2], dW[3], db[3],
+                dln[4], dln[5], dW[4], db[4], dW[5], db[5])
+
+
 class _PatchTokensFn(torch.autograd.Function):
     """VideoPatchEmbed (:72-77) + flatten/CLS/pos/temporal (:305-320): patch gather -> MFMA GEMM (+bias)
     -> token assembly.  No gradient flows to the input frames."""
@@ -349,7 +520,8 @@ class SpaceTimeBlock(nn.Module):
 
     def forward(self, x, B, T, n, ec):
         geom = (B, T, n, self.num_heads, self.norm1.eps)
-        return _SpaceTimeBlockFn.apply(
+        fn = _SpaceTimeBlockCFn if block_calls_ok(ec, B * (1 + T * n), x.shape[-1], self.mlp.fc1.weight.shape[0]) else _SpaceTimeBlockFn
+        return fn.apply(
             x, geom, ec,
             self.norm3.weight, self.norm3.bias, self.timeattn.qkv.weight, self.timeattn.qkv.bias,
             self.timeattn.proj.weight, self.timeattn.proj.bias,

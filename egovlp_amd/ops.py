@@ -56,6 +56,9 @@ _HARD_DEFAULTS = {
     # (egovlp_amd.dist.Bf16GradSync(use_hooks=False).poll)
     "backward_poll": None,
     "kernel_timer": None,
+    # one C-ABI call per SpaceTimeBlock forward / backward (egv_block_fwd / egv_block_bwd, one workspace arena per direction)
+    # instead of the per-kernel calls: the same launches, ~10x less host work.  Off: the per-kernel reference path.
+    "block_calls": os.environ.get("EGV_BLOCK_CALLS", "1") == "1",
 }
 
 
@@ -116,6 +119,7 @@ class ExecContext:
     gemm_grid = property(lambda self: self.get("gemm_grid"))
     backward_poll = property(lambda self: self.get("backward_poll"))
     kernel_timer = property(lambda self: self.get("kernel_timer"))
+    block_calls = property(lambda self: self.get("block_calls"))
 
     def poll_backward(self):
         fn = self.get("backward_poll")
@@ -157,6 +161,42 @@ class ExecContext:
         several side streams the body goes to the one with the least work dealt to it so far in this step (`cost`: any additive
         measure, the callers pass MACs)."""
         return _SideStream(self, inputs, cost)
+
+    def assign_side_streams(self, costs):
+        """The dealing of `side_stream()` for a batch of weight-gradient GEMMs that a C block call will enqueue itself: -> for each
+        cost a (torch stream, torch event) pair -- the event is recorded on the current stream and waited for by the side stream
+        INSIDE the C call -- and the same bookkeeping (`dirty`, the end-of-backward join callback, load accounting)."""
+        sd = self._side
+        main = torch.cuda.current_stream()
+        if sd["stream"] is None:
+            sd["stream"] = torch.cuda.Stream()
+            sd["extra"] = [torch.cuda.Stream() for _ in range(_wgrad_stream_count() - 1)]
+        pool = [sd["stream"]] + sd["extra"]
+        load = sd.get("load")
+        if load is None or len(load) != len(pool):
+            load = sd["load"] = [0.0] * len(pool)
+        evs = sd.get("events")
+        if evs is None or len(evs) < len(costs):
+            evs = sd["events"] = [torch.cuda.Event() for _ in range(max(6, len(costs)))]
+            for e in evs:
+                e.record(main)                 # materialises the underlying hipEvent_t
+        out = []
+        for i, c in enumerate(costs):
+            if _WGRAD_DEAL == "rr":
+                k = sd["rr"] % len(pool)
+                sd["rr"] += 1
+            else:
+                k = min(range(len(pool)), key=load.__getitem__)
+            load[k] += float(c)
+            out.append((pool[k], evs[i]))
+        sd["main"], sd["dirty"] = main, True
+        if not sd["queued"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._join_callback)
+                sd["queued"] = True
+            except RuntimeError:
+                pass
+        return out
 
     def begin_step(self):
         """Start of a forward / backward pass: forget a join callback that never ran (a backward that raised leaves
@@ -542,17 +582,7 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         gemm_nt(a_t, b_t, passes=passes, out_f32=out_f32, ksplit=pick_ksplit(M, N, Kc), K=Kc, ec=ec)
         return cs
     if ksplit is None:
-        # as many k-slices as fit ONE round of the persistent grid (256 workgroups, or the data-parallel cap: a slice count
-        # sized for 256 on a 248-workgroup grid would spill 4 work units into a second round and double the wgrad's time)
-        tiles = ((M + 255) // 256) * ((N + 255) // 256)
-        nkt = (Kd + 63) // 64
-        # ... and HALF of that when the wgrad runs on the side stream next to the dgrad chain: it no longer has to fill the
-        # chip by itself, half the workgroups leave CUs to the main stream's kernels, and the fp32 slabs (and the reduce that
-        # reads them) are half as big.  Same box: 796.6 -> 819.8 pairs/s (+2.9 %); a third: 788, a quarter: 635 -- the wgrads
-        # then become the critical path (profiles/r02_ab_wgrad_ksplit.txt).
-        # (a third with two wgrad streams: two of them then share the free CUs)
-        div = _WGRAD_KSPLIT_DIV or ((3 if ec._side["extra"] else 2) if ec.on_side_stream() else 1)
-        ksplit = max(1, min(ec.gemm_grid // max(tiles, 1) // div, nkt // 2))
+        ksplit = wgrad_ksplit(M, N, Kd, ec, ec.on_side_stream())
     cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
     partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
     d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, Kd, passes, 1.0, ACT_NONE, None,
@@ -566,6 +596,20 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt(trans)")
     return cs
+
+
+def wgrad_ksplit(M, N, Kd, ec, on_side):
+    """k-slices of a TN weight-gradient GEMM (output M x N, contraction over Kd token rows): as many as fit ONE round of the
+    persistent grid (256 workgroups, or the data-parallel cap: a slice count sized for 256 on a 248-workgroup grid would spill 4
+    work units into a second round and double the wgrad's time) ... and HALF of that when the wgrad runs on the side stream next
+    to the dgrad chain: it no longer has to fill the chip by itself, half the workgroups leave CUs to the main stream's kernels,
+    and the fp32 slabs (and the reduce that reads them) are half as big.  Same box: 796.6 -> 819.8 pairs/s (+2.9 %); a third:
+    788, a quarter: 635 -- the wgrads then become the critical path (profiles/r02_ab_wgrad_ksplit.txt).  (A third with two wgrad
+    streams: two of them then share the free CUs.)"""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    nkt = (Kd + 63) // 64
+    div = _WGRAD_KSPLIT_DIV or ((3 if ec._side["extra"] else 2) if on_side else 1)
+    return max(1, min(ec.gemm_grid // max(tiles, 1) // div, nkt // 2))
 
 
 def pick_ksplit(M, N, K):

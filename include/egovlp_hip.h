@@ -118,6 +118,48 @@ int egv_layernorm_fwd_f16f6(const float* x, int64_t ldx, const float* gamma, con
                             int32_t cols, uint16_t* y16, uint16_t* yslots, egv_bf16* ybf, int64_t ldy, float* mean, float* rstd,
                             void* stream);
 
+/* ---- one call per SpaceTimeBlock ----------------------------------------------------------------------------------
+ * SpaceTimeBlock.forward (model/video_transformer.py:163-177: t = timeattn(norm3(x)); tr = x + t; s = attn(norm1(tr)); sr = x + s;
+ * out = sr + mlp(norm2(sr))) and its backward, enqueued from C: the same kernels with the same arguments in the same order as the
+ * per-kernel entry points above (LayerNorm -> qkv GEMM -> divided attention -> proj GEMM, twice, then fc1 / GELU / fc2), with every
+ * intermediate in ONE caller-provided arena per direction -- what costs the host ~50 tensor allocations and ~30 calls per block
+ * otherwise.  Token-major [M = B (1 + T n), D] fp32 residual stream; D = 64 H.
+ * fwd_passes / bwd_passes: 3 = split-bf16 three-product, 1 = single-pass bf16 (bwd_passes <= fwd_passes); train != 0 keeps what
+ * the backward needs (z_bf16 != 0: fc1 saves gelu'(z) as bf16 -- single-pass backward -- instead of the fp32 pre-activation).
+ * The forward arena must stay untouched until egv_block_bwd has run on it.                                                     */
+typedef struct egv_block_geom {
+  int32_t B, T, n, H, D, Hd;
+  int32_t fwd_passes, bwd_passes, train, z_bf16;
+  float eps;
+  int32_t grid_cap;     /* as egv_gemm_desc.grid_cap */
+} egv_block_geom;
+typedef struct egv_block_params {                 /* weight index: 0 timeattn.qkv, 1 timeattn.proj, 2 attn.qkv, 3 attn.proj, 4 fc1, 5 fc2 */
+  const float *n3w, *n3b, *n1w, *n1b, *n2w, *n2b; /* LayerNorm affine (norm3 = temporal, norm1 = spatial, norm2 = MLP)              */
+  const float* bias[6];
+  const egv_bf16 *w_hi[6], *w_lo[6]; int64_t ldw[6];     /* W[N,K] planes (forward)                                              */
+  const egv_bf16 *wt_hi[6], *wt_lo[6]; int64_t ldwt[6];  /* W^T[K,N] planes (dgrad; may be NULL for egv_block_fwd)               */
+} egv_block_params;
+int64_t egv_block_fwd_arena_bytes(const egv_block_geom* g);
+/* byte offsets into the forward arena of: n3_hi, timeattn-out hi, n1_hi, attn-out hi, n2_hi, h_hi, qkv_t hi, qkv_s hi, tr, sr, z   */
+int egv_block_fwd_offsets(const egv_block_geom* g, int64_t* off11);
+int egv_block_fwd(const egv_block_geom* g, const egv_block_params* p, const float* x, float* out, void* arena, void* stream);
+/* Backward.  g_out: dL/d out fp32 [M, D]; g_hi / g_lo: the same as planes if the caller has them (else NULL: split here).
+ * Outputs: d_x fp32 [M, D] and its planes dx_hi[, dx_lo]; `grads`: ONE fp32 buffer holding dW x 6, db x 6 and the three
+ * LayerNorms' (dgamma, dbeta) at the offsets of egv_block_grad_layout (order: weights 0..5, biases 0..5, norm3 g/b, norm1 g/b,
+ * norm2 g/b).  Weight-gradient GEMM i runs on side_stream[i] behind side_event[i] recorded on `stream` (NULL: on `stream`) with
+ * wgrad_ksplit[i] k-slices (slabs in the backward arena); the caller joins the side streams.                                     */
+typedef struct egv_block_bwd_io {
+  const float* g_out; const egv_bf16 *g_hi, *g_lo;
+  const float* x; const void* fwd_arena; void* bwd_arena;
+  float* d_x; egv_bf16 *dx_hi, *dx_lo;
+  float* grads;
+  void* side_stream[6]; void* side_event[6];
+  int32_t wgrad_ksplit[6];
+} egv_block_bwd_io;
+int64_t egv_block_bwd_arena_bytes(const egv_block_geom* g, const int32_t* wgrad_ksplit6);
+int egv_block_grad_layout(const egv_block_geom* g, int64_t* offsets18, int64_t* total_floats);
+int egv_block_bwd(const egv_block_geom* g, const egv_block_params* p, const egv_block_bwd_io* io, void* stream);
+
 /* ---- LayerNorm ----------------------------------------------------------------------------------
  * nn.LayerNorm over the last dim (video eps 1e-6: model/video_transformer.py:146,156,159,228,253;
  * DistilBERT eps 1e-12).  Optional fused pre-add: the normalised input is x + x_add (DistilBERT's

@@ -183,3 +183,45 @@ def test_narrow_classification_head_wiring():
     assert "egv_cross_entropy_fwd_bwd" in calls
     assert m.vid_proj[0].weight.grad.shape == (2, 768) and m.vid_proj[0].bias.grad.shape == (2,)
     assert m.video_model.blocks[0].mlp.fc1.weight.grad is not None and m.txt_proj[1].weight.grad is None
+
+
+def test_block_calls_replace_the_per_kernel_calls_of_the_video_blocks(model):
+    """At a geometry where every GEMM of a block is un-split (B = 8, T = 4: M = 6280 tokens) the 12 SpaceTimeBlocks run through ONE
+    C-ABI call per direction (egv_block_fwd / egv_block_bwd, csrc/block.hip): no per-kernel call of a video block is left, every
+    parameter still receives a gradient of its own shape, and a block's 18 gradients are views of ONE buffer (autograd keeps views
+    as they are: no copies)."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.model.video_transformer import block_calls_ok
+    from egovlp_amd.optim import AdamW
+    from egovlp_amd.trainer.trainer_egoclip import egoclip_step
+    opt = AdamW(model.parameters(), lr=3e-5)
+    ec = model.exec_ctx
+    assert block_calls_ok(ec, 8 * 785, 768, 3072) and not block_calls_ok(ec, 2 * 393, 768, 3072)
+    with mock_hip() as calls:
+        ec.set_precision("bf16x3", "bf16")
+        try:
+            for p in model.parameters():
+                p.grad = None
+            egoclip_step(model, EgoNCE(), opt, _batch(B=8, T=4), 1, 0)
+            calls.clear()
+            for p in model.parameters():
+                p.grad = None
+            egoclip_step(model, EgoNCE(), opt, _batch(B=8, T=4), 1, 0)
+            c = collections.Counter(calls)
+            blk = model.video_model.blocks[3]
+            ptrs = sorted(p.grad.data_ptr() for p in blk.parameters())
+            span = ptrs[-1] - ptrs[0]
+            shapes_ok = all(p.grad is not None and p.grad.shape == p.shape for p in model.parameters())
+            ec.set(block_calls=False)
+            calls.clear()
+            for p in model.parameters():
+                p.grad = None
+            egoclip_step(model, EgoNCE(), opt, _batch(B=8, T=4), 1, 0)
+            ref = collections.Counter(calls)
+        finally:
+            ec.unset("fwd_passes", "bwd_passes", "block_calls")
+    assert c["egv_block_fwd"] == 12 and c["egv_block_bwd"] == 12 and ref["egv_block_fwd"] == 0
+    assert c["egv_divided_attn_fwd"] == 0 and c["egv_divided_attn_bwd"] == 0 and ref["egv_divided_attn_fwd"] == 24
+    assert ref["egv_gemm_nt"] - c["egv_gemm_nt"] == 12 * 18 and ref["egv_layernorm_fwd"] - c["egv_layernorm_fwd"] == 36
+    assert shapes_ok
+    assert span < 4 * (sum(p.numel() for p in blk.parameters()) + 64 * 18)        # one buffer per block, not 18 allocations
