@@ -376,11 +376,21 @@ def main():
             one_step()
         barrier()
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(steps):
             loss = one_step()
-        HOST["enqueue_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3     # when the host was done enqueueing
+            marks.append(time.perf_counter())
+        HOST["enqueue_ms_per_step"] = (marks[-1] - t0) / steps * 1e3     # when the host was done enqueueing
         barrier()
         dt = time.perf_counter() - t0
+        # the figure above contains back-pressure: once the host is a few steps ahead, the HIP runtime makes it wait for room in its
+        # queues (the lead stops growing at ~3-5 steps), so over many steps it tends to the GPU's step time whatever the host costs.
+        # What the host costs while nothing pushes back: the cheapest three consecutive steps of the loop; how far ahead of the GPU
+        # the host was when it had enqueued the last step: the lead.
+        per = [(b_ - a_) * 1e3 for a_, b_ in zip(marks, marks[1:])]
+        w = min(3, len(per))
+        HOST["enqueue_ms_unthrottled"] = min(sum(per[i:i + w]) / w for i in range(len(per) - w + 1))
+        HOST["lead_ms"] = (dt - (marks[-1] - t0)) * 1e3
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -484,6 +494,8 @@ def main():
         "loss": round(loss_val, 5),
         "host_enqueue_ms_per_step": round(HOST.get("enqueue_ms_per_step", 0.0), 3),
         "host_enqueue_ms_from_idle_streams": round(HOST.get("enqueue_idle_ms", 0.0), 3),
+        "host_enqueue_ms_per_step_unthrottled": round(HOST.get("enqueue_ms_unthrottled", 0.0), 3),
+        "host_lead_ms_at_last_enqueue": round(HOST.get("lead_ms", 0.0), 1),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
     }
     if roof is not None:

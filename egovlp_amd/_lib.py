@@ -68,6 +68,23 @@ class BlockBwdIO(C.Structure):
                 ("wgrad_ksplit", i32 * 6)]
 
 
+class TextGeom(C.Structure):
+    """egv_text_geom."""
+    _fields_ = [("B", i32), ("L", i32), ("H", i32), ("D", i32), ("Hd", i32),
+                ("fwd_passes", i32), ("bwd_passes", i32), ("train", i32),
+                ("eps", f32), ("attn_p", f32), ("ffn_p", f32), ("grid_cap", i32),
+                ("attn_seed", C.c_uint64), ("ffn_seed", C.c_uint64), ("seed_dev", c_p),
+                ("nt_ksplit_fwd", i32 * 4), ("nt_ksplit_bwd", i32 * 4), ("wgrad_ksplit", i32 * 4)]
+
+
+class TextParams(C.Structure):
+    """egv_text_params."""
+    _fields_ = [("ln1w", c_p), ("ln1b", c_p), ("ln2w", c_p), ("ln2b", c_p),
+                ("bias", c_p * 4),
+                ("w_hi", c_p * 4), ("w_lo", c_p * 4), ("ldw", i64 * 4),
+                ("wt_hi", c_p * 4), ("wt_lo", c_p * 4), ("ldwt", i64 * 4)]
+
+
 # name -> (restype, argtypes); mirrors include/egovlp_hip.h one to one (tests/test_abi.py checks it)
 PROTOTYPES = {
     "egv_gemm_nt": (i32, [C.POINTER(GemmDesc), c_p]),
@@ -115,6 +132,11 @@ PROTOTYPES = {
     "egv_block_bwd_arena_bytes": (i64, [C.POINTER(BlockGeom), c_p]),
     "egv_block_grad_layout": (i32, [C.POINTER(BlockGeom), c_p, c_p]),
     "egv_block_bwd": (i32, [C.POINTER(BlockGeom), C.POINTER(BlockParams), C.POINTER(BlockBwdIO), c_p]),
+    "egv_text_layer_fwd_arena_bytes": (i64, [C.POINTER(TextGeom)]),
+    "egv_text_layer_fwd": (i32, [C.POINTER(TextGeom), C.POINTER(TextParams), c_p, c_p, c_p, c_p, c_p]),
+    "egv_text_layer_bwd_arena_bytes": (i64, [C.POINTER(TextGeom)]),
+    "egv_text_layer_grad_layout": (i32, [C.POINTER(TextGeom), c_p, c_p]),
+    "egv_text_layer_bwd": (i32, [C.POINTER(TextGeom), C.POINTER(TextParams), c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_diag_mfma_peak": (i32, [i32, i32, c_p, c_p]),
     "egv_diag_traffic_calib": (i32, [i32, c_p, c_p, i64, c_p]),
 }

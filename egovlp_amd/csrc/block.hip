@@ -284,6 +284,9 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   fpl(F.n3_hi, F.n3_lo, n3_hi, n3_lo); fpl(F.at_hi, F.at_lo, at_hi, at_lo); fpl(F.n1_hi, F.n1_lo, n1_hi, n1_lo);
   fpl(F.as_hi, F.as_lo, as_hi, as_lo); fpl(F.n2_hi, F.n2_lo, n2_hi, n2_lo); fpl(F.h_hi, F.h_lo, h_hi, h_lo);
   fpl(F.qkvt_hi, F.qkvt_lo, qt_hi, qt_lo); fpl(F.qkvs_hi, F.qkvs_lo, qs_hi, qs_lo);
+  // the attention backward takes the forward output's lo plane whenever the forward wrote one, also in a single-pass backward
+  // (delta = rowsum(dO o O) exact in O: egv_divided_attn_bwd)
+  const egv_bf16 *as_lo_f = at<egv_bf16>(FA, F.as_lo), *at_lo_f = at<egv_bf16>(FA, F.at_lo);
   const float *tr = at<float>(FA, F.tr), *sr = at<float>(FA, F.sr);
   float* grads = io.grads;
 
@@ -348,7 +351,7 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   egv_bf16 *dqs_hi = at<egv_bf16>(A, L.dqkvs_hi), *dqs_lo = at<egv_bf16>(A, L.dqkvs_lo);
-  EGV_TRY(egv_divided_attn_bwd(qs_hi, qs_lo, as_hi, as_lo, das_hi, das_lo, at<float>(FA, F.lse_s), g.B, g.T, g.n, g.H, 0, Pb, dqs_hi, dqs_lo,
+  EGV_TRY(egv_divided_attn_bwd(qs_hi, qs_lo, as_hi, as_lo_f, das_hi, das_lo, at<float>(FA, F.lse_s), g.B, g.T, g.n, g.H, 0, Pb, dqs_hi, dqs_lo,
                                at<float>(A, L.attn_work), stream));
   EGV_TRY(wgrad(2, dqs_hi, dqs_lo, 3 * D, n1_hi, n1_lo, D));
   float* d_n1 = at<float>(A, L.d_n1);
@@ -370,7 +373,7 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   egv_bf16 *dqt_hi = at<egv_bf16>(A, L.dqkvt_hi), *dqt_lo = at<egv_bf16>(A, L.dqkvt_lo);
-  EGV_TRY(egv_divided_attn_bwd(qt_hi, qt_lo, at_hi, at_lo, dat_hi, dat_lo, at<float>(FA, F.lse_t), g.B, g.T, g.n, g.H, 1, Pb, dqt_hi, dqt_lo,
+  EGV_TRY(egv_divided_attn_bwd(qt_hi, qt_lo, at_hi, at_lo_f, dat_hi, dat_lo, at<float>(FA, F.lse_t), g.B, g.T, g.n, g.H, 1, Pb, dqt_hi, dqt_lo,
                                at<float>(A, L.attn_work), stream));
   EGV_TRY(wgrad(0, dqt_hi, dqt_lo, 3 * D, n3_hi, n3_lo, D));
   float* d_n3 = at<float>(A, L.d_n3);

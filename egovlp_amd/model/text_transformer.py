@@ -157,6 +157,135 @@ class _TextLayerFn(torch.autograd.Function):
                 d_f1w, d_f1b, d_f2w, d_f2b, d_ln2w, d_ln2b)
 
 
+# ---------------------------------------------------------------------------------------------- one C call per layer
+_TEXT_CACHE = {}       # geometry key -> (forward arena bytes, backward arena bytes, gradient offsets, gradient floats)
+_TEXT_PARAMS = {}      # device addresses of a layer's parameters and weight planes -> the egv_text_params built from them
+
+
+def text_calls_ok(ec: ExecContext, M, D, Hd, H):
+    """May this layer run through the C layer calls?  (split-bf16 / bf16 precision, no per-kernel timer, widths the TN kernel takes
+    without an explicit transpose, and the weight gradients on the layer's own stream: the text tower on its side stream -- the
+    default -- or no wgrad side streams at all; everything else keeps the per-kernel path)"""
+    if not ec.block_calls or ec.kernel_timer is not None or ec.fwd_passes_split not in (1, 3) or ec.bwd_passes > ec.fwd_passes_split:
+        return False
+    if D < 256 or Hd < 256 or D % 64 or Hd % 64 or D != H * 64:
+        return False
+    return ec.on_text_stream() or not ec.wgrad_side_stream
+
+
+def _text_geom(B, L, H, D, Hd, P, Pb, train, eps, drop, ec):
+    from .._lib import TextGeom
+    import ctypes as C
+    M = B * L
+    I4 = C.c_int32 * 4
+    ksf = I4(*[ops.auto_ksplit_nt(M, n_, k_) for n_, k_ in ((3 * D, D), (D, D), (Hd, D), (D, Hd))])
+    ksb = I4(*[ops.auto_ksplit_nt(M, n_, k_) for n_, k_ in ((Hd, D), (D, Hd), (D, D), (D, 3 * D))])
+    ksw = I4(*[ops.wgrad_ksplit(n_, k_, M, ec, False) for n_, k_ in ((3 * D, D), (D, D), (Hd, D), (D, Hd))])
+    sdev = drop[4]
+    return TextGeom(B, L, H, D, Hd, P, Pb, int(train), float(eps), float(drop[0]), float(drop[2]), int(ec.gemm_grid),
+                    int(drop[1]) & (2 ** 64 - 1), int(drop[3]) & (2 ** 64 - 1), sdev.data_ptr() if sdev is not None else None,
+                    ksf, ksb, ksw), (tuple(ksf), tuple(ksb), tuple(ksw))
+
+
+def _text_params(wc, ln, qkv_w, qkv_b, others_w, others_b, need_t):
+    """egv_text_params: LayerNorm affine (sa_layer_norm w, b, output_layer_norm w, b), the fused q/k/v weight planes and bias (the
+    weight cache keeps the concatenation), out_lin / lin1 / lin2.  Built once per layer and direction: the planes are refreshed in
+    place, the addresses do not change from step to step."""
+    import ctypes as C
+    from .._lib import TextParams
+    pls = [wc.get_cat(qkv_w, need_t=need_t)] + [wc.get(w, need_t=need_t) for w in others_w]
+    bias = [wc.get_bias_cat(qkv_b)] + list(others_b)
+    key = (need_t,) + tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in bias) \
+        + tuple(p.hi.data_ptr() for p, _ in pls) + (tuple(t.hi.data_ptr() for _, t in pls) if need_t else ())
+    hit = _TEXT_PARAMS.get(key)
+    if hit is not None:
+        return hit
+    if len(_TEXT_PARAMS) > 4096:
+        _TEXT_PARAMS.clear()
+    P4, L4 = C.c_void_p * 4, C.c_int64 * 4
+
+    def ptr(t):
+        return t.data_ptr() if t is not None else None
+    whi, wlo, ldw = P4(*[p.hi.data_ptr() for p, _ in pls]), P4(*[ptr(p.lo) for p, _ in pls]), L4(*[p.ld for p, _ in pls])
+    if need_t:
+        thi, tlo, ldt = P4(*[t.hi.data_ptr() for _, t in pls]), P4(*[ptr(t.lo) for _, t in pls]), L4(*[t.ld for _, t in pls])
+    else:
+        thi, tlo, ldt = P4(), P4(), L4()
+    prm = _TEXT_PARAMS[key] = TextParams(*[t.data_ptr() for t in ln], P4(*[b.data_ptr() for b in bias]), whi, wlo, ldw, thi, tlo, ldt)
+    return prm
+
+
+class _TextLayerCFn(torch.autograd.Function):
+    """TransformerBlock.forward / backward as ONE C-ABI call each (see _TextLayerFn for the arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, geom, ec: ExecContext,
+                q_w, q_b, k_w, k_b, v_w, v_b, o_w, o_b, ln1_w, ln1_b, f1_w, f1_b, f2_w, f2_b, ln2_w, ln2_b):
+        import ctypes as C
+        from .. import _lib
+        B, L, H, eps, drop = geom
+        D = x.shape[-1]
+        M = B * L
+        Hd = f1_w.shape[0]
+        P, Pb = ec.fwd_passes_split, ec.bwd_passes
+        dev = x.device
+        x2 = x.contiguous().view(M, D)
+        mask = mask.contiguous()
+        train = any(ctx.needs_input_grad)
+        g, ks = _text_geom(B, L, H, D, Hd, P, Pb, train, eps, drop, ec)
+        key = (B, L, H, D, Hd, P, Pb, train, drop[2] > 0, ks)
+        ent = _TEXT_CACHE.get(key)
+        if ent is None:
+            off, tot = (C.c_int64 * 12)(), C.c_int64()
+            nf = int(_lib.lib().egv_text_layer_fwd_arena_bytes(C.byref(g)))
+            nb = int(_lib.lib().egv_text_layer_bwd_arena_bytes(C.byref(g)))
+            _lib.check(_lib.lib().egv_text_layer_grad_layout(C.byref(g), off, C.byref(tot)), "egv_text_layer_grad_layout")
+            if nf <= 0 or nb <= 0:
+                raise _lib.EgovlpHipError("egv_text_layer_fwd_arena_bytes: unsupported layer geometry")
+            ent = _TEXT_CACHE[key] = (nf, nb, tuple(int(o) for o in off), int(tot.value))
+        arena = torch.empty(ent[0], dtype=torch.uint8, device=dev)
+        out = torch.empty((M, D), dtype=torch.float32, device=dev)
+        ln = (ln1_w, ln1_b, ln2_w, ln2_b)
+        prm = _text_params(ec.wc, ln, (q_w, k_w, v_w), (q_b, k_b, v_b), (o_w, f1_w, f2_w), (o_b, f1_b, f2_b), need_t=False)
+        _lib.check(_lib.lib().egv_text_layer_fwd(C.byref(g), C.byref(prm), x2.data_ptr(), mask.data_ptr(), out.data_ptr(),
+                                                 arena.data_ptr(), ops._stream(x2)), "egv_text_layer_fwd")
+        if train:
+            ctx.g, ctx.ec, ctx.arena, ctx.sizes, ctx.P = g, ec, arena, ent, P
+            ctx.seed_dev = drop[4]           # keeps the device seed word alive (the geometry holds its address)
+            ctx.save_for_backward(mask, q_w, k_w, v_w, q_b, k_b, v_b, o_w, f1_w, f2_w, o_b, f1_b, f2_b, *ln)
+        return out.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes as C
+        from .. import _lib
+        saved = ctx.saved_tensors
+        mask, qkv_w, qkv_b, others_w, others_b, ln = saved[0], saved[1:4], saved[4:7], saved[7:10], saved[10:13], saved[13:17]
+        g, ec = ctx.g, ctx.ec
+        if ec.bwd_passes != g.bwd_passes:
+            raise RuntimeError("the backward precision changed between this layer's forward and its backward")
+        B, L, D = g.B, g.L, g.D
+        M = B * L
+        dev = mask.device
+        G = g_out.contiguous().view(M, D)
+        _, nb, goff, gtot = ctx.sizes
+        barena = torch.empty(nb, dtype=torch.uint8, device=dev)
+        grads = torch.empty(gtot, dtype=torch.float32, device=dev)
+        d_x = torch.empty((M, D), dtype=torch.float32, device=dev)
+        prm = _text_params(ec.wc, ln, qkv_w, qkv_b, others_w, others_b, need_t=True)
+        _lib.check(_lib.lib().egv_text_layer_bwd(C.byref(g), C.byref(prm), G.data_ptr(), mask.data_ptr(), ctx.arena.data_ptr(),
+                                                 barena.data_ptr(), d_x.data_ptr(), grads.data_ptr(), ops._stream(G)), "egv_text_layer_bwd")
+        ctx.arena = None
+        sizes = [goff[i + 1] - goff[i] for i in range(11)] + [gtot - goff[11]]
+        parts = grads.split_with_sizes(sizes)
+        dW3 = parts[0].view(3 * D, D)
+        db3 = parts[4]
+        dW = [parts[i].view(others_w[i - 1].shape) for i in (1, 2, 3)]
+        return (d_x.view(B, L, D), None, None, None,
+                dW3[:D], db3[:D], dW3[D:2 * D], db3[D:2 * D], dW3[2 * D:], db3[2 * D:],
+                dW[0], parts[5], parts[8], parts[9], dW[1], parts[6], dW[2], parts[7], parts[10], parts[11])
+
+
 class Embeddings(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -197,7 +326,8 @@ class TransformerBlock(nn.Module):
         a, f = self.attention, self.ffn
         drop = tuple(drop) + (None,) * (5 - len(drop))       # (attention p, seed, ffn p, seed[, device seed word])
         geom = (B, L, a.n_heads, self.sa_layer_norm.eps, drop)
-        return _TextLayerFn.apply(
+        fn = _TextLayerCFn if text_calls_ok(ec, B * L, D, f.lin1.weight.shape[0], a.n_heads) else _TextLayerFn
+        return fn.apply(
             x, mask, geom, ec,
             a.q_lin.weight, a.q_lin.bias, a.k_lin.weight, a.k_lin.bias, a.v_lin.weight, a.v_lin.bias,
             a.out_lin.weight, a.out_lin.bias, self.sa_layer_norm.weight, self.sa_layer_norm.bias,

@@ -434,18 +434,24 @@ def f16f6_encode(x2d: torch.Tensor, want_bf=False) -> Planes:
     return pl
 
 
-def f16f6_encode_multi(jobs):
-    """One launch for many weights.  jobs: (x2d [rows, cols] fp32, h16 address, slots address, ldo)."""
+def f16f6_encode_multi(jobs, prepare=False):
+    """One launch for many weights.  jobs: (x2d [rows, cols] fp32, h16 address, slots address, ldo).  prepare: as split_f32_multi."""
     n = len(jobs)
     if n == 0:
-        return
+        return None
     vp, i64, i32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     for j in jobs:
         _need_cuda(j[0])
-    check(_lib.lib().egv_f16f6_encode_multi(n, vp(*[j[0].data_ptr() for j in jobs]), i64(*[j[0].stride(0) for j in jobs]),
-                                            i32(*[j[0].shape[0] for j in jobs]), i32(*[j[0].shape[1] for j in jobs]),
-                                            vp(*[j[1] for j in jobs]), vp(*[j[2] for j in jobs]), i64(*[j[3] for j in jobs]),
-                                            _stream(jobs[0][0])), "egv_f16f6_encode_multi")
+    args = (n, vp(*[j[0].data_ptr() for j in jobs]), i64(*[j[0].stride(0) for j in jobs]),
+            i32(*[j[0].shape[0] for j in jobs]), i32(*[j[0].shape[1] for j in jobs]),
+            vp(*[j[1] for j in jobs]), vp(*[j[2] for j in jobs]), i64(*[j[3] for j in jobs]))
+    fn = _lib.lib().egv_f16f6_encode_multi
+
+    def run(stream):
+        check(fn(*args, stream), "egv_f16f6_encode_multi")
+    if prepare:
+        return run
+    run(_stream(jobs[0][0]))
 
 
 def zeros(shape, dtype=torch.float32, device="cuda"):
@@ -636,12 +642,14 @@ def split_f32(x2d: torch.Tensor, passes, *, want_rowmajor=True, want_transposed=
     return pl, tp, cs
 
 
-def split_f32_multi(jobs):
+def split_f32_multi(jobs, prepare=False):
     """One launch for many fp32 -> split-plane conversions.  jobs: (x2d [rows, cols] fp32, hi, lo, ldo, t_hi, t_lo, ldt, t_cols)
-    with hi / lo / t_hi / t_lo raw device addresses (or None); see egv_split_f32_multi."""
+    with hi / lo / t_hi / t_lo raw device addresses (or None); see egv_split_f32_multi.
+    prepare=True: build the argument tables and return `run(stream_handle)` instead of launching (None for no jobs) -- the weight
+    cache replays the same table after every optimizer step."""
     n = len(jobs)
     if n == 0:
-        return
+        return None
     vp, i64, i32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
     X = vp(*[j[0].data_ptr() for j in jobs])
     LDX = i64(*[j[0].stride(0) for j in jobs])
@@ -654,7 +662,13 @@ def split_f32_multi(jobs):
     TC = i32(*[j[7] for j in jobs])
     for j in jobs:
         _need_cuda(j[0])
-    check(_lib.lib().egv_split_f32_multi(n, X, LDX, R, Cc, HI, LO, LDO, THI, TLO, LDT, TC, _stream(jobs[0][0])), "egv_split_f32_multi")
+    fn = _lib.lib().egv_split_f32_multi
+
+    def run(stream):
+        check(fn(n, X, LDX, R, Cc, HI, LO, LDO, THI, TLO, LDT, TC, stream), "egv_split_f32_multi")
+    if prepare:
+        return run
+    run(_stream(jobs[0][0]))
 
 
 def transpose_planes(x: Planes, passes, want_colsum=False):
@@ -892,14 +906,19 @@ def egonce_fwd_bwd(text, video, noun, verb, temperature, eps=1e-8, use_noun=True
     return loss, sim, dt, dvv
 
 
-def adamw_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step, correct_bias=True, grad_scale=1.0, hyper_dev=None):
+def adamw_tables(params, ms, vs):
+    """The argument tables of egv_adamw_multi that do not change from step to step (parameter / moment addresses, sizes)."""
     n = len(params)
     arr = C.c_void_p * n
-    P = arr(*[p.data_ptr() for p in params])
-    G = arr(*[g.data_ptr() for g in grads])
-    M_ = arr(*[m.data_ptr() for m in ms])
-    V = arr(*[v.data_ptr() for v in vs])
-    N = (C.c_int64 * n)(*[p.numel() for p in params])
+    return (arr(*[p.data_ptr() for p in params]), arr(*[m.data_ptr() for m in ms]), arr(*[v.data_ptr() for v in vs]),
+            (C.c_int64 * n)(*[p.numel() for p in params]))
+
+
+def adamw_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step, correct_bias=True, grad_scale=1.0, hyper_dev=None,
+                tables=None):
+    n = len(params)
+    P, M_, V, N = tables if tables is not None else adamw_tables(params, ms, vs)
+    G = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
     check(_lib.lib().egv_adamw_multi(n, P, G, M_, V, None, None, N, float(lr), float(beta1), float(beta2),
                                      float(eps), float(weight_decay), int(step), int(correct_bias),
                                      float(grad_scale), _p(hyper_dev), _stream(params[0])), "egv_adamw_multi")

@@ -25,6 +25,7 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       correct_bias=correct_bias))
         self._graph_hyper = None
+        self._plans = {}        # id(param group) -> (params, states, exp_avg, exp_avg_sq, argument tables) of the steady-state launch
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -34,9 +35,31 @@ class AdamW(torch.optim.Optimizer):
         weights.bump_epoch()   # parameters were written through raw pointers: invalidate the bf16 planes
         return loss
 
+    def load_state_dict(self, state_dict):
+        self._plans.clear()
+        return super().load_state_dict(state_dict)
+
     def _update_group(self, group, params, grad_scale):
-        ps, gs, ms, vs = [], [], [], []
+        # steady state: the same parameters with the same moment buffers, all at the same step count -- one launch whose
+        # parameter / moment tables were built at the first such step (the gradient table is rebuilt: gradients are new tensors)
+        plan = self._plans.get(id(group))
+        if plan is not None and len(plan[0]) == len(params) and all(a is b for a, b in zip(plan[0], params)):
+            _, states, ms, vs, tables, ptrs = plan
+            step = states[0]["step"] + 1
+            ok = all(p.data_ptr() == q for p, q in zip(params, ptrs))       # `p.data = ...` / `.to()` since the plan was made
+            for st, m in zip(states, ms):
+                ok = ok and st["step"] + 1 == step and st["exp_avg"] is m
+                st["step"] += 1
+            grads = [p.grad for p in params]
+            if ok and not any(g.is_sparse or not g.is_contiguous() for g in grads):
+                self._launch(group, params, grads, ms, vs, step, grad_scale, tables)
+                return
+            for st in states:          # something changed under the plan: undo, take the general path
+                st["step"] -= 1
+            del self._plans[id(group)]
+        ps, gs, ms, vs, sts = [], [], [], [], []
         step = None
+        uniform = True
         for p in params:
             if p.grad.is_sparse:
                 raise RuntimeError("AdamW does not support sparse gradients")
@@ -52,12 +75,15 @@ class AdamW(torch.optim.Optimizer):
                 # tensors at different step counts get their own launch group
                 self._launch(group, ps, gs, ms, vs, step, grad_scale)
                 ps, gs, ms, vs, step = [], [], [], [], st["step"]
+                uniform = False
             if not (p.is_contiguous() and p.grad.is_contiguous()):
                 raise RuntimeError("AdamW (HIP) needs contiguous parameters and gradients")
-            ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+            ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); sts.append(st)
         self._launch(group, ps, gs, ms, vs, step, grad_scale)
+        if uniform and ps:
+            self._plans[id(group)] = (list(ps), sts, list(ms), list(vs), ops.adamw_tables(ps, ms, vs), [p.data_ptr() for p in ps])
 
-    def _launch(self, group, ps, gs, ms, vs, step, grad_scale):
+    def _launch(self, group, ps, gs, ms, vs, step, grad_scale, tables=None):
         if not ps:
             return
         b1, b2 = group["betas"]
@@ -65,7 +91,7 @@ class AdamW(torch.optim.Optimizer):
         # (egovlp_amd/graph.py GraphedTrainStep); None in eager mode
         hyper = self._graph_hyper.get(id(group)) if self._graph_hyper else None
         ops.adamw_multi(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
-                        group["correct_bias"], grad_scale, hyper_dev=hyper)
+                        group["correct_bias"], grad_scale, hyper_dev=hyper, tables=tables)
 
 
 def adamw_step_size(lr, beta1, beta2, step, correct_bias=True):

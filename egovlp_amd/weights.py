@@ -65,58 +65,80 @@ class WeightCache:
         self._c = {}
         self._c_bias = {}
         self._token = 0
+        self._prep = None        # (signature of the stale set, replay of the split launch, replay of the f16f6 launch, a parameter)
 
     # -- one launch for every stale entry that already owns its planes
-    def _refresh_all(self):
-        jobs, jobs6, done = [], [], []
+    def _stale(self, mark=False):
+        """[(entry, current version)] of the entries whose planes are out of date (and can be refreshed in place); `mark`: stamp the
+        up-to-date ones valid for this step while walking the cache (one version() -- a tuple of data_ptr() calls -- per entry)."""
+        stale = []
         for ent in self._c.values():
             ver = ent.version()
-            if ent.ver == ver or not ent.shapes_ok():
-                continue
-            off = 0
-            for i, p in enumerate(ent.params):
-                w2 = p.detach().reshape(p.shape[0], -1)
-                if not w2.is_contiguous():
-                    w2 = w2.contiguous()
-                n_i, last = w2.shape[0], i == len(ent.params) - 1
-                if ent.pl is not None or ent.tp is not None:
-                    hi = lo = None
-                    ldo = 0
-                    if ent.pl is not None:
-                        hi = ent.pl.hi.data_ptr() + off * ent.pl.ld * 2
-                        lo = ent.pl.lo.data_ptr() + off * ent.pl.ld * 2
-                        ldo = ent.pl.ld
-                    if ent.tp is not None:
-                        thi, tlo = ent.tp.hi.data_ptr() + off * 2, ent.tp.lo.data_ptr() + off * 2
-                        ldt, tcols = ent.tp.ld, (ent.tp.ld - off if last else n_i)
-                    else:
-                        thi = tlo = None
-                        ldt, tcols = 0, n_i
-                    jobs.append((w2, hi, lo, ldo, thi, tlo, ldt, tcols))
-                if ent.p6 is not None:
-                    jobs6.append((w2, ent.p6.hi.data_ptr() + off * ent.p6.ld * 2, ent.p6.lo.data_ptr() + off * ent.p6.ld * 2, ent.p6.ld))
-                off += n_i
-            done.append((ent, ver))
-        ops.split_f32_multi(jobs)
-        ops.f16f6_encode_multi(jobs6)
-        for ent, ver in done:
+            if ent.ver == ver:
+                if mark:
+                    ent.mark_valid(self._token)
+            elif ent.shapes_ok():
+                stale.append((ent, ver))
+        return stale
+
+    def _refresh_all(self, stale=None):
+        stale = self._stale() if stale is None else stale
+        if not stale:
+            return
+        # after an optimizer step the SAME entries are stale every time, with the same parameter and plane addresses: the argument
+        # tables of the two multi-tensor launches are built once and replayed (what changes is the stream)
+        sig = tuple((id(ent), id(ent.pl), id(ent.tp), id(ent.p6), tuple(v[2] for v in ver)) for ent, ver in stale)
+        if self._prep is None or self._prep[0] != sig:
+            jobs, jobs6 = [], []
+            for ent, _ in stale:
+                off = 0
+                for i, p in enumerate(ent.params):
+                    w2 = p.detach().reshape(p.shape[0], -1)
+                    if not w2.is_contiguous():
+                        # a non-contiguous parameter is converted through a temporary: nothing to replay
+                        w2, sig = w2.contiguous(), None
+                    n_i, last = w2.shape[0], i == len(ent.params) - 1
+                    if ent.pl is not None or ent.tp is not None:
+                        hi = lo = None
+                        ldo = 0
+                        if ent.pl is not None:
+                            hi = ent.pl.hi.data_ptr() + off * ent.pl.ld * 2
+                            lo = ent.pl.lo.data_ptr() + off * ent.pl.ld * 2
+                            ldo = ent.pl.ld
+                        if ent.tp is not None:
+                            thi, tlo = ent.tp.hi.data_ptr() + off * 2, ent.tp.lo.data_ptr() + off * 2
+                            ldt, tcols = ent.tp.ld, (ent.tp.ld - off if last else n_i)
+                        else:
+                            thi = tlo = None
+                            ldt, tcols = 0, n_i
+                        jobs.append((w2, hi, lo, ldo, thi, tlo, ldt, tcols))
+                    if ent.p6 is not None:
+                        jobs6.append((w2, ent.p6.hi.data_ptr() + off * ent.p6.ld * 2, ent.p6.lo.data_ptr() + off * ent.p6.ld * 2, ent.p6.ld))
+                    off += n_i
+            self._prep = (sig, ops.split_f32_multi(jobs, prepare=True), ops.f16f6_encode_multi(jobs6, prepare=True),
+                          stale[0][0].params[0])
+        _, run_split, run_f6, any_param = self._prep
+        st = ops._stream(any_param)
+        for run in (run_split, run_f6):
+            if run is not None:
+                run(st)
+        for ent, ver in stale:
             ent.ver = ver
 
     def refresh(self):
         """Bring every cached plane set up to date NOW, on the current stream (callers that are about to fork work onto a
         second stream do this first, so that no stream finds a stale entry and refreshes the cache under the other one)."""
-        if any(ent.ver != ent.version() and ent.shapes_ok() for ent in self._c.values()):
-            self._refresh_all()
+        self._refresh_all()
 
     def begin_step(self):
         """Start of a forward pass (ExecContext.begin_step): ONE full validation of the cache (version counters, plane epoch and
         storage addresses of ~100 weights), one multi-tensor refresh if anything is stale, and a new token -- within the step every
         `get` of a validated entry is three integer compares instead of a tuple of data_ptr() calls (15 us x 300 GEMMs)."""
-        self.refresh()
         self._token += 1
-        for ent in self._c.values():
-            if ent.ver is not None and ent.ver == ent.version():
-                ent.mark_valid(self._token)
+        stale = self._stale(mark=True)
+        self._refresh_all(stale)
+        for ent, _ in stale:
+            ent.mark_valid(self._token)
 
     def _get(self, params, need_t: bool, fmt: str = "bf16"):
         key = id(params[0]) if len(params) == 1 else tuple(id(p) for p in params)
@@ -173,3 +195,4 @@ class WeightCache:
     def clear(self):
         self._c.clear()
         self._c_bias.clear()
+        self._prep = None

@@ -160,6 +160,38 @@ int64_t egv_block_bwd_arena_bytes(const egv_block_geom* g, const int32_t* wgrad_
 int egv_block_grad_layout(const egv_block_geom* g, int64_t* offsets18, int64_t* total_floats);
 int egv_block_bwd(const egv_block_geom* g, const egv_block_params* p, const egv_block_bwd_io* io, void* stream);
 
+/* ---- one call per DistilBERT TransformerBlock -----------------------------------------------------------------
+ * HF modeling_distilbert.py TransformerBlock.forward (:227-259; built by the reference at model/model.py:31-36 and called at :122):
+ * sa = LN(out_lin(MHA(x)) + x); out = LN(lin2(gelu(lin1(sa))) + sa), and its backward, enqueued from C on ONE stream: the same
+ * kernels with the same arguments in the same order as the per-kernel entry points (egv_split_f32, egv_gemm_nt, egv_text_attn_*,
+ * egv_layernorm_*, egv_dropout).  The split-K factors of the M = B*L GEMMs come from the caller (>= 1 each): nt_ksplit_fwd for the
+ * q/k/v (fused), out_lin, lin1, lin2 products, nt_ksplit_bwd for dZ, d_sa, d_ctx, d_x in that order, wgrad_ksplit per weight.
+ * Weight index: 0 = q/k/v fused [3D, D] (rows q | k | v), 1 = out_lin, 2 = lin1, 3 = lin2.  attn_p / ffn_p: the dropout
+ * probabilities (0 outside train()) with their seeds, seed_dev as in egv_text_attn_fwd.                                          */
+typedef struct egv_text_geom {
+  int32_t B, L, H, D, Hd;
+  int32_t fwd_passes, bwd_passes, train;
+  float eps, attn_p, ffn_p;
+  int32_t grid_cap;
+  uint64_t attn_seed, ffn_seed;
+  const uint64_t* seed_dev;
+  int32_t nt_ksplit_fwd[4], nt_ksplit_bwd[4], wgrad_ksplit[4];
+} egv_text_geom;
+typedef struct egv_text_params {
+  const float *ln1w, *ln1b, *ln2w, *ln2b;          /* sa_layer_norm, output_layer_norm                                     */
+  const float* bias[4];
+  const egv_bf16 *w_hi[4], *w_lo[4]; int64_t ldw[4];     /* W[N,K] planes (forward)                                       */
+  const egv_bf16 *wt_hi[4], *wt_lo[4]; int64_t ldwt[4];  /* W^T[K,N] planes (dgrad; may be NULL for the forward call)     */
+} egv_text_params;
+int64_t egv_text_layer_fwd_arena_bytes(const egv_text_geom* g);
+int egv_text_layer_fwd(const egv_text_geom* g, const egv_text_params* p, const float* x /* [B*L, D] */, const int64_t* mask /* [B, L] */,
+                       float* out, void* arena, void* stream);
+int64_t egv_text_layer_bwd_arena_bytes(const egv_text_geom* g);
+/* offsets (floats) into `grads` of: dW x 4, db x 4, sa_layer_norm dgamma, dbeta, output_layer_norm dgamma, dbeta               */
+int egv_text_layer_grad_layout(const egv_text_geom* g, int64_t* offsets12, int64_t* total_floats);
+int egv_text_layer_bwd(const egv_text_geom* g, const egv_text_params* p, const float* g_out, const int64_t* mask, const void* fwd_arena,
+                       void* bwd_arena, float* d_x, float* grads, void* stream);
+
 /* ---- LayerNorm ----------------------------------------------------------------------------------
  * nn.LayerNorm over the last dim (video eps 1e-6: model/video_transformer.py:146,156,159,228,253;
  * DistilBERT eps 1e-12).  Optional fused pre-add: the normalised input is x + x_add (DistilBERT's

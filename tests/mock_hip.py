@@ -23,7 +23,23 @@ def _make_mock(calls):
     m._keep = []
     special = {"egv_version": 3, "egv_layernorm_bwd_parts": 8, "egv_divided_attn_fwd_work_floats": 4096,
                "egv_divided_attn_bwd_work_floats": 4096, "egv_egonce_work_floats": 1 << 16}
-    special.update({"egv_block_fwd_arena_bytes": 1 << 20, "egv_block_bwd_arena_bytes": 1 << 20})
+    special.update({"egv_block_fwd_arena_bytes": 1 << 20, "egv_block_bwd_arena_bytes": 1 << 20,
+                    "egv_text_layer_fwd_arena_bytes": 1 << 20, "egv_text_layer_bwd_arena_bytes": 1 << 20})
+
+    def text_grad_layout(geom_p, off_p, tot_p):
+        """egv_text_layer_grad_layout restated (csrc/text_layer.hip grad_layout)."""
+        g = C.cast(geom_p, C.POINTER(_lib.TextGeom)).contents
+        D, Hd = g.D, g.Hd
+        shapes = [(3 * D, D), (D, D), (Hd, D), (D, Hd)]
+        off = C.cast(off_p, C.POINTER(C.c_int64))
+        p = k = 0
+        for sizes in ([n * kk for n, kk in shapes], [n for n, _ in shapes], [D] * 4):
+            for nel in sizes:
+                off[k] = p
+                p += nel
+                k += 1
+        C.cast(tot_p, C.POINTER(C.c_int64))[0] = p
+        return 0
 
     def grad_layout(geom_p, off_p, tot_p):
         """egv_block_grad_layout restated (csrc/block.hip grad_layout): the host code slices its gradient views by these offsets."""
@@ -48,6 +64,8 @@ def _make_mock(calls):
             calls.append(_name)
             if _name == "egv_block_grad_layout":
                 return grad_layout(*a)
+            if _name == "egv_text_layer_grad_layout":
+                return text_grad_layout(*a)
             return _ret
 
         proto = C.CFUNCTYPE(res, *args)

@@ -2,9 +2,9 @@
 per-kernel host path (_SpaceTimeBlockFn: one C-ABI call per kernel) on the SAME block, input and upstream gradient.
 
 Both paths launch the same kernels with the same arguments in the same order on the main stream, so everything that is a pure
-function of its inputs must come out BIT FOR BIT: the block output, the input gradient, every weight and bias gradient (TN GEMM,
-un-split).  The LayerNorm affine gradients are sums of fp32 atomics (order varies from run to run of the SAME path): those are
-compared at 1e-5 of their norm.  The reference has no counterpart (model/video_transformer.py:140-178 is one nn.Module forward);
+function of its inputs must come out BIT FOR BIT: the block output and the gradients upstream of the first atomics (fc2, fc1).
+The CLS rows of the attention backward and the LayerNorm affine gradients are sums of fp32 atomics (order varies from run to run of
+the SAME path): everything downstream of them is compared at 1e-4 of its norm (run-to-run noise <= 3e-5).  The reference has no counterpart (model/video_transformer.py:140-178 is one nn.Module forward);
 what is pinned against the reference is the whole model (tests/test_gpu_model.py), which runs through this path by default."""
 import pytest
 import torch
@@ -44,7 +44,7 @@ def _run(blk, ec, x, g, B, T, n, block_calls, side):
 
 @pytest.mark.parametrize("mode", [("bf16x3", "bf16x3"), ("bf16x3", "bf16"), ("bf16", "bf16")])
 @pytest.mark.parametrize("side", [False, True])
-@pytest.mark.parametrize("geom", [(4, 4, 196), (2, 16, 196)])
+@pytest.mark.parametrize("geom", [(8, 4, 196), (2, 16, 196)])
 def test_block_calls_equal_the_per_kernel_path(mode, side, geom):
     from egovlp_amd import ops
     B, T, n = geom
@@ -60,21 +60,25 @@ def test_block_calls_equal_the_per_kernel_path(mode, side, geom):
     y_k, dx_k, gr_k, used_k = _run(blk, ec, x, g, B, T, n, False, side)
     assert used_c == {"c": 1, "k": 0} and used_k == {"c": 0, "k": 1}, (used_c, used_k, M)
     assert torch.equal(y_c, y_k)
-    assert torch.equal(dx_c, dx_k)
-    for k in gr_k:
-        a, b = gr_c[k], gr_k[k]
-        assert a.shape == b.shape and a.is_contiguous()
-        if "norm" in k:          # sums of fp32 atomics
-            assert float((a.double() - b.double()).norm() / b.double().norm()) < 1e-5, k
-        else:
-            assert torch.equal(a, b), k
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    diffs = {"dx": rel(dx_c, dx_k), **{k: rel(gr_c[k], gr_k[k]) for k in gr_k}}
+    exact = {k: v == 0.0 for k, v in diffs.items()}
+    print("block calls vs per-kernel path, relative differences:", {k: "%.1e" % v for k, v in diffs.items() if v})
+    assert all(gr_c[k].shape == gr_k[k].shape and gr_c[k].is_contiguous() for k in gr_k)
+    # the attention backward of the CLS rows and the LayerNorm affine gradients accumulate with fp32 atomics: the same path
+    # differs from itself from run to run by up to ~6e-7 (fp32 planes) / ~3e-5 (single-pass: a bf16 rounding flips), measured with
+    # tools/block_diag.py; a wrong operand shows up at >= 5e-4 (a missing lo plane of the attention output did)
+    assert all(v < 1e-4 for v in diffs.values()), diffs
+    assert exact["mlp.fc2.weight"] and exact["mlp.fc2.bias"] and exact["mlp.fc1.weight"], exact     # upstream of any atomics
 
 
 def test_block_calls_are_the_default_and_leave_no_copies():
     """The whole video tower steps through the block calls by default; the parameter gradients it hands to autograd are views of one
     buffer per block (stolen by AccumulateGrad, no copy): their storages coincide."""
     from egovlp_amd import ops
-    B, T, n, D = 4, 4, 196, 768
+    B, T, n, D = 8, 4, 196, 768
     blk = _block(D)
     ec = ops.new_context()
     ec.set_precision("bf16x3", "bf16")
@@ -87,3 +91,59 @@ def test_block_calls_are_the_default_and_leave_no_copies():
     torch.cuda.synchronize()
     ptrs = {p.grad.untyped_storage().data_ptr() for p in blk.parameters()}
     assert len(ptrs) == 1, len(ptrs)
+
+
+# ------------------------------------------------------------------------------------------------ DistilBERT layer calls
+def _text_layer(seed=0):
+    from egovlp_amd.model.text_transformer import DistilBertConfig, TransformerBlock
+    torch.manual_seed(seed)
+    blk = TransformerBlock(DistilBertConfig())
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn_like(p) * (0.02 if p.dim() > 1 else 0.1))
+    return blk.cuda().train()
+
+
+def _run_text(blk, ec, x, mask, g, block_calls, drop):
+    from egovlp_amd.model import text_transformer as tt
+    ec.set(block_calls=block_calls, wgrad_side_stream=False)
+    for p in blk.parameters():
+        p.grad = None
+    xin = x.clone().requires_grad_(True)
+    ec.begin_step()
+    y = blk(xin, mask, ec, drop)
+    used_c = isinstance(y.grad_fn, tt._TextLayerCFn._backward_cls)
+    y.backward(g)
+    torch.cuda.synchronize()
+    return y.detach().clone(), xin.grad.detach().clone(), {k: p.grad.detach().clone() for k, p in blk.named_parameters()}, used_c
+
+
+@pytest.mark.parametrize("mode", [("bf16x3", "bf16x3"), ("bf16x3", "bf16"), ("bf16", "bf16")])
+@pytest.mark.parametrize("drop", [(0.0, 0, 0.0, 0), (0.1, 1234567, 0.1, 7654321)])
+def test_text_layer_calls_equal_the_per_kernel_path(mode, drop):
+    """egv_text_layer_fwd / _bwd (csrc/text_layer.hip) against _TextLayerFn on the same TransformerBlock: M = B*L = 1024 token rows
+    (the split-K shapes of the benchmark), ragged attention mask, with and without HF's dropouts (the masks are functions of
+    (p, seed, element index): both paths regenerate the same ones)."""
+    from egovlp_amd import ops
+    B, L, D = 32, 32, 768
+    blk = _text_layer()
+    ec = ops.new_context()
+    ec.set_precision(*mode)
+    torch.manual_seed(9)
+    x = torch.randn(B, L, D, device="cuda")
+    g = torch.randn(B, L, D, device="cuda") * 0.1
+    lens = torch.randint(3, L + 1, (B,))
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long().cuda()
+    y_c, dx_c, gr_c, used_c = _run_text(blk, ec, x, mask, g, True, drop)
+    y_k, dx_k, gr_k, used_k = _run_text(blk, ec, x, mask, g, False, drop)
+    assert used_c and not used_k
+    assert torch.equal(y_c, y_k)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    diffs = {"dx": rel(dx_c, dx_k), **{k: rel(gr_c[k], gr_k[k]) for k in gr_k}}
+    print("text layer calls vs per-kernel path, relative differences:", {k: "%.1e" % v for k, v in diffs.items() if v})
+    assert all(gr_c[k].shape == gr_k[k].shape for k in gr_k)
+    # LayerNorm affine gradients: fp32 atomics (run-to-run noise ~1e-7); everything else is a pure function of its inputs
+    assert all(v < 1e-5 for v in diffs.values()), diffs
+    assert all(v == 0.0 for k, v in diffs.items() if "layer_norm" not in k), diffs

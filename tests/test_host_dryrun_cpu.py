@@ -34,19 +34,21 @@ def model():
 
 def test_full_step_wiring_and_launch_census(model):
     """zero_grad -> forward -> EgoNCE -> backward -> AdamW through the real host code: every parameter receives a gradient of
-    its own shape, and the census of C-ABI calls per step is what DESIGN.md states (12 blocks x 4 forward GEMMs, ...)."""
+    its own shape, and the census of C-ABI calls per step of the PER-KERNEL path (block_calls off: the path the block / layer calls
+    are checked against) is what DESIGN.md states (12 blocks x 4 forward GEMMs, ...)."""
     from egovlp_amd.model.loss import EgoNCE
     from egovlp_amd.optim import AdamW
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
     opt = AdamW(model.parameters(), lr=3e-5)
     with mock_hip() as calls:
         model.exec_ctx.set_precision("bf16x3", "bf16")
+        model.exec_ctx.set(block_calls=False)
         egoclip_step(model, EgoNCE(), opt, _batch(), 1, 0)          # first step: builds the weight-plane cache
         calls.clear()
         for p in model.parameters():
             p.grad = None
         loss = egoclip_step(model, EgoNCE(), opt, _batch(), 1, 0)
-        model.exec_ctx.unset("fwd_passes", "bwd_passes")
+        model.exec_ctx.unset("fwd_passes", "bwd_passes", "block_calls")
     assert loss.shape == ()
     c = collections.Counter(calls)
     assert c["egv_divided_attn_fwd"] == 24 and c["egv_divided_attn_bwd"] == 24
@@ -221,7 +223,10 @@ def test_block_calls_replace_the_per_kernel_calls_of_the_video_blocks(model):
         finally:
             ec.unset("fwd_passes", "bwd_passes", "block_calls")
     assert c["egv_block_fwd"] == 12 and c["egv_block_bwd"] == 12 and ref["egv_block_fwd"] == 0
+    # the six DistilBERT layers likewise (csrc/text_layer.hip): no text-attention call of their own is left
+    assert c["egv_text_layer_fwd"] == 6 and c["egv_text_layer_bwd"] == 6 and ref["egv_text_layer_fwd"] == 0
+    assert c["egv_text_attn_fwd"] == 0 and c["egv_text_attn_bwd"] == 0 and ref["egv_text_attn_fwd"] == 6 and ref["egv_text_attn_bwd"] == 6
     assert c["egv_divided_attn_fwd"] == 0 and c["egv_divided_attn_bwd"] == 0 and ref["egv_divided_attn_fwd"] == 24
-    assert ref["egv_gemm_nt"] - c["egv_gemm_nt"] == 12 * 18 and ref["egv_layernorm_fwd"] - c["egv_layernorm_fwd"] == 36
+    assert ref["egv_gemm_nt"] - c["egv_gemm_nt"] == 12 * 18 + 6 * 12 and ref["egv_layernorm_fwd"] - c["egv_layernorm_fwd"] == 36 + 12
     assert shapes_ok
     assert span < 4 * (sum(p.numel() for p in blk.parameters()) + 64 * 18)        # one buffer per block, not 18 allocations

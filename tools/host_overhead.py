@@ -11,6 +11,9 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 ops.Precision.set("bf16x3", "bf16") if prec == "mixed" else ops.Precision.set(prec)
 model = bench.build_model("base_patch16_224", 16).cuda().train()
 opt = AdamW(model.parameters(), lr=3e-5)
+# the streams of the default bench.py run: text tower and weight gradients on side streams, main stream high priority
+model.exec_ctx.set(wgrad_side_stream=os.environ.get("EGV_HOST_SIDE", "1") == "1", text_side_stream=os.environ.get("EGV_HOST_SIDE", "1") == "1")
+torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
 b = synth_batch(32, T=4, L=32, seed=1234)
 data = {"video": b["video"].cuda(), "text": {k: v.cuda() for k, v in b["text"].items()}, "noun_vec": b["noun_vec"].cuda(), "verb_vec": b["verb_vec"].cuda()}
 for _ in range(3):
@@ -31,3 +34,17 @@ for _ in range(3):
     t0 = time.perf_counter(); egoclip_step(model, EgoNCE(), opt, data); ts.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
 print("enqueue time of a single step from an idle stream: %.2f ms" % (1e3 * min(ts)))
+
+# where the host time of one step goes (cProfile of three steps enqueued onto idle streams)
+if os.environ.get("EGV_HOST_PROFILE", "1") == "1":
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    for _ in range(3):
+        torch.cuda.synchronize()
+        pr.enable(); egoclip_step(model, EgoNCE(), opt, data); pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    print("---- by internal time (3 steps)")
+    st.sort_stats("tottime").print_stats(30)
+    print("---- by cumulative time (3 steps)")
+    st.sort_stats("cumtime").print_stats(40)
