@@ -711,11 +711,17 @@ int launch_time_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const
 
 }  // namespace
 
+int egv_attn_time_mfma_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
+                                float* ws, hipStream_t s);
+int egv_attn_time_mfma_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
+                                const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s);
+
+// T <= 4: the register-resident vector-ALU kernels above (HBM-bound); 4 < T <= 16: one wave per (location, head) on the matrix
+// cores (attn_time_mfma.hip)
 int egv_attn_time_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol,
                            float* lse, float* ws, hipStream_t s) {
   if (T <= 4) return launch_time_fwd<4>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
-  if (T <= 8) return launch_time_fwd<8>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
-  if (T <= 16) return launch_time_fwd<16>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
+  if (T <= 16) return egv_attn_time_mfma_fwd_impl(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
   return EGV_ERR_ARG;
 }
 
@@ -723,8 +729,7 @@ int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh
                            const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls,
                            hipStream_t s) {
   if (T <= 4) return launch_time_bwd<4>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
-  if (T <= 8) return launch_time_bwd<8>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
-  if (T <= 16) return launch_time_bwd<16>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
+  if (T <= 16) return egv_attn_time_mfma_bwd_impl(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
   return EGV_ERR_ARG;
 }
 
