@@ -159,7 +159,6 @@ class _TextLayerFn(torch.autograd.Function):
 
 # ---------------------------------------------------------------------------------------------- one C call per layer
 _TEXT_CACHE = {}       # geometry key -> (forward arena bytes, backward arena bytes, gradient offsets, gradient floats)
-_TEXT_PARAMS = {}      # device addresses of a layer's parameters and weight planes -> the egv_text_params built from them
 
 
 def text_calls_ok(ec: ExecContext, M, D, Hd, H):
@@ -189,19 +188,17 @@ def _text_geom(B, L, H, D, Hd, P, Pb, train, eps, drop, ec):
 
 def _text_params(wc, ln, qkv_w, qkv_b, others_w, others_b, need_t):
     """egv_text_params: LayerNorm affine (sa_layer_norm w, b, output_layer_norm w, b), the fused q/k/v weight planes and bias (the
-    weight cache keeps the concatenation), out_lin / lin1 / lin2.  Built once per layer and direction: the planes are refreshed in
-    place, the addresses do not change from step to step."""
+    weight cache keeps the concatenation), out_lin / lin1 / lin2.  Built once per layer and direction and kept on the model's weight
+    cache (see video_transformer._block_params)."""
     import ctypes as C
     from .._lib import TextParams
     pls = [wc.get_cat(qkv_w, need_t=need_t)] + [wc.get(w, need_t=need_t) for w in others_w]
     bias = [wc.get_bias_cat(qkv_b)] + list(others_b)
-    key = (need_t,) + tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in bias) \
-        + tuple(p.hi.data_ptr() for p, _ in pls) + (tuple(t.hi.data_ptr() for _, t in pls) if need_t else ())
-    hit = _TEXT_PARAMS.get(key)
-    if hit is not None:
-        return hit
-    if len(_TEXT_PARAMS) > 4096:
-        _TEXT_PARAMS.clear()
+    small = tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in bias)
+    key = (id(qkv_w[0]), need_t)
+    hit = wc.param_structs.get(key)
+    if hit is not None and hit[1] == small and all(a[0] is b[0] and a[1] is b[1] for a, b in zip(hit[0], pls)):
+        return hit[2]
     P4, L4 = C.c_void_p * 4, C.c_int64 * 4
 
     def ptr(t):
@@ -211,7 +208,8 @@ def _text_params(wc, ln, qkv_w, qkv_b, others_w, others_b, need_t):
         thi, tlo, ldt = P4(*[t.hi.data_ptr() for _, t in pls]), P4(*[ptr(t.lo) for _, t in pls]), L4(*[t.ld for _, t in pls])
     else:
         thi, tlo, ldt = P4(), P4(), L4()
-    prm = _TEXT_PARAMS[key] = TextParams(*[t.data_ptr() for t in ln], P4(*[b.data_ptr() for b in bias]), whi, wlo, ldw, thi, tlo, ldt)
+    prm = TextParams(*[t.data_ptr() for t in ln], P4(*[b.data_ptr() for b in bias]), whi, wlo, ldw, thi, tlo, ldt)
+    wc.param_structs[key] = (pls, small, prm)
     return prm
 
 

@@ -233,30 +233,27 @@ def _block_geom(B, T, n, H, D, Hd, P, Pb, train, z_bf16, eps, grid):
     return BlockGeom(B, T, n, H, D, Hd, P, Pb, int(train), int(z_bf16), float(eps), int(grid))
 
 
-_BLOCK_PARAMS = {}     # device addresses of a block's parameters and weight planes -> the egv_block_params built from them
-
-
 def _block_params(wc, ln, biases, weights, need_t):
     """egv_block_params from the parameter tensors: LayerNorm affine (n3w, n3b, n1w, n1b, n2w, n2b), the six biases and the
     cached operand planes of the six weights (W^T planes too when `need_t`).  The planes are refreshed IN PLACE after an optimizer
-    step, so the addresses -- and with them the struct -- stay the same from step to step: it is built once per block and direction."""
+    step, so the struct stays the same from step to step: it is kept on the model's weight cache, keyed by the block's first weight
+    and the direction, and reused while the cache still holds the very same plane objects and the small parameters have not moved."""
     import ctypes as C
     from .._lib import BlockParams
     P6, L6 = C.c_void_p * 6, C.c_int64 * 6
     pls = [wc.get(w, need_t=need_t) for w in weights]
-    key = (need_t,) + tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in biases) \
-        + tuple(p.hi.data_ptr() for p, _ in pls) + (tuple(t.hi.data_ptr() for _, t in pls) if need_t else ())
-    hit = _BLOCK_PARAMS.get(key)
-    if hit is not None:
-        return hit
-    if len(_BLOCK_PARAMS) > 4096:
-        _BLOCK_PARAMS.clear()
+    small = tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in biases)
+    key = (id(weights[0]), need_t)
+    hit = wc.param_structs.get(key)
+    if hit is not None and hit[1] == small and all(a[0] is b[0] and a[1] is b[1] for a, b in zip(hit[0], pls)):
+        return hit[2]
     whi, wlo, ldw = P6(*[p.hi.data_ptr() for p, _ in pls]), P6(*[p.lo.data_ptr() for p, _ in pls]), L6(*[p.ld for p, _ in pls])
     if need_t:
         thi, tlo, ldt = P6(*[t.hi.data_ptr() for _, t in pls]), P6(*[t.lo.data_ptr() for _, t in pls]), L6(*[t.ld for _, t in pls])
     else:
         thi, tlo, ldt = P6(), P6(), L6()
-    prm = _BLOCK_PARAMS[key] = BlockParams(*[t.data_ptr() for t in ln], P6(*[b.data_ptr() for b in biases]), whi, wlo, ldw, thi, tlo, ldt)
+    prm = BlockParams(*[t.data_ptr() for t in ln], P6(*[b.data_ptr() for b in biases]), whi, wlo, ldw, thi, tlo, ldt)
+    wc.param_structs[key] = (pls, small, prm)
     return prm
 
 

@@ -65,6 +65,7 @@ class WeightCache:
         self._c = {}
         self._c_bias = {}
         self._token = 0
+        self.param_structs = {}  # (id of a layer's first weight, direction) -> (plane objects, small-parameter addresses, C struct): the block / layer calls
         self._prep = None        # (signature of the stale set, replay of the split launch, replay of the f16f6 launch, a parameter)
 
     # -- one launch for every stale entry that already owns its planes
@@ -87,7 +88,9 @@ class WeightCache:
             return
         # after an optimizer step the SAME entries are stale every time, with the same parameter and plane addresses: the argument
         # tables of the two multi-tensor launches are built once and replayed (what changes is the stream)
-        sig = tuple((id(ent), id(ent.pl), id(ent.tp), id(ent.p6), tuple(v[2] for v in ver)) for ent, ver in stale)
+        def at(pl):
+            return 0 if pl is None else (pl.hi.data_ptr(), pl.lo.data_ptr() if pl.lo is not None else 0)
+        sig = tuple((at(ent.pl), at(ent.tp), at(ent.p6), tuple(v[2] for v in ver)) for ent, ver in stale)   # every address in the tables
         if self._prep is None or self._prep[0] != sig:
             jobs, jobs6 = [], []
             for ent, _ in stale:
@@ -195,4 +198,5 @@ class WeightCache:
     def clear(self):
         self._c.clear()
         self._c_bias.clear()
+        self.param_structs.clear()
         self._prep = None

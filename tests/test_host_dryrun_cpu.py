@@ -230,3 +230,27 @@ def test_block_calls_replace_the_per_kernel_calls_of_the_video_blocks(model):
     assert ref["egv_gemm_nt"] - c["egv_gemm_nt"] == 12 * 18 + 6 * 12 and ref["egv_layernorm_fwd"] - c["egv_layernorm_fwd"] == 36 + 12
     assert shapes_ok
     assert span < 4 * (sum(p.numel() for p in blk.parameters()) + 64 * 18)        # one buffer per block, not 18 allocations
+
+
+def test_block_parameter_structs_follow_the_weight_planes(model):
+    """The C structs of the block / layer calls hold raw plane addresses and are reused from step to step; they live on the model's
+    own weight cache and are rebuilt the moment the cache holds different plane objects (a struct keyed by addresses alone once
+    survived its model: the next model's tensors landed on the same addresses with the lo planes elsewhere -> NaN scores)."""
+    from egovlp_amd.model.video_transformer import _block_params
+    from egovlp_amd.ops import Planes
+    ec = model.exec_ctx
+    blk = model.video_model.blocks[0]
+    ln = (blk.norm3.weight, blk.norm3.bias, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias)
+    ws = (blk.timeattn.qkv.weight, blk.timeattn.proj.weight, blk.attn.qkv.weight, blk.attn.proj.weight, blk.mlp.fc1.weight, blk.mlp.fc2.weight)
+    bs = (blk.timeattn.qkv.bias, blk.timeattn.proj.bias, blk.attn.qkv.bias, blk.attn.proj.bias, blk.mlp.fc1.bias, blk.mlp.fc2.bias)
+    with mock_hip():
+        a = _block_params(ec.wc, ln, bs, ws, need_t=False)
+        assert _block_params(ec.wc, ln, bs, ws, need_t=False) is a                  # same planes: same struct
+        ent = ec.wc._c[id(ws[4])]
+        old = ent.pl
+        ent.pl = Planes(old.hi.clone(), old.lo.clone(), old.rows, old.cols)
+        b = _block_params(ec.wc, ln, bs, ws, need_t=False)
+        assert b is not a and b.w_hi[4] == ent.pl.hi.data_ptr() and b.w_lo[4] == ent.pl.lo.data_ptr()
+        assert all(b.w_hi[i] == a.w_hi[i] for i in (0, 1, 2, 3, 5))
+    other = _model()
+    assert other.exec_ctx.wc.param_structs is not ec.wc.param_structs and not other.exec_ctx.wc.param_structs
