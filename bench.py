@@ -490,8 +490,13 @@ def main():
                                # GEMM grid under a process group, two wgrad streams and 256 workgroups without
                                "wgrad_streams": (ops._wgrad_stream_count() if args.wgrad_side else 0), "gemm_grid": grid,
                                "main_stream_high_priority": bool(args.main_priority),
+                               "max_steps_in_flight": int(ec.max_steps_in_flight),
                                "step_replayed_from_hip_graph": bool(args.graph and world == 1 and not use_dist)}},
         "loss": round(loss_val, 5),
+        # caching-allocator state after the timed loop: reserved HBM and how often an allocation had to free cached blocks and retry
+        # (each retry synchronises the device: a host that runs many steps ahead holds that many steps' workspaces)
+        "hbm_reserved_gb": round(torch.cuda.memory_reserved() / 2 ** 30, 1),
+        "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
         "host_enqueue_ms_per_step": round(HOST.get("enqueue_ms_per_step", 0.0), 3),
         "host_enqueue_ms_from_idle_streams": round(HOST.get("enqueue_idle_ms", 0.0), 3),
         "host_enqueue_ms_per_step_unthrottled": round(HOST.get("enqueue_ms_unthrottled", 0.0), 3),

@@ -59,6 +59,12 @@ _HARD_DEFAULTS = {
     # one C-ABI call per SpaceTimeBlock forward / backward (egv_block_fwd / egv_block_bwd, one workspace arena per direction)
     # instead of the per-kernel calls: the same launches, ~10x less host work.  Off: the per-kernel reference path.
     "block_calls": os.environ.get("EGV_BLOCK_CALLS", "1") == "1",
+    # how many steps the host may have enqueued beyond the one the GPU is executing.  Workspaces that side streams touch go back to
+    # the caching allocator only when the GPU has passed them, so the memory a training loop holds grows with the host's lead: at
+    # B = 16, T = 16 (66 GB of such workspaces per step) a lead of four steps reserved 273 of the 288 GB and one slower box went into
+    # allocator retries (a device synchronisation each).  Two steps of lead keep the GPU fed (the host needs ~10 ms per step) and
+    # bound the memory.  0: no limit.
+    "max_steps_in_flight": int(os.environ.get("EGV_MAX_STEPS_IN_FLIGHT", "2")),
 }
 
 
@@ -71,6 +77,7 @@ class ExecContext:
         self._s = dict(settings)
         self._side = {"stream": None, "main": None, "dirty": False, "queued": False, "extra": [], "rr": 0}
         self._text = {"stream": None, "main": None}     # "main": the stream forward() forked the text tower from
+        self._inflight = []                             # events of the steps the host has enqueued (see _throttle)
         self._wc = None
 
     # ---- settings (inherited) ------------------------------------------------------------------------------------------
@@ -120,6 +127,7 @@ class ExecContext:
     backward_poll = property(lambda self: self.get("backward_poll"))
     kernel_timer = property(lambda self: self.get("kernel_timer"))
     block_calls = property(lambda self: self.get("block_calls"))
+    max_steps_in_flight = property(lambda self: self.get("max_steps_in_flight"))
 
     def poll_backward(self):
         fn = self.get("backward_poll")
@@ -203,8 +211,22 @@ class ExecContext:
         'queued' set and later passes would not queue theirs), and validate / refresh the weight-plane cache once for the step."""
         self._side["queued"] = False
         self._side["load"] = None
+        self._throttle()
         if self._wc is not None:
             self._wc.begin_step()
+
+    def _throttle(self):
+        """Flow control of the training loop (setting max_steps_in_flight): an event per begin_step on the current stream -- the side
+        streams of the previous step were joined into it -- and a host wait for the event of `limit` steps ago."""
+        limit = self.get("max_steps_in_flight")
+        if limit <= 0 or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+            return
+        q = self._inflight
+        ev = torch.cuda.Event()
+        ev.record()
+        q.append(ev)
+        while len(q) > limit:
+            q.pop(0).synchronize()
 
     def join_side_stream(self):
         """Make the main stream (the one the side work was forked from) and the current stream wait for everything enqueued on

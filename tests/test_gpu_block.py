@@ -147,3 +147,18 @@ def test_text_layer_calls_equal_the_per_kernel_path(mode, drop):
     # LayerNorm affine gradients: fp32 atomics (run-to-run noise ~1e-7); everything else is a pure function of its inputs
     assert all(v < 1e-5 for v in diffs.values()), diffs
     assert all(v == 0.0 for k, v in diffs.items() if "layer_norm" not in k), diffs
+
+
+def test_host_lead_is_bounded():
+    """ExecContext.begin_step keeps at most `max_steps_in_flight` step events: the host waits for the step before those (flow control
+    that bounds the workspaces held for side streams; 0 switches it off)."""
+    from egovlp_amd import ops
+    ec = ops.new_context()
+    assert ec.max_steps_in_flight == 2
+    for _ in range(5):
+        ec.begin_step()
+        torch.empty(1 << 20, device="cuda").normal_()
+    assert len(ec._inflight) == 2
+    ec.set(max_steps_in_flight=0)
+    ec.begin_step()
+    assert len(ec._inflight) == 2          # untouched
