@@ -31,4 +31,15 @@ timeout 300 python tools/attn_time.py 2>&1 | grep -v amdgpu > $O/attention_isola
 timeout 300 python tools/host_overhead.py mixed 2>&1 | grep -v amdgpu > $O/host_overhead.txt
 timeout 600 python bench.py --frames 16 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg > $O/bench_config4_T16_B16.json 2>> $O/bench_default.err
 timeout 600 python bench.py --arch large_patch14_224 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg > $O/bench_config5_vitl14_B16.json 2>> $O/bench_default.err
+# kernel statistics of BASELINE configs 4 (T = 16, B = 16) and 5 (ViT-L/14, B = 16)
+for C in "config4 --frames 16 --batch 16" "config5 --arch large_patch14_224 --batch 16"; do
+  set -- $C; name=$1; shift
+  rm -rf /tmp/prof_$name
+  ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg --wgrad-side 0 --text-side 0 "$@" ) > $O/prof_$name.log 2>&1
+  f=$(find /tmp/prof_$name -name "*kernel_trace.csv" | head -1)
+  [ -n "$f" ] && python tools/trace_stats.py $f 3 $O/${name}_kernel_stats_timed_mixed.csv >> $O/prof_$name.log 2>&1
+done
+# the data-parallel code path (process group, RCCL streams, gradient exchange, 248-workgroup grid) at world size 1
+( timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg --force-dist 2>&1 | grep "^{" ) > $O/bench_force_dist_w1.json
+timeout 300 python tools/block_diag.py 2>&1 | grep -v amdgpu | cut -c1-400 > $O/block_calls_run_to_run.txt
 tail -4 $O/pytest_gpu.txt; cat $O/smoke.log; cut -c1-300 $O/bench_default.json; cut -c1-200 $O/bench_graph_replay.json; tail -3 $O/bench_gpus2_on_1gpu_box.txt; cat $O/pmc_traffic.log; head -3 $O/kernel_stats_timed_mixed.csv; head -6 $O/stream_timeline.txt
