@@ -3,7 +3,7 @@
 //
 // Rounds 1 - 3 ran this on the vector ALU (q / k / v of a location in registers, every dot product reduced with DPP steps): HBM-bound
 // at T = 4 (5 keys), instruction-bound at T = 16 -- 16 x 17 dot products + as many axpys per head cost ~25 000 VALU issues per wave
-// (396 us forward / 926 us backward per block at B = 16, config 4) where the qkv planes stream in ~25 us.  Here ONE wave owns one
+// (396 us forward / 926 us backward per block at B = 16, config 4, where the 616 MB of planes need ~80 us).  Here ONE wave owns one
 // (b, h) and LOCS = 16 / TP consecutive locations (TP = T rounded up to 4, 8 or 16: one location at T = 16, four at T = 4 -- the rows
 // of a tile are (location, frame) pairs and probabilities across locations are masked to 0) and every product is an MFMA 16x16x32
 // on 16-row tiles:
@@ -22,9 +22,9 @@
 //     computed twice with the operands swapped (8 more MFMAs) instead of being transposed through LDS.
 // Everything is wave-private (no barrier) except the reduction of the CLS token's gradient partials over a workgroup's units.
 // Masks: rows / columns whose frame >= T or location >= n, pairs from different locations and the pad rows of the CLS tiles are
-// forced to probability 0.  What bounds it: the global loads (diagnostic builds, profiles/r04m_*: at T = 16 the 16 rows of a tile
-// lie 0.9 MB apart and the loads alone take 82 of the forward's 144 us -- 1.4 TB/s; at T = 4 a tile is four 18-KB runs and the same
-// code moves 4 TB/s), then the 8-byte plane stores.
+// forced to probability 0.  What bounds it: HBM -- at T = 16, B = 16 the three-pass forward reads 462 MB and writes 154 MB in 141 us
+// (4.4 TB/s = 0.55 of peak; the loads alone, diagnostic build: 82 us = 5.6 TB/s), the single-pass backward moves 539 MB in 138 us;
+// fetching the tiles cooperatively per workgroup (adjacent tokens per instruction) changed nothing (profiles/r04q_*).
 #include "attn_common.h"
 #include "egovlp_hip.h"
 
