@@ -4,8 +4,8 @@ export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $O
 ( timeout 2400 python -m pytest tests -m gpu -q -s 2>&1 | grep -v "amdgpu\|^$" | tail -300 ) > $O/pytest_gpu.txt 2>&1
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $O/smoke.log 2>&1
-timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 600 python bench.py --graph 1 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg > $O/bench_graph_replay.json 2>> $O/bench_default.err
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+timeout 600 python bench.py --steps 20 --warmup 5 --graph 1 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg > $O/bench_graph_replay.json 2>> $O/bench_default.err
 timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 > $O/bench_gpus2_on_1gpu_box.txt 2>&1; echo "exit code $?" >> $O/bench_gpus2_on_1gpu_box.txt
 for PREC in mixed bf16; do
   rm -rf /tmp/prof_$PREC
@@ -29,8 +29,8 @@ timeout 300 python tools/gemm_bench.py 3 1 2>&1 | grep -v amdgpu > $O/gemm_bench
 timeout 300 python tools/hipblaslt_probe.py 2>&1 | grep -v amdgpu > $O/vendor_gemm_probe.txt
 timeout 300 python tools/attn_time.py 2>&1 | grep -v amdgpu > $O/attention_isolated.txt
 timeout 300 python tools/host_overhead.py mixed 2>&1 | grep -v amdgpu > $O/host_overhead.txt
-timeout 600 python bench.py --frames 16 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg > $O/bench_config4_T16_B16.json 2>> $O/bench_default.err
-timeout 600 python bench.py --arch large_patch14_224 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg > $O/bench_config5_vitl14_B16.json 2>> $O/bench_default.err
+timeout 600 python bench.py --steps 20 --warmup 5 --frames 16 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg > $O/bench_config4_T16_B16.json 2>> $O/bench_default.err
+timeout 600 python bench.py --steps 20 --warmup 5 --arch large_patch14_224 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg > $O/bench_config5_vitl14_B16.json 2>> $O/bench_default.err
 # kernel statistics of BASELINE configs 4 (T = 16, B = 16) and 5 (ViT-L/14, B = 16)
 for C in "config4 --frames 16 --batch 16" "config5 --arch large_patch14_224 --batch 16"; do
   set -- $C; name=$1; shift
