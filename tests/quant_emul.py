@@ -9,6 +9,7 @@ fp32 emulation of what the MFMA path would compute from ROUNDED operands:
   bf16x3    : A_hi B_hi + A_hi B_lo + A_lo B_hi           (three bf16 products; lo = bf16(x - hi))
   fp16      : fp16(A) fp16(B)
   fp16+F    : as bf16+F with hi = fp16(x) (11 significant bits; saturating) and the residual taken against it
+  fp16~F[:S]: fp16(A) fp16(B) + F(A 2^-S) F(B_lo 2^S) + F(A_lo 2^S) F(B 2^-S)   with F a PLAIN fp8 format (e5m2 / e4m3), fixed scales
   bf16+F    : A_hi B_hi + q_F(A) q_F(B_lo) + q_F(A_lo) q_F(B)   with F an MX element format (e4m3 / e5m2 / e2m3 / e3m2 / e2m1):
               q_F = OCP-MX block quantisation, one E8M0 scale per 32 consecutive k-elements -- the operand form of gfx950's
               `v_mfma_scale_f32_16x16x128_f8f6f4`; B_lo = B - B_hi is taken in fp32 BEFORE quantising.
@@ -93,6 +94,15 @@ class Scheme:
         al, bl = a - ah, b - bh
         if n == "bf16x3":
             return mm(ah, bh) + (mm(ah, bf16_hi(bl)) + mm(bf16_hi(al), bh))
+        if n.startswith("fp16~"):                # fp16 main product + two PLAIN (unscaled) fp8 correction products with fixed
+            # power-of-two scales: c = F(x 2^-S), l = F((x - fp16(x)) 2^S), so that c(A) l(B) + l(A) c(B) needs no rescaling and
+            # accumulates straight into the main product's accumulator ("fp16~e5m2", "fp16~e5m2:6": S = 6 by default)
+            fmt, _, sh = n[5:].partition(":")
+            S = float(2 ** int(sh or 6))
+            ah, bh = a.to(torch.float16).float(), b.to(torch.float16).float()
+            ca, cb = minifloat(a / S, fmt), minifloat(b / S, fmt)
+            la, lb = minifloat((a - ah) * S, fmt), minifloat((b - bh) * S, fmt)
+            return mm(ah, bh) + (mm(ca, lb) + mm(la, cb))
         if n.startswith("fp16+"):                # fp16 main product, MX corrections of the fp16 residual
             ah, bh = a.to(torch.float16).float(), b.to(torch.float16).float()
             al, bl = a - ah, b - bh
