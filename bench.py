@@ -377,16 +377,19 @@ def main():
         barrier()
         t0 = time.perf_counter()
         marks = [t0]
+        w0 = ec.flow_wait_s
         for _ in range(steps):
             loss = one_step()
             marks.append(time.perf_counter())
-        HOST["enqueue_ms_per_step"] = (marks[-1] - t0) / steps * 1e3     # when the host was done enqueueing
+        waited = ec.flow_wait_s - w0            # inside ExecContext._throttle: the host waiting for the step of two steps ago
+        HOST["enqueue_ms_per_step"] = (marks[-1] - t0 - waited) / steps * 1e3     # host time per step, flow-control waits excluded
+        HOST["flow_wait_ms_per_step"] = waited / steps * 1e3
         barrier()
         dt = time.perf_counter() - t0
-        # the figure above contains back-pressure: once the host is a few steps ahead, the HIP runtime makes it wait for room in its
-        # queues (the lead stops growing at ~3-5 steps), so over many steps it tends to the GPU's step time whatever the host costs.
-        # What the host costs while nothing pushes back: the cheapest three consecutive steps of the loop; how far ahead of the GPU
-        # the host was when it had enqueued the last step: the lead.
+        # flow control (max_steps_in_flight, default 2) stops the host before the HIP runtime's own back-pressure would (which sets in
+        # 3 - 5 steps ahead and cannot be told apart from work): the waits are explicit and timed, what remains is the host's work.
+        # Cross-checks: the cheapest three consecutive steps of the loop (wall clock, waits included when they happen) and how far
+        # ahead of the GPU the host was when it had enqueued the last step.
         per = [(b_ - a_) * 1e3 for a_, b_ in zip(marks, marks[1:])]
         w = min(3, len(per))
         HOST["enqueue_ms_unthrottled"] = min(sum(per[i:i + w]) / w for i in range(len(per) - w + 1))
@@ -499,6 +502,7 @@ def main():
         "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),
         "host_enqueue_ms_per_step": round(HOST.get("enqueue_ms_per_step", 0.0), 3),
         "host_enqueue_ms_from_idle_streams": round(HOST.get("enqueue_idle_ms", 0.0), 3),
+        "host_flow_control_wait_ms_per_step": round(HOST.get("flow_wait_ms_per_step", 0.0), 3),
         "host_enqueue_ms_per_step_unthrottled": round(HOST.get("enqueue_ms_unthrottled", 0.0), 3),
         "host_lead_ms_at_last_enqueue": round(HOST.get("lead_ms", 0.0), 1),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 import sys
 from dataclasses import dataclass
 from typing import Optional
@@ -78,6 +79,7 @@ class ExecContext:
         self._side = {"stream": None, "main": None, "dirty": False, "queued": False, "extra": [], "rr": 0}
         self._text = {"stream": None, "main": None}     # "main": the stream forward() forked the text tower from
         self._inflight = []                             # events of the steps the host has enqueued (see _throttle)
+        self.flow_wait_s = 0.0                          # seconds the host has waited in _throttle so far
         self._wc = None
 
     # ---- settings (inherited) ------------------------------------------------------------------------------------------
@@ -226,7 +228,9 @@ class ExecContext:
         ev.record()
         q.append(ev)
         while len(q) > limit:
+            t0 = time.perf_counter()
             q.pop(0).synchronize()
+            self.flow_wait_s += time.perf_counter() - t0       # host time spent waiting here (bench.py reports it)
 
     def join_side_stream(self):
         """Make the main stream (the one the side work was forked from) and the current stream wait for everything enqueued on
