@@ -123,9 +123,9 @@ PROTOTYPES = {
     "egv_relu_split": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p]),
     "egv_version": (i32, []),
     "egv_split_f32_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "egv_f16f6_encode": (i32, [c_p, i64, i32, i32, c_p, c_p, c_p, i64, c_p]),
-    "egv_f16f6_encode_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "egv_layernorm_fwd_f16f6": (i32, [c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
+    "egv_f16x2_encode": (i32, [c_p, i64, i32, i32, c_p, c_p, c_p, i64, i32, c_p]),
+    "egv_f16x2_encode_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p]),
+    "egv_layernorm_fwd_f16x2": (i32, [c_p, i64, c_p, c_p, f32, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, c_p]),
     "egv_block_fwd_arena_bytes": (i64, [C.POINTER(BlockGeom)]),
     "egv_block_fwd_offsets": (i32, [C.POINTER(BlockGeom), c_p]),
     "egv_block_fwd": (i32, [C.POINTER(BlockGeom), C.POINTER(BlockParams), c_p, c_p, c_p, c_p]),

@@ -28,6 +28,7 @@ struct FwdLayout {
   int64_t n3_hi, n3_lo, mean3, rstd3, qkvt_hi, qkvt_lo, at_hi, at_lo, lse_t, work_t;
   int64_t tr, n1_hi, n1_lo, mean1, rstd1, qkvs_hi, qkvs_lo, as_hi, as_lo, lse_s, work_s;
   int64_t sr, n2_hi, n2_lo, mean2, rstd2, h_hi, h_lo, z;
+  int64_t n3_bf, n1_bf, n2_bf, h_bf;     // f16x2 forward (P == 2) of a training step: bf16 copies for the single-pass backward
   int64_t total;
 };
 
@@ -49,17 +50,20 @@ Geo geo_of(const egv_block_geom& g) {
 
 bool geom_ok(const egv_block_geom& g) {
   if (g.B <= 0 || g.T <= 0 || g.n <= 0 || g.H <= 0 || g.D != g.H * 64 || g.Hd <= 0 || g.D % 32 || g.Hd % 32) return false;
-  if ((g.fwd_passes != 1 && g.fwd_passes != 3) || (g.bwd_passes != 1 && g.bwd_passes != 3) || g.bwd_passes > g.fwd_passes) return false;
+  if (g.fwd_passes < 1 || g.fwd_passes > 3 || (g.bwd_passes != 1 && g.bwd_passes != 3) || g.bwd_passes > g.fwd_passes) return false;
+  if (g.fwd_passes == 2 && (g.bwd_passes != 1 || (g.train && !g.z_bf16))) return false;   // f16x2 forward: single-pass bf16 backward
   return true;
 }
 
 FwdLayout fwd_layout(const egv_block_geom& g) {
   const Geo o = geo_of(g);
-  const bool lo = o.P == 3;
+  const bool lo = o.P != 1;              // split-bf16 (P == 3) and f16x2 (P == 2) operands are two planes
+  const bool bf = o.P == 2 && g.train;
   FwdLayout L;
   Bump b;
   auto plane = [&](int64_t cols) { return b.take(o.M * cols * 2); };
   auto plane_lo = [&](int64_t cols) { return lo ? b.take(o.M * cols * 2) : (int64_t)-1; };
+  auto plane_bf = [&](int64_t cols) { return bf ? b.take(o.M * cols * 2) : (int64_t)-1; };
   L.n3_hi = plane(o.D); L.n3_lo = plane_lo(o.D);
   L.mean3 = b.take(o.M * 4); L.rstd3 = b.take(o.M * 4);
   L.qkvt_hi = plane(3 * o.D); L.qkvt_lo = plane_lo(3 * o.D);
@@ -78,6 +82,7 @@ FwdLayout fwd_layout(const egv_block_geom& g) {
   L.mean2 = b.take(o.M * 4); L.rstd2 = b.take(o.M * 4);
   L.h_hi = plane(o.Hd); L.h_lo = plane_lo(o.Hd);
   L.z = g.train ? b.take(o.M * o.Hd * (g.z_bf16 ? 2 : 4)) : (int64_t)-1;
+  L.n3_bf = plane_bf(o.D); L.n1_bf = plane_bf(o.D); L.n2_bf = plane_bf(o.D); L.h_bf = plane_bf(o.Hd);
   L.total = b.off;
   return L;
 }
@@ -195,10 +200,17 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   const Geo o = geo_of(g);
   const FwdLayout L = fwd_layout(g);
   const int P = o.P;
+  const int Pa = P == 2 ? 3 : P;         // attention and the proj Linears: split-bf16 three-product operands in the f16x2 mode
   const int32_t M = (int32_t)o.M, D = (int32_t)o.D, Hd = (int32_t)o.Hd;
   for (int i = 0; i < 6; ++i)
-    if (!p.w_hi[i] || (P == 3 && !p.w_lo[i])) return EGV_ERR_ARG;
+    if (!p.w_hi[i] || (P != 1 && !p.w_lo[i])) return EGV_ERR_ARG;
   char* A = (char*)arena;
+  // LayerNorm -> operand planes of the qkv / fc1 Linears: split-bf16, or f16x2 (first-operand role, + the bf16 copy the backward reads)
+  auto ln = [&](const float* in, const float* gw, const float* gb, egv_bf16* y_hi, egv_bf16* y_lo, int64_t bf_off, float* mean, float* rstd) -> int {
+    if (P == 2)
+      return egv_layernorm_fwd_f16x2(in, D, gw, gb, g.eps, M, D, (uint16_t*)y_hi, (uint16_t*)y_lo, at<egv_bf16>(A, bf_off), D, mean, rstd, stream);
+    return egv_layernorm_fwd(in, nullptr, D, gw, gb, g.eps, M, D, nullptr, y_hi, y_lo, nullptr, D, mean, rstd, stream);
+  };
   egv_bf16 *n3_hi = at<egv_bf16>(A, L.n3_hi), *n3_lo = at<egv_bf16>(A, L.n3_lo);
   egv_bf16 *qt_hi = at<egv_bf16>(A, L.qkvt_hi), *qt_lo = at<egv_bf16>(A, L.qkvt_lo);
   egv_bf16 *at_hi = at<egv_bf16>(A, L.at_hi), *at_lo = at<egv_bf16>(A, L.at_lo);
@@ -210,39 +222,37 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   float *tr = at<float>(A, L.tr), *sr = at<float>(A, L.sr);
 
   // ---- temporal attention branch (:166-167)
-  EGV_TRY(egv_layernorm_fwd(x, nullptr, D, p.n3w, p.n3b, g.eps, M, D, nullptr, n3_hi, n3_lo, nullptr, D, at<float>(A, L.mean3),
-                            at<float>(A, L.rstd3), stream));
+  EGV_TRY(ln(x, p.n3w, p.n3b, n3_hi, n3_lo, L.n3_bf, at<float>(A, L.mean3), at<float>(A, L.rstd3)));
   {
     egv_gemm_desc d = nt_desc(n3_hi, n3_lo, D, p.w_hi[0], p.w_lo[0], p.ldw[0], M, 3 * D, D, P, g.grid_cap);
     d.bias = p.bias[0]; d.out_hi = qt_hi; d.out_lo = qt_lo; d.ldoh = 3 * D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
-  EGV_TRY(egv_divided_attn_fwd(qt_hi, qt_lo, g.B, g.T, g.n, g.H, 1, P, at_hi, at_lo, at<float>(A, L.lse_t), at<float>(A, L.work_t), stream));
+  EGV_TRY(egv_divided_attn_fwd(qt_hi, qt_lo, g.B, g.T, g.n, g.H, 1, Pa, at_hi, at_lo, at<float>(A, L.lse_t), at<float>(A, L.work_t), stream));
   {
-    egv_gemm_desc d = nt_desc(at_hi, at_lo, D, p.w_hi[1], p.w_lo[1], p.ldw[1], M, D, D, P, g.grid_cap);
+    egv_gemm_desc d = nt_desc(at_hi, at_lo, D, p.w_hi[1], p.w_lo[1], p.ldw[1], M, D, D, Pa, g.grid_cap);
     d.bias = p.bias[1]; d.residual = x; d.ldr = D; d.out_f32 = tr; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   // ---- spatial attention branch (:168-171; the residual is the block INPUT x, :171)
-  EGV_TRY(egv_layernorm_fwd(tr, nullptr, D, p.n1w, p.n1b, g.eps, M, D, nullptr, n1_hi, n1_lo, nullptr, D, at<float>(A, L.mean1),
-                            at<float>(A, L.rstd1), stream));
+  EGV_TRY(ln(tr, p.n1w, p.n1b, n1_hi, n1_lo, L.n1_bf, at<float>(A, L.mean1), at<float>(A, L.rstd1)));
   {
     egv_gemm_desc d = nt_desc(n1_hi, n1_lo, D, p.w_hi[2], p.w_lo[2], p.ldw[2], M, 3 * D, D, P, g.grid_cap);
     d.bias = p.bias[2]; d.out_hi = qs_hi; d.out_lo = qs_lo; d.ldoh = 3 * D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
-  EGV_TRY(egv_divided_attn_fwd(qs_hi, qs_lo, g.B, g.T, g.n, g.H, 0, P, as_hi, as_lo, at<float>(A, L.lse_s), at<float>(A, L.work_s), stream));
+  EGV_TRY(egv_divided_attn_fwd(qs_hi, qs_lo, g.B, g.T, g.n, g.H, 0, Pa, as_hi, as_lo, at<float>(A, L.lse_s), at<float>(A, L.work_s), stream));
   {
-    egv_gemm_desc d = nt_desc(as_hi, as_lo, D, p.w_hi[3], p.w_lo[3], p.ldw[3], M, D, D, P, g.grid_cap);
+    egv_gemm_desc d = nt_desc(as_hi, as_lo, D, p.w_hi[3], p.w_lo[3], p.ldw[3], M, D, D, Pa, g.grid_cap);
     d.bias = p.bias[3]; d.residual = x; d.ldr = D; d.out_f32 = sr; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   // ---- MLP (:175, :46-52): exact-erf GELU in the fc1 epilogue
-  EGV_TRY(egv_layernorm_fwd(sr, nullptr, D, p.n2w, p.n2b, g.eps, M, D, nullptr, n2_hi, n2_lo, nullptr, D, at<float>(A, L.mean2),
-                            at<float>(A, L.rstd2), stream));
+  EGV_TRY(ln(sr, p.n2w, p.n2b, n2_hi, n2_lo, L.n2_bf, at<float>(A, L.mean2), at<float>(A, L.rstd2)));
   {
     egv_gemm_desc d = nt_desc(n2_hi, n2_lo, D, p.w_hi[4], p.w_lo[4], p.ldw[4], M, Hd, D, P, g.grid_cap);
     d.bias = p.bias[4]; d.act = EGV_ACT_GELU; d.out_hi = h_hi; d.out_lo = h_lo; d.ldoh = Hd;
+    if (P == 2) { d.out_fmt = 1; d.out_bf = at<egv_bf16>(A, L.h_bf); }     // h in the f16x2 format (+ bf16 copy when training)
     if (g.train) {
       d.aux_out = at<float>(A, L.z); d.ldaux = Hd;
       d.aux_bf16 = g.z_bf16 ? 2 : 0;      // bf16: gelu'(z) itself (the backward is single-pass), else the fp32 pre-activation
@@ -280,9 +290,10 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
     ph = at<egv_bf16>(FA, hi);
     pl = Pb == 3 ? at<egv_bf16>(FA, lo) : nullptr;
   };
+  const bool x2 = o.P == 2;              // f16x2 forward: the activations' single-pass operands are their bf16 copies
   const egv_bf16 *n3_hi, *n3_lo, *at_hi, *at_lo, *n1_hi, *n1_lo, *as_hi, *as_lo, *n2_hi, *n2_lo, *h_hi, *h_lo, *qt_hi, *qt_lo, *qs_hi, *qs_lo;
-  fpl(F.n3_hi, F.n3_lo, n3_hi, n3_lo); fpl(F.at_hi, F.at_lo, at_hi, at_lo); fpl(F.n1_hi, F.n1_lo, n1_hi, n1_lo);
-  fpl(F.as_hi, F.as_lo, as_hi, as_lo); fpl(F.n2_hi, F.n2_lo, n2_hi, n2_lo); fpl(F.h_hi, F.h_lo, h_hi, h_lo);
+  fpl(x2 ? F.n3_bf : F.n3_hi, F.n3_lo, n3_hi, n3_lo); fpl(F.at_hi, F.at_lo, at_hi, at_lo); fpl(x2 ? F.n1_bf : F.n1_hi, F.n1_lo, n1_hi, n1_lo);
+  fpl(F.as_hi, F.as_lo, as_hi, as_lo); fpl(x2 ? F.n2_bf : F.n2_hi, F.n2_lo, n2_hi, n2_lo); fpl(x2 ? F.h_bf : F.h_hi, F.h_lo, h_hi, h_lo);
   fpl(F.qkvt_hi, F.qkvt_lo, qt_hi, qt_lo); fpl(F.qkvs_hi, F.qkvs_lo, qs_hi, qs_lo);
   // the attention backward takes the forward output's lo plane whenever the forward wrote one, also in a single-pass backward
   // (delta = rowsum(dO o O) exact in O: egv_divided_attn_bwd)

@@ -1,0 +1,60 @@
+// The f16x2 operand format: a product A B^T in fp32-grade accuracy from TWO fp16 MFMA products instead of three bf16 ones.
+//
+//   A (activations, first operand):   a1 = fp16((1 - e) a)      a2 = fp16(a - a1)            e = 2^-6
+//   B (weights, second operand):      b1 = fp16(b)              b2 = fp16(b1 + (b - b1) / e)
+//   a b  ~=  a1 b1 + a2 b2
+//
+// a2 = e a - rho (rho = the rounding error of a1), so a2 b2 = (e a - rho)(b1 + (b - b1) / e) = e a b1 + a (b - b1) - rho b1 - ...: the
+// second product hands back the e a b1 that a1 left out, carries the residual of b, and cancels a1's rounding error; what is NOT
+// compensated -- the roundings of a2 and b2 and the cross term rho (b - b1) / e -- is attenuated by e or by 2^-12 / e: ~2^-17 relative
+// per product, the class of the split-bf16 three-product scheme (measured on random operands: 5.3e-6 against 4.4e-6; embeddings of
+// the EgoClip model vs the fp32 oracle 3.2e-5 against 2.7e-5, tests/quant_emul.py scheme "fp16x2").  Both products accumulate into the
+// same fp32 accumulator, nothing is rescaled, and an operand is two fp16 planes -- the same bytes and the same [rows, ld] geometry as
+// the split-bf16 (hi, lo) planes, so the GEMM's stage layout, DMA and fragment reads are the three-product kernel's.
+// Range: fp16 (6e-5 .. 65504 normal); values below ~4e-3 lose relative (not absolute) precision in a2.  The format is used for
+// FORWARD operands (activations of O(1), weights); gradients keep bf16's exponent range.
+#pragma once
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+constexpr float F16X2_E = 0.015625f;          // e = 2^-6
+constexpr float F16X2_INV_E = 64.0f;
+
+__device__ __forceinline__ float f16x2_clamp(float x) { return fminf(fmaxf(x, -65504.0f), 65504.0f); }
+
+// first-operand (activation) encoding
+__device__ __forceinline__ void f16x2_a(float x, _Float16& a1, _Float16& a2) {
+  x = f16x2_clamp(x);
+  a1 = (_Float16)(x - x * F16X2_E);            // (1 - e) x is exact in fp32 for e = 2^-6 up to one rounding of the subtraction
+  a2 = (_Float16)(x - (float)a1);
+}
+// second-operand (weight) encoding
+__device__ __forceinline__ void f16x2_b(float x, _Float16& b1, _Float16& b2) {
+  x = f16x2_clamp(x);
+  b1 = (_Float16)x;
+  b2 = (_Float16)((float)b1 + (x - (float)b1) * F16X2_INV_E);
+}
+
+__device__ __forceinline__ uint32_t f16x2_pack(_Float16 lo, _Float16 hi) {
+  return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+// eight consecutive values -> the two 16-byte plane pieces (ROLE 0: first operand, 1: second operand) [+ the bf16 piece]
+template <int ROLE>
+__device__ __forceinline__ void f16x2_encode8(const float (&v)[8], u32x4_t& p1, u32x4_t& p2) {
+  _Float16 h1[8], h2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (ROLE == 0) f16x2_a(v[e], h1[e], h2[e]);
+    else f16x2_b(v[e], h1[e], h2[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    p1[e] = f16x2_pack(h1[2 * e], h1[2 * e + 1]);
+    p2[e] = f16x2_pack(h2[2 * e], h2[2 * e + 1]);
+  }
+}
+__device__ __forceinline__ u32x4_t bf16_piece8(const float (&v)[8]) {
+  return (u32x4_t){f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]), f32x2_to_bf16x2(v[4], v[5]), f32x2_to_bf16x2(v[6], v[7])};
+}

@@ -48,14 +48,11 @@
 #include <type_traits>
 
 #include "common.h"
-#include "f6.h"
+#include "f16x2.h"
 #include "egovlp_hip.h"
 
 namespace {
 
-#ifndef EGV_F6_DMA
-#define EGV_F6_DMA 1      // who issues the LDS-DMA inside the f16f6 main loop (see k_tile6); 0 / 2: A/B diagnostics
-#endif
 constexpr int KT = 64;    // contraction depth of one LDS tile
 constexpr int NFW = 8;    // 16-column fragments per wave
 constexpr int BNB = 256;  // block tile columns
@@ -67,8 +64,8 @@ enum { EPI_RAW = 0,      // store the accumulators (split-K partial slab, or pla
        EPI_GELU = 2,     // + bias, pre-activation -> aux_out, gelu -> fp32 and/or planes
        EPI_GELU_BWD = 3, // * gelu'(aux_in) -> fp32 and/or planes
        EPI_GENERIC = 4,  // everything at run time (alpha, ReLU', ...)
-       EPI_GELU_F6 = 5 };// EPI_GELU with the activation written in the f16f6 operand format (csrc/f6.h): fp16 plane + MXFP6 slots
-                         // [+ bf16 plane for the backward], the saved gelu' as bf16 -- fc1 forward of the f16f6 mode
+       EPI_GELU_X2 = 5 };// EPI_GELU with the activation written in the f16x2 operand format (csrc/f16x2.h, first-operand role): two
+                         // fp16 planes [+ bf16 plane for the backward], the saved gelu' as bf16 -- fc1 forward of the f16x2 mode
 
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
 typedef __attribute__((ext_vector_type(8))) short s16x8v;
@@ -126,26 +123,7 @@ __device__ __forceinline__ f16x8_t ld128h_asm(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
   return __builtin_bit_cast(f16x8_t, r);
 }
-// One MXFP6 slot (32 B: 24 B of codes, the scale byte, pad) of the f16f6 loop: two 16-byte reads by lanes 0-31 ONLY (EXEC masked
-// inside the asm: lanes 32-63 are the k-groups of the K = 128 instruction that a 32-deep k-tile does not fill, and reading for them
-// would cost the LDS as much again).  Their registers keep whatever they held; they are taken out of the product through the
-// SCALE operand instead (slot_scale: E8M0 byte 0 = 2^-127 on both sides, 2^-254 x anything an E2M3 block can sum to is 0 in fp32).
-// a0 / a1: the two 16-B chunks of the slot (their order in LDS depends on the row's chunk permutation, so two addresses).
-// Two 16-byte reads (chunks s and s + 2 of the row, csrc/f6.h); the MFMA operand is the 8-register tuple of the two results side by
-// side (FP6 reads its first 6 dwords), which the register coalescer forms without copies from two whole 128-bit values as long
-// as they are defined and dead inside one loop iteration.
-template <int OFF>
-__device__ __forceinline__ void ld_slot_asm(u32x4_t& s0, u32x4_t& s1, unsigned a0, unsigned a1) {
-  asm volatile("s_mov_b32 exec_hi, 0\n\tds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_mov_b32 exec_hi, -1"
-               : "=&v"(s0), "=&v"(s1)
-               : "v"(a0), "v"(a1), "i"(OFF));
-}
-typedef __attribute__((ext_vector_type(8))) int i32x8_t;
-__device__ __forceinline__ i32x8_t slot_operand(const u32x4_t& s0, const u32x4_t& s1) {
-  return __builtin_bit_cast(i32x8_t, __builtin_shufflevector(s0, s1, 0, 1, 2, 3, 4, 5, 6, 7));
-}
 __device__ __forceinline__ void tie(u32x2_t& x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void anchor(const f32x4_t& x) { asm volatile("" ::"v"(x)); }   // "x exists here": stops code sinking
 __device__ __forceinline__ void tie(unsigned& x) { asm volatile("" : "+v"(x)); }
 
 // Loop condition of the ROLLED epilogue loops.  LLVM's block-frequency estimate multiplies by ~32 per loop level, so a
@@ -219,16 +197,16 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
 // ids [r G, (r + 1) G), XCD remap inside a round), bands in id order, so every workgroup gets the tall tiles in its early rounds
 // and the short ones in its last: M = 25 120 x N = 2304 is 53 + 32 bands = 765 tiles = 5 + 5 + 4 units per workgroup where 79
 // bands of 320 rows are 711 tiles = 3 rounds of 5 (-6.7 %); N = 3072: 5 + 5 + 5 + 4 instead of 4 x 5 (-5 %).
-// PROD: 0 = one product per k-tile from single planes (plain loops), 3 = fused bf16x3, 6 = f16f6 (fp16 product + one block-scaled
-// MXFP6 product per 32-deep k-tile; same stage layout and DMA as 3).
+// PROD: 0 = one product per k-tile from single planes (plain loops), 3 = fused bf16x3 (A_hi B_lo + A_lo B_hi + A_hi B_hi on the bf16
+// MFMA), 2 = f16x2 (A_1 B_1 + A_2 B_2 on the fp16 MFMA, csrc/f16x2.h): the same loop with one pass less and the other opcode.
 template <int MF, bool TN, int EPI, int PROD, bool MIXED = false>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg_arg, const int nb5_arg) {
-  constexpr bool F6 = PROD == 6;
+  constexpr bool X2 = PROD == 2;
   constexpr bool F3 = PROD != 0;      // the fused stage layout ([A_hi | A_lo | B_hi | B_lo] x 64 B, 32-deep k-tiles)
-  constexpr bool IS_GELU = EPI == EPI_GELU || EPI == EPI_GELU_F6;
-  static_assert(!MIXED || (PROD == 3 && MF == 5 && !TN), "mixed row bands: the fused three-product NT instance with 320-row tiles");
-  static_assert(!F6 || MF == 4, "the f16f6 loop keeps 8 registers per MXFP6 slot: 256-row tiles only");
-  static_assert(EPI != EPI_GELU_F6 || F6, "f16f6 outputs are produced by the f16f6 instances only");
+  constexpr bool IS_GELU = EPI == EPI_GELU || EPI == EPI_GELU_X2;
+  static_assert(PROD == 0 || PROD == 2 || PROD == 3, "");
+  static_assert(!MIXED || (F3 && MF == 5 && !TN), "mixed row bands: the fused NT instances with 320-row tiles");
+  static_assert(EPI != EPI_GELU_X2 || X2, "f16x2 outputs are produced by the f16x2 instances only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef EGV_DIAG
   const int dbg = dbg_arg;      // `make diag` build only (tools/gemm_trace.py, tools/gemm_bench.py with EGV_GEMM_DBG)
@@ -269,10 +247,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   auto stamp = [&](int t, int i) {
     if (stamp_on && t < 64 && lane == 0) stamp_lds[t * 4 + i] = __builtin_amdgcn_s_memtime();
   };
-  auto stamp8 = [&](int t, int i) {     // the f16f6 loop: 8 stamps per k-tile, first 32 k-tiles (tools/f6_trace.py)
-    if (stamp_on && t < 32 && lane == 0) stamp_lds[t * 8 + i] = __builtin_amdgcn_s_memtime();
-  };
-
   const int tiles_n = (p.N + BNB - 1) / BNB;
   const int nb5 = MIXED ? nb5_arg : 0;
   const int tiles_m = MIXED ? nb5 + (p.M - nb5 * 320 + 255) / 256 : (p.M + BM - 1) / BM;
@@ -551,152 +525,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
     for (int i = 0; i < MF; ++i) cs[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (F6) {
-      // ---- f16f6 NT main loop (csrc/f6.h) ------------------------------------------------------------------------------------
-      // Per 32-deep k-tile and fragment pair: ONE fp16 MFMA (A_h . B_h) and ONE block-scaled MXFP6 MFMA whose k-group 0 multiplies
-      // c6(A) . l6(B) and k-group 1 l6(A) . c6(B) (groups 2, 3 = lanes 32-63: scale 0) -- 2 issue units where bf16x3 spends 3
-      // (measured: 31.3 vs 48.0 ns per fragment and k-tile, tools/mx_probe.hip).  The stage layout and the DMA are the fused
-      // loop's: "hi" rows are 32 fp16, "lo" rows the 64-byte slot pair of the block.
-      // Phase j (0..7) runs the fp16 products of B fragment j and the MXFP6 products of B slot j - 2 (two phases behind; slots 6, 7
-      // in a tail that overlaps the hand-over), each against the MF resident A sets.  The fp16 fragments are prefetched across
-      // k-tiles as in the fused loop; the SLOTS are fetched and consumed inside one k-tile: a slot is an MFMA operand tuple
-      // assembled from two reads, and only values that are defined and dead within one loop iteration coalesce into that tuple
-      // without copies (loop-carried ones cost ~350 moves and 100 spills).  A k-tile of this loop has half the MFMA work of the
-      // fused loop's, so what it cannot afford is the burst of LDS reads all eight waves issue right behind the k-tile barrier
-      // with the matrix pipes idle (first version: 470-750 of 4150 cycles per k-tile, profiles/r04c_f6_ktile_stamps_*.txt):
-      // the A slots are fetched one behind each fp16 MFMA of phase 0 and first used in phase 2.
-      // Reads complete in issue order; waits count the reads issued behind the ones needed:
-      //   phase 0:  B slot 0 (2), B_h(1)   | wait 3  -> B_h(0), A_h (in flight from the previous tail) | fp16(0) + A slot i behind MFMA i
-      //   phase 1:  B slot 1, B_h(2)       | wait 11 -> B_h(1)                                         | fp16(1)
-      //   phase j:  B slot j, B_h(j+1)     | wait 3  -> B_h(j), B slot j-2, (j = 2: the A slots)       | fp16(j), mx6(j-2)      (j = 7: wait 2)
-      //   tail:     wait 0, hand-over (barrier), B_h(0)', mx6(6) with A_h' fetched behind its MFMAs, mx6(7)
-      f16x8_t Ah[MF], Bh[2];
-      unsigned lmask = lane < 32 ? 0xffu : 0u;            // lanes 32-63: scale byte 0 (see ld_slot_asm)
-      asm volatile("" : "+v"(lmask));
-      // this lane's slot: row (lane & 15) of the fragment, chunks (s, s + 2) of the 64-B row with s = 0 (c6) or 1 (l6); LDS position
-      // of source chunk s in row r is s ^ g((r >> 2) & 3).  A side: k-group 0 reads c6, k-group 1 l6; B side the other way round.
-      const int gg6 = (0x78 >> (2 * ((lane >> 2) & 3))) & 3;
-      const int kg = (lane >> 4) & 1;
-      const unsigned fah = lds0 + a_rd0, fbh = lds0 + b_rd0;
-      const unsigned fas = lds0 + F3_ALO + (wm * MF * 16 + (lane & 15)) * 64 + ((kg ^ gg6) << 4);
-      const unsigned fbs = lds0 + F3_B + F3_BLO + (wn * 128 + (lane & 15)) * 64 + (((1 - kg) ^ gg6) << 4);
-      auto k_tile6 = [&](const int t) {
-        const bool HN = t + 1 < nt;
-        const int sb = (t & 1) * STAGE;
-        const unsigned rbh = fbh + sb, rbs = fbs + sb, ras = fas + sb;
-        char* dma_lds = smem + (STAGE - sb);
-        avo = nt_avo; bvo = nt_bvo;
-        asm volatile("" : "+v"(avo), "+v"(bvo));
-        u32x4_t As0[MF], As1[MF], Bs0[3], Bs1[3];
-        int Asc[MF];
-        stamp8(t, 0);
-        auto mm_h = [&](auto Jc, auto Ic) {
-          constexpr int j = decltype(Jc)::value, i = decltype(Ic)::value;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
-        };
-        auto mm_6 = [&](auto Jc, const int bsc, auto Ic) {
-          constexpr int j = decltype(Jc)::value, i = decltype(Ic)::value;
-          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(slot_operand(Bs0[j % 3], Bs1[j % 3]), slot_operand(As0[i], As1[i]),
-                                                                       acc[i][j], 2, 2, 0, bsc, 0, Asc[i]);
-        };
-        static_for<0, NFW>([&](auto Jc) {
-          constexpr int j = decltype(Jc)::value;
-          ld_slot_asm<j * 1024>(Bs0[j % 3], Bs1[j % 3], rbs, rbs ^ 32u);
-          if constexpr (j < NFW - 1) Bh[(j + 1) & 1] = ld128h_asm<(j + 1) * 1024>(rbh);
-          // DMA of k-tile t+1, split by operand: waves 0-3 stage the A rows (activations, from HBM: early, phases 0-3), waves 4-7 the
-          // B rows (weights, L2-resident: phases 3-6) -- the two waves of a SIMD are blocked by their pieces at different times
-          if constexpr (EGV_F6_DMA == 0) {
-            if (j < 4 && loader && HN) {
-              constexpr int PP = (NP + 3) / 4;
-              static_for<j * PP, (j + 1) * PP < NP ? (j + 1) * PP : NP>([&](auto Ic) { piece(dma_lds, decltype(Ic)::value, j * PP); });
-            }
-          } else {
-            constexpr int PA = 2 * GA, PB = 2 * GB;            // pieces of one wave's A share / B share (hi + slots)
-            constexpr int JB0 = EGV_F6_DMA == 1 ? 3 : 0;       // first phase of the B loaders
-            if (j < 4 && wave < 4 && HN) {
-              constexpr int PP = (PA + 3) / 4;
-              static_for<j * PP, (j + 1) * PP < PA ? (j + 1) * PP : PA>([&](auto Ic) { piece(dma_lds, decltype(Ic)::value, j * PP); });
-            }
-            if (j >= JB0 && j < JB0 + 4 && wave >= 4 && HN) {
-              constexpr int PP = (PB + 3) / 4, jj = j - JB0;
-              static_for<PA + jj * PP, PA + ((jj + 1) * PP < PB ? (jj + 1) * PP : PB)>(
-                  [&](auto Ic) { piece(dma_lds, decltype(Ic)::value, PA + jj * PP); });
-            }
-          }
-          lgkm_wait<(j == 1) ? 2 * MF + 3 : ((j == NFW - 1) ? 2 : 3)>();
-          if constexpr (j == 0) stamp8(t, 1);
-          if constexpr (j == 2) stamp8(t, 2);
-          if constexpr (j == 4) stamp8(t, 3);
-          tie(Bh[j & 1]);
-          if constexpr (j == 0) static_for<0, MF>([&](auto Ic) { tie(Ah[decltype(Ic)::value]); });
-          int bsc = 0;
-          if constexpr (j >= 2) {
-            tie(Bs0[(j - 2) % 3]); tie(Bs1[(j - 2) % 3]);
-            bsc = (int)(Bs1[(j - 2) % 3][2] & lmask);
-            if constexpr (j == 2) {
-              static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; tie(As0[i]); tie(As1[i]); });
-              static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; Asc[i] = (int)(As1[i][2] & lmask); });
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<0, MF>([&](auto Ic) {
-            constexpr int i = decltype(Ic)::value;
-            mm_h(Jc, Ic);
-            if constexpr (j == 0) {
-              __builtin_amdgcn_sched_barrier(0);
-              ld_slot_asm<i * 1024>(As0[i], As1[i], ras, ras ^ 32u);     // first read by mx6(0) in phase 2
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          });
-          if constexpr (j >= 2) {
-            static_for<0, MF>([&](auto Ic) { mm_6(std::integral_constant<int, j - 2>{}, bsc, Ic); });
-            // the finished accumulators of column j - 2 are next read a whole k-tile later: without a use HERE MachineSink moves
-            // all 8 MF block-scaled MFMAs of the k-tile into the loop latch (and keeps every B slot alive until then)
-            static_for<0, MF>([&](auto Ic) { anchor(acc[decltype(Ic)::value][j - 2]); });
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        // ---- tail: hand-over to k-tile t+1 under the MXFP6 products of B slots 6 and 7; the next A_h is fetched behind them
-        stamp8(t, 4);
-        lgkm_wait<0>();
-        tie(Bs0[0]); tie(Bs1[0]); tie(Bs0[1]); tie(Bs1[1]);
-        const int bsc6 = (int)(Bs1[6 % 3][2] & lmask), bsc7 = (int)(Bs1[7 % 3][2] & lmask);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned nah = fah + (STAGE - sb);
-        if (HN) {
-          // k-tile t+1 (this wave's DMA pieces) has landed; every read of stage t & 1 by this wave has returned
-          stamp8(t, 5);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          stamp8(t, 6);
-          __builtin_amdgcn_s_barrier();
-          stamp8(t, 7);
-          stage_advance();
-          Bh[0] = ld128h_asm<0>(fbh + (STAGE - sb));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<0, MF>([&](auto Ic) {
-          constexpr int i = decltype(Ic)::value;
-          mm_6(std::integral_constant<int, 6>{}, bsc6, Ic);
-          anchor(acc[i][6]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (HN) Ah[i] = ld128h_asm<i * 1024>(nah);        // A_h: its last reader was the fp16 pass of phase 7
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        static_for<0, MF>([&](auto Ic) { mm_6(std::integral_constant<int, 7>{}, bsc7, Ic); anchor(acc[decltype(Ic)::value][7]); });
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      if (nt > 0) {
-        // k-tile 0 has landed and every wave is past a barrier behind that: B_h(0), A_h -- what phase 0 counts on
-        Bh[0] = ld128h_asm<0>(fbh);
-        static_for<0, MF>([&](auto Ic) { Ah[decltype(Ic)::value] = ld128h_asm<decltype(Ic)::value * 1024>(fah); });
-        if ((dbg & 0xfff) == 200) ts1 = __builtin_amdgcn_s_memrealtime();
-#pragma unroll 1
-        for (int t = 0; t < nt; ++t) k_tile6(t);
-      }
-    } else if constexpr (F3) {
-      // ---- fused three-product NT main loop (see the F3 note at the top of the kernel) --------------------------------------
+    if constexpr (F3) {
+      // ---- fused NT main loop: three bf16 products, or the two fp16 products of f16x2 (see the F3 note at the top of the kernel) ----
       // Phase j (0..7) multiplies B fragment pair j (hi, lo) with the MF resident A pairs: 3 MF MFMAs in three passes over i
-      // (hi.lo, lo.hi, hi.hi -- five independent accumulators between two MFMAs on the same one).  Fetch plan (asm reads
+      // (hi.lo, lo.hi, hi.hi -- five independent accumulators between two MFMAs on the same one); f16x2: two passes, lo.lo and
+      // hi.hi (plane 1 = "hi", plane 2 = "lo"), on the fp16 opcode -- same fetch plan, same waits.  Fetch plan (asm reads
       // complete in issue order; every wait counts the reads issued behind the ones it needs):
       //   phase 7 of the previous k-tile, behind the barrier:  B(0) pair | A_lo[0..MF) after pass 1 | A_hi[i-1] behind the
       //     hi.hi MFMA of i (its last reader is one MFMA back), A_hi[MF-1] last
@@ -712,6 +545,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       auto rd_al = [&](unsigned ra) { static_for<0, MF>([&](auto Ic) { constexpr int i = decltype(Ic)::value; Al[i] = ld128_asm<i * 1024 + F3_ALO>(ra); }); };
       auto rd_ah = [&](auto Ic, unsigned ra) { constexpr int i = decltype(Ic)::value; Ah[i] = ld128_asm<i * 1024>(ra); };
       const bool grp5 = !MIXED || mf == 5;          // wave-uniform: does this tile use the fifth fragment group?
+      auto mma = [&](const bf16x8_t& b, const bf16x8_t& a, f32x4_t c) -> f32x4_t {
+        if constexpr (X2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+      };
       auto pass = [&](auto Jc, const bf16x8_t& b, bf16x8_t (&a)[MF]) {
         constexpr int j = decltype(Jc)::value;
 #ifdef EGV_F3_SKIP      // diagnostics build (WRONG results): the loop with one of its three products left out, everything else in place
@@ -720,12 +557,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         static_for<0, MF>([&](auto Ic) {
           constexpr int i = decltype(Ic)::value;
           if (MIXED && i == MF - 1) {
-            if (grp5) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0);
+            if (grp5) acc[i][j] = mma(b, a[i], acc[i][j]);
           } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = mma(b, a[i], acc[i][j]);
           }
         });
       };
+      // the passes of one phase: bf16x3 (hi.lo, lo.hi, hi.hi) = (Bh, Al), (Bl, Ah), (Bh, Ah); f16x2 (lo.lo, hi.hi) = (Bl, Al), (Bh, Ah)
+      auto pass_lo = [&](auto Jc, const int q) { pass(Jc, X2 ? Bl[q] : Bh[q], Al); };
+      auto pass_mid = [&](auto Jc, const int q) { if constexpr (!X2) pass(Jc, Bl[q], Ah); };
       auto k_tile3 = [&](const int t) {
         const bool HN = t + 1 < nt;
         const int sb = (t & 1) * STAGE;
@@ -743,15 +583,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           if constexpr (j == 0) {
             lgkm_wait<MF + 2>();          // B(0) pair and A_lo landed; outstanding: A_hi x MF, B(1) pair
             tie(Bh[0]);
+            tie(Bl[0]);
             static_for<0, MF>([&](auto Ic) { tie(Al[decltype(Ic)::value]); });
             __builtin_amdgcn_sched_barrier(0);
-            pass(Jc, Bh[0], Al);
+            pass_lo(Jc, 0);
             __builtin_amdgcn_sched_barrier(0);
             lgkm_wait<2>();               // A_hi landed
             tie(Bl[0]);
             static_for<0, MF>([&](auto Ic) { tie(Ah[decltype(Ic)::value]); });
             __builtin_amdgcn_sched_barrier(0);
-            pass(Jc, Bl[0], Ah);
+            pass_mid(Jc, 0);
             pass(Jc, Bh[0], Ah);
             __builtin_amdgcn_sched_barrier(0);
           } else if constexpr (j < NFW - 1) {
@@ -759,8 +600,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             tie(Bh[j & 1]);
             tie(Bl[j & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            pass(Jc, Bh[j & 1], Al);
-            pass(Jc, Bl[j & 1], Ah);
+            pass_lo(Jc, j & 1);
+            pass_mid(Jc, j & 1);
             pass(Jc, Bh[j & 1], Ah);
             __builtin_amdgcn_sched_barrier(0);
           } else {
@@ -777,18 +618,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
               rd_b3(std::integral_constant<int, 0>{}, nb);
             }
             __builtin_amdgcn_sched_barrier(0);
-            pass(Jc, Bh[j & 1], Al);
+            pass_lo(Jc, j & 1);
             __builtin_amdgcn_sched_barrier(0);
             if (HN) rd_al(na);            // A_lo has no reader left in this k-tile
             __builtin_amdgcn_sched_barrier(0);
-            pass(Jc, Bl[j & 1], Ah);
+            pass_mid(Jc, j & 1);
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, MF>([&](auto Ic) {
               constexpr int i = decltype(Ic)::value;
               if (MIXED && i == MF - 1) {
-                if (grp5) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
+                if (grp5) acc[i][j] = mma(Bh[j & 1], Ah[i], acc[i][j]);
               } else {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bh[j & 1], Ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mma(Bh[j & 1], Ah[i], acc[i][j]);
               }
               __builtin_amdgcn_sched_barrier(0);
               if constexpr (i > 0) {
@@ -1164,12 +1005,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       } else {
         // GELU / GELU' / generic epilogues without plane outputs (test shapes): loads in the loop
 #pragma unroll 1
-        for (int i = 0; EGV_COLD_LOOP(EPI != EPI_GELU_F6 && i < mfe); ++i) {
+        for (int i = 0; EGV_COLD_LOOP(EPI != EPI_GELU_X2 && i < mfe); ++i) {
           put_i(i);
 #pragma unroll 1
           for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
             const f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5)));
-            if constexpr (EPI != EPI_GELU_F6) epilogue4<EPI>(p, val, mw + 16 * i + 2 * it + rs32, n, z, ksplit);
+            if constexpr (EPI != EPI_GELU_X2) epilogue4<EPI>(p, val, mw + 16 * i + 2 * it + rs32, n, z, ksplit);
           }
         }
       }
@@ -1190,8 +1031,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         const long ld4 = 4 * p.ldoh;
         bf16_t* dz = nullptr;
         if (IS_GELU && p.aux_out) dz = (bf16_t*)p.aux_out + (long)(mw + rs16) * p.ldaux + n;
-        // f16f6 outputs: the bf16 copy for the backward at a fixed element distance from the fp16 plane (0: not wanted)
-        const long dbf = (EPI == EPI_GELU_F6 && p.out_bf) ? (long)(p.out_bf - p.out_hi) : 0;
+        // f16x2 outputs: the bf16 copy for the backward at a fixed element distance from the first fp16 plane (0: not wanted)
+        const long dbf = (EPI == EPI_GELU_X2 && p.out_bf) ? (long)(p.out_bf - p.out_hi) : 0;
         const long ldz4 = 4 * p.ldaux;
         const bool saved_grad = p.aux_bf16 == 2;
         auto row16 = [&](const int it, const f32x4_t zin) {
@@ -1236,13 +1077,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             }
           }
           constexpr int PSITE = IS_GELU ? EGV_NT_GELU_PLANES : ((EPI == EPI_GELU_BWD) ? EGV_NT_GELUBWD_PLANES : EGV_NT_GEMM_PLANES);
-          if constexpr (EPI == EPI_GELU_F6) {
-            // the activation in the f16f6 operand format: the 16 lanes of a row hold its 128 columns, 8 each -- a quad = one MX block
+          if constexpr (EPI == EPI_GELU_X2) {
+            // the activation in the f16x2 operand format (first-operand role): two fp16 planes [+ the bf16 copy]
             const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const F6Lane o = f6_encode8(vv, el);
-            egv_store16<PSITE>(dh, o.h16);
-            if (dbf) egv_store16<PSITE>(dh + dbf, o.bf);
-            f6_store_piece<PSITE>((char*)(dh + dlo - 8 * (el & 3)), el, o.piece);
+            u32x4_t o1, o2;
+            f16x2_encode8<0>(vv, o1, o2);
+            egv_store16<PSITE>(dh, o1);
+            egv_store16<PSITE>(dh + dlo, o2);
+            if (dbf) egv_store16<PSITE>(dh + dbf, bf16_piece8(vv));
           } else {
             uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
             split_bf16x2(v0[0], v0[1], h0, l0);
@@ -1274,15 +1116,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         nvm = mfe * 4 * (1 + (dlo ? 1 : 0) + (dz ? 1 : 0) + (dbf ? 1 : 0));
       } else {
         // plane output together with fp32 side outputs / in-loop inputs (test shapes, the all-bf16x3 mode's fp32 z): rolled
-        // (never the f16f6 flavour: the launcher only accepts it with the fast path's argument set)
+        // (never the f16x2-output flavour: the launcher only accepts it with the fast path's argument set)
 #pragma unroll 1
-        for (int i = 0; EGV_COLD_LOOP(EPI != EPI_GELU_F6 && i < mfe); ++i) {
+        for (int i = 0; EGV_COLD_LOOP(EPI != EPI_GELU_X2 && i < mfe); ++i) {
           put_i(i);
 #pragma unroll 1
           for (int it = 0; EGV_COLD_LOOP(it < 4); ++it) {
             const unsigned a0 = (r16 + it * 2048) ^ ((it & 1) << 6);
             const int m = mw + 16 * i + 4 * it + rs16;
-            if constexpr (EPI != EPI_GELU_F6) {
+            if constexpr (EPI != EPI_GELU_X2) {
               epilogue4<EPI>(p, *(const f32x4_t*)(smem + a0), m, n, z, ksplit);
               epilogue4<EPI>(p, *(const f32x4_t*)(smem + (a0 ^ 16u)), m, n + 4, z, ksplit);
             }
@@ -1376,39 +1218,45 @@ int pick_mixed_bands(const egv_gemm_desc& p, int grid) {
 
 template <int MF, bool TN, int PROD = 0>
 int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
-  if constexpr (PROD == 6) {
-    if (p.ksplit > 1) return EGV_ERR_ARG;
-  } else {
-    if (p.ksplit > 1 || TN) return launch_big<MF, TN, EPI_RAW, PROD>(p, s);   // split-K slab / wgrad: plain fp32 output
+  if (p.ksplit > 1 || TN) {
+    if (PROD == 2 || p.out_fmt != 0) return EGV_ERR_ARG;            // f16x2: forward products only (un-split, NT)
+    return launch_big<MF, TN, EPI_RAW, PROD>(p, s);                 // split-K slab / wgrad: plain fp32 output
   }
-  if constexpr (PROD == 3 && MF == 5 && !TN) {
+  if constexpr (PROD == 2) {
+    // f16x2 output (fc1 -> fc2 of the forward): GELU epilogue only, planes only
+    if (p.out_fmt == 1 && (p.act != EGV_ACT_GELU || p.alpha != 1.0f || !p.out_hi || !p.out_lo || p.residual || p.out_f32 ||
+                           (p.aux_out && !p.aux_bf16) || p.ldoh % 8 != 0))
+      return EGV_ERR_ARG;
+  } else {
+    if (p.out_fmt != 0) return EGV_ERR_ARG;
+  }
+  if constexpr (PROD != 0 && MF == 5 && !TN) {
     // the two multi-round forward shapes of the step (qkv: plane outputs; fc1: GELU + planes + saved gelu') with mixed row bands
     const int cap = p.grid_cap > 0 ? p.grid_cap : 256;
     const int nb5 = pick_mixed_bands(p, cap);
     if (nb5 >= 0 && p.alpha == 1.0f) {
-      if (p.act == EGV_ACT_NONE && (p.bias || p.residual || p.out_hi)) return launch_big<5, false, EPI_LINEAR, 3, true>(p, s, nb5);
-      if (p.act == EGV_ACT_GELU) return launch_big<5, false, EPI_GELU, 3, true>(p, s, nb5);
+      if (p.act == EGV_ACT_NONE && (p.bias || p.residual || p.out_hi)) return launch_big<5, false, EPI_LINEAR, PROD, true>(p, s, nb5);
+      if (p.act == EGV_ACT_GELU) {
+        if constexpr (PROD == 2) {
+          if (p.out_fmt == 1) return launch_big<5, false, EPI_GELU_X2, 2, true>(p, s, nb5);
+        }
+        return launch_big<5, false, EPI_GELU, PROD, true>(p, s, nb5);
+      }
     }
   }
-  if constexpr (PROD == 6) {
-    // f16f6 instances: the epilogues the forward of the step uses (qkv: bias -> bf16 planes; proj / fc2: bias + residual -> fp32;
-    // fc1: GELU -> f16f6 planes + saved gelu'), nothing else
-    if (p.alpha != 1.0f) return EGV_ERR_ARG;
-    if (p.act == EGV_ACT_NONE && p.out_fmt == 0) return launch_big<MF, false, EPI_LINEAR, 6>(p, s);
-    if (p.act == EGV_ACT_GELU && p.out_fmt == 0) return launch_big<MF, false, EPI_GELU, 6>(p, s);
-    if (p.act == EGV_ACT_GELU && p.out_fmt == 1) {
-      if (!p.out_hi || !p.out_lo || p.residual || p.out_f32 || (p.aux_out && !p.aux_bf16) || p.ldoh % 32 != 0 || p.N % 32 != 0)
-        return EGV_ERR_ARG;
-      return launch_big<MF, false, EPI_GELU_F6, 6>(p, s);
+  if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
+    if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, PROD>(p, s);
+    return launch_big<MF, false, EPI_LINEAR, PROD>(p, s);
+  }
+  if (p.alpha == 1.0f && p.act == EGV_ACT_GELU) {
+    if constexpr (PROD == 2) {
+      if (p.out_fmt == 1) return launch_big<MF, false, EPI_GELU_X2, 2>(p, s);
     }
-    return EGV_ERR_ARG;
+    return launch_big<MF, false, EPI_GELU, PROD>(p, s);
+  }
+  if constexpr (PROD == 2) {
+    return EGV_ERR_ARG;                                             // the forward of the step uses nothing else
   } else {
-    if (p.out_fmt != 0) return EGV_ERR_ARG;
-    if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
-      if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, PROD>(p, s);
-      return launch_big<MF, false, EPI_LINEAR, PROD>(p, s);
-    }
-    if (p.alpha == 1.0f && p.act == EGV_ACT_GELU) return launch_big<MF, false, EPI_GELU, PROD>(p, s);
     if (p.alpha == 1.0f && p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD, PROD>(p, s);
     return launch_big<MF, false, EPI_GENERIC, PROD>(p, s);
   }
@@ -1456,7 +1304,7 @@ int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant) {
   static const int f3_env = getenv("EGV_GEMM_F3") ? atoi(getenv("EGV_GEMM_F3")) : 1;
   f3 = f3 && f3_env != 0;
 #endif
-  if (p.passes == 2) return launch_epi<4, false, 6>(p, s);      // f16f6: 256-row tiles (8 registers per MXFP6 slot)
+  if (p.passes == 2) return mf == 5 ? launch_epi<5, false, 2>(p, s) : launch_epi<4, false, 2>(p, s);      // f16x2
   if (f3) return mf == 5 ? launch_epi<5, false, 3>(p, s) : launch_epi<4, false, 3>(p, s);
   if (mf == 5) return launch_epi<5, false>(p, s);
   return launch_epi<4, false>(p, s);

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue_kernel(const egv_g
 static int gemm_variant(const egv_gemm_desc& p) {
   const bool big_ok = egv_gemm_big_supports(p);
   if (p.trans) return big_ok ? 3 : -1;
-  if (p.passes == 2) return big_ok ? 3 : -1;   // f16f6 operands: the big-tile kernel is the only one that reads them
+  if (p.passes == 2) return big_ok ? 3 : -1;   // f16x2 operands: the big-tile kernel is the only one that multiplies them
   // big tiles only when there are enough of them to occupy the chip (DistilBERT's M = 1024 GEMMs make 12)
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
   if (big_ok && big_tiles >= 128) return 3;
@@ -262,9 +262,8 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const int variant = gemm_variant(p);
   if (variant < 0) return EGV_ERR_ARG;
   if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // bf16 aux: gemm_big GELU epilogues only
-  // f16f6 operands / outputs (csrc/f6.h): the big-tile NT kernel only, K and lda / ldb in whole 32-element MX blocks
-  if ((p.passes == 2 || p.out_fmt != 0) && (variant < 3 || p.trans || p.passes != 2 || p.K % 32 != 0 || p.lda % 32 != 0 || p.ldb % 32 != 0))
-    return EGV_ERR_ARG;
+  // f16x2 operands / outputs (csrc/f16x2.h): the big-tile NT kernel only, un-split
+  if ((p.passes == 2 || p.out_fmt != 0) && (variant < 3 || p.trans || p.passes != 2 || p.ksplit > 1)) return EGV_ERR_ARG;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);

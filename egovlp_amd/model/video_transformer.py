@@ -39,7 +39,7 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, pa
     ec = ops.DEFAULT if ec is None else ec
     if not isinstance(dy, Planes):
         dy = ops.split_f32(dy, Pb)[0]
-    x_pl = x_pl.bwd()              # an f16f6 forward operand hands over its bf16 plane
+    x_pl = x_pl.bwd()              # an f16x2 forward operand hands over its bf16 plane
     M, K = x_pl.rows, x_pl.cols
     N = dy.cols
     dev = x_pl.hi.device
@@ -116,14 +116,14 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         x2 = x.contiguous().view(M, D)
         train = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward; this is the reliable signal
         Hd = fc1_w.shape[0]
-        # 'f16f6': the LayerNorm -> qkv / fc1 and fc1 -> fc2 hand-overs are in the f16f6 operand format (one fp16 + one block-scaled
-        # MXFP6 product, big-tile kernel only); attention and the proj Linears keep split-bf16 three-product operands (Pa).  Token
+        # 'f16x2': the LayerNorm -> qkv / fc1 and fc1 -> fc2 hand-overs are in the f16x2 operand format (two fp16 products instead of
+        # three bf16 ones, big-tile kernel only); attention and the proj Linears keep split-bf16 three-product operands (Pa).  Token
         # counts too small for the big-tile kernel (toy geometries) run the block in bf16x3.
-        if P == 2 and not (ops.f16f6_gemm_ok(M, 3 * D, D) and ops.f16f6_gemm_ok(M, Hd, D) and ops.f16f6_gemm_ok(M, D, Hd)):
+        if P == 2 and not (ops.f16x2_gemm_ok(M, 3 * D, D) and ops.f16x2_gemm_ok(M, Hd, D) and ops.f16x2_gemm_ok(M, D, Hd)):
             P = 3
-        f6 = P == 2
-        Pa = 3 if f6 else P
-        wf = "f16f6" if f6 else "bf16"
+        fx2 = P == 2
+        Pa = 3 if fx2 else P
+        wf = "f16x2" if fx2 else "bf16"
 
         def W(p, fmt="bf16"):
             return wc.get(p, need_t=False, fmt=fmt)[0]
@@ -144,7 +144,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         ops.gemm_nt(a_s, W(sproj_w), passes=Pa, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
         # ---- MLP (:175, Mlp.forward :46-52), exact-erf GELU fused into the fc1 epilogue
         n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P, want_bf=train)
-        h = ops.empty_planes_f16f6(M, Hd, dev, want_bf=train) if f6 else ops.empty_planes(M, Hd, P, dev)
+        h = ops.empty_planes_f16x2(M, Hd, dev, want_bf=train) if fx2 else ops.empty_planes(M, Hd, P, dev)
         # saved for backward: the fp32 pre-activation z in the all-bf16x3 parity mode; when backward runs single-pass bf16
         # anyway, gelu'(z) itself as bf16 -- the epilogue has Phi(z) and phi(z) in registers, the buffer is half the bytes,
         # and the fc2-dgrad epilogue becomes one multiply instead of a second erf evaluation over 77 M elements
@@ -220,8 +220,10 @@ _W_ORDER = ("tqkv", "tproj", "sqkv", "sproj", "fc1", "fc2")
 
 def block_calls_ok(ec: ExecContext, M, D, Hd):
     """May this block run through the C block calls?  (split-bf16 / bf16 precision, no per-kernel timer attached, every GEMM of
-    the block un-split and at least one 256-wide tile: the per-kernel path covers the toy shapes and the f16f6 mode)"""
-    if not ec.block_calls or ec.kernel_timer is not None or ec.fwd_passes not in (1, 3) or ec.bwd_passes > ec.fwd_passes:
+    the block un-split and at least one 256-wide tile: the per-kernel path covers the toy shapes)"""
+    if not ec.block_calls or ec.kernel_timer is not None or ec.bwd_passes > ec.fwd_passes:
+        return False
+    if ec.fwd_passes == 2 and not (ops.f16x2_gemm_ok(M, 3 * D, D) and ops.f16x2_gemm_ok(M, Hd, D) and ops.f16x2_gemm_ok(M, D, Hd)):
         return False
     if D < 256 or Hd < 256 or D % 64 or Hd % 64 or M < 256:
         return False
@@ -233,7 +235,10 @@ def _block_geom(B, T, n, H, D, Hd, P, Pb, train, z_bf16, eps, grid):
     return BlockGeom(B, T, n, H, D, Hd, P, Pb, int(train), int(z_bf16), float(eps), int(grid))
 
 
-def _block_params(wc, ln, biases, weights, need_t):
+_X2_FMTS = ("f16x2", "bf16", "f16x2", "bf16", "f16x2", "f16x2")     # f16x2 mode: qkv / fc1 / fc2 weights in the f16x2 format, proj split-bf16
+
+
+def _block_params(wc, ln, biases, weights, need_t, x2=False):
     """egv_block_params from the parameter tensors: LayerNorm affine (n3w, n3b, n1w, n1b, n2w, n2b), the six biases and the
     cached operand planes of the six weights (W^T planes too when `need_t`).  The planes are refreshed IN PLACE after an optimizer
     step, so the struct stays the same from step to step: it is kept on the model's weight cache, keyed by the block's first weight
@@ -241,9 +246,9 @@ def _block_params(wc, ln, biases, weights, need_t):
     import ctypes as C
     from .._lib import BlockParams
     P6, L6 = C.c_void_p * 6, C.c_int64 * 6
-    pls = [wc.get(w, need_t=need_t) for w in weights]
+    pls = [wc.get(w, need_t=need_t, fmt=(_X2_FMTS[i] if x2 else "bf16")) for i, w in enumerate(weights)]
     small = tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in biases)
-    key = (id(weights[0]), need_t)
+    key = (id(weights[0]), need_t, x2)
     hit = wc.param_structs.get(key)
     if hit is not None and hit[1] == small and all(a[0] is b[0] and a[1] is b[1] for a, b in zip(hit[0], pls)):
         return hit[2]
@@ -276,7 +281,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         dev = x.device
         x2 = x.contiguous().view(M, D)
         train = any(ctx.needs_input_grad)
-        z_bf16 = Pb == 1 and ops.uses_big_gemm(M, Hd, D)
+        z_bf16 = Pb == 1 and ops.uses_big_gemm(M, Hd, D, P)
         key = (B, T, n, H, D, Hd, P, Pb, train, z_bf16)
         g = _block_geom(*key, eps, ec.gemm_grid)
         ent = _BLOCK_CACHE.get(key)
@@ -292,7 +297,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         ln = (n3w, n3b, n1w, n1b, n2w, n2b)
         biases = (tqkv_b, tproj_b, sqkv_b, sproj_b, fc1_b, fc2_b)
         weights = (tqkv_w, tproj_w, sqkv_w, sproj_w, fc1_w, fc2_w)
-        prm = _block_params(ec.wc, ln, biases, weights, need_t=False)
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=False, x2=P == 2)
         _lib.check(_lib.lib().egv_block_fwd(C.byref(g), C.byref(prm), x2.data_ptr(), out.data_ptr(), arena.data_ptr(), ops._stream(x2)),
                    "egv_block_fwd")
         if train:
@@ -357,7 +362,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         for st in {s_ for s_ in streams if s_ is not None}:      # the side streams read / write these allocations of the main stream
             for t in (ctx.arena, barena, grads) + ((g_pl.hi,) if g_hi is not None else ()):
                 t.record_stream(st)
-        prm = _block_params(ec.wc, ln, biases, weights, need_t=True)
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2)
         P6 = C.c_void_p * 6
         io = BlockBwdIO(G.data_ptr(), g_hi, g_lo, x2.data_ptr(), ctx.arena.data_ptr(), barena.data_ptr(),
                         d_x.data_ptr(), dx_pl.hi.data_ptr(), dx_pl.lo.data_ptr() if dx_pl.lo is not None else None, grads.data_ptr(),

@@ -35,12 +35,12 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # the module-level names of earlier rounds (`Precision.set`, `ops.WGRAD_SIDE_STREAM = ...`, `ops.BACKWARD_POLL = ...`,
 # `ops.KERNEL_TIMER`, `ops.set_gemm_grid`) are views of DEFAULT's settings, kept for scripts and tests.  STATE (stream objects,
 # the dirty / queued flags of the wgrad stream, the weight-plane cache) is private to a context and never inherited.
-# "f16f6" (forward only; passes code 2 = its MFMA issue units): the video tower's qkv / fc1 / fc2 Linears run as one fp16 product
-# plus one block-scaled MXFP6 correction product on operands in the f16f6 format (include/egovlp_hip.h, csrc/f6.h); attention, the
-# proj Linears, the patch embedding, the text tower and the heads stay split-bf16 three-product (tests/precision_table.py: which
-# products tolerate what).
-_PASSES = {"bf16x3": 3, "bf16": 1, "f16f6": 2}
-_PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16f6"}
+# "f16x2" (forward only; passes code 2 = its two MFMA products): the video blocks' qkv / fc1 / fc2 Linears run as TWO fp16 products on
+# operands in the f16x2 format (include/egovlp_hip.h, csrc/f16x2.h) -- the accuracy of the three-product split-bf16 scheme at two
+# thirds of its MFMA work; attention, the proj Linears, the patch embedding, the text tower and the heads stay split-bf16
+# three-product.
+_PASSES = {"bf16x3": 3, "bf16": 1, "f16x2": 2}
+_PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16x2"}
 _HARD_DEFAULTS = {
     "fwd_passes": 3, "bwd_passes": 3,
     # weight-gradient GEMMs on their own HIP stream.  OFF unless the owner of the gradient hooks turns it on (bench.py and
@@ -109,10 +109,10 @@ class ExecContext:
 
     def set_precision(self, fwd: str = "bf16x3", bwd: Optional[str] = None):
         """'bf16x3' = split-bf16, three MFMA products, fp32-grade (meets the 1e-3 parity bar); 'bf16' = single pass;
-        'f16f6' (forward only, with a single-pass 'bf16' backward) = fp16 + MXFP6 correction product, ~1.3e-4 on the embeddings."""
-        bwd = bwd if bwd is not None else ("bf16" if fwd == "f16f6" else fwd)
-        if bwd == "f16f6" or (fwd == "f16f6" and bwd != "bf16"):
-            raise ValueError("'f16f6' is a forward format; it pairs with the single-pass 'bf16' backward")
+        'f16x2' (forward only, with a single-pass 'bf16' backward) = two fp16 products, fp32-grade like 'bf16x3' (3e-5 on the embeddings)."""
+        bwd = bwd if bwd is not None else ("bf16" if fwd == "f16x2" else fwd)
+        if bwd == "f16x2" or (fwd == "f16x2" and bwd != "bf16"):
+            raise ValueError("'f16x2' is a forward format; it pairs with the single-pass 'bf16' backward")
         return self.set(fwd_passes=_PASSES[fwd], bwd_passes=_PASSES[bwd])
 
     def precision_name(self):
@@ -120,7 +120,7 @@ class ExecContext:
 
     fwd_passes = property(lambda self: self.get("fwd_passes"))
     # what every forward product OUTSIDE the video blocks' qkv / fc1 / fc2 Linears runs with (patch embedding, text tower, heads,
-    # attention, proj): the f16f6 mode keeps them split-bf16 three-product
+    # attention, proj): the f16x2 mode keeps them split-bf16 three-product
     fwd_passes_split = property(lambda self: 3 if self.get("fwd_passes") == 2 else self.get("fwd_passes"))
     bwd_passes = property(lambda self: self.get("bwd_passes"))
     wgrad_side_stream = property(lambda self: self.get("wgrad_side_stream"))
@@ -406,12 +406,12 @@ def _need_cuda(*ts):
 
 @dataclass
 class Planes:
-    hi: torch.Tensor                 # bf16 [rows, ld]                                  | fmt 'f16f6': fp16 [rows, ld]
-    lo: Optional[torch.Tensor]       # bf16 [rows, ld] or None (passes == 1)            | fmt 'f16f6': the MXFP6 slot plane, int16 [rows, ld]
+    hi: torch.Tensor                 # bf16 [rows, ld]                                  | fmt 'f16x2': fp16 plane 1 [rows, ld]
+    lo: Optional[torch.Tensor]       # bf16 [rows, ld] or None (passes == 1)            | fmt 'f16x2': fp16 plane 2 [rows, ld]
     rows: int
     cols: int                        # logical columns (<= ld)
-    fmt: str = "bf16"                # 'bf16' (split planes) or 'f16f6' (include/egovlp_hip.h: egv_f16f6_encode)
-    bf: Optional[torch.Tensor] = None  # fmt 'f16f6' only: bf16(value) [rows, ld], what the single-pass backward GEMMs read
+    fmt: str = "bf16"                # 'bf16' (split planes) or 'f16x2' (include/egovlp_hip.h: egv_f16x2_encode; role: first / second operand)
+    bf: Optional[torch.Tensor] = None  # fmt 'f16x2' only: bf16(value) [rows, ld], what the single-pass backward GEMMs read
 
     @property
     def ld(self):
@@ -424,11 +424,11 @@ class Planes:
         return v
 
     def bwd(self):
-        """The operand view the backward GEMMs take: the planes themselves, or the bf16 copy of an f16f6 operand."""
+        """The operand view the backward GEMMs take: the planes themselves, or the bf16 copy of an f16x2 operand."""
         if self.fmt == "bf16":
             return self
         if self.bf is None:
-            raise ValueError("this f16f6 operand was produced without its bf16 plane (forward outside a training step)")
+            raise ValueError("this f16x2 operand was produced without its bf16 plane (forward outside a training step)")
         return Planes(self.bf, None, self.rows, self.cols)
 
 
@@ -440,28 +440,29 @@ def empty_planes(rows, cols, passes, device, ld=None, zero=False):
     return Planes(hi, lo, rows, cols)
 
 
-def empty_planes_f16f6(rows, cols, device, want_bf=False):
-    """Uninitialised f16f6 operand planes [rows, cols] (cols % 32 == 0)."""
-    if cols % 32:
-        raise ValueError("f16f6 operands come in whole 32-element MX blocks")
+def empty_planes_f16x2(rows, cols, device, want_bf=False):
+    """Uninitialised f16x2 operand planes [rows, cols] (cols % 8 == 0)."""
+    if cols % 8:
+        raise ValueError("f16x2 operands come in 16-byte pieces (cols % 8 == 0)")
     hi = torch.empty((rows, cols), dtype=torch.float16, device=device)
-    lo = torch.empty((rows, cols), dtype=torch.int16, device=device)
+    lo = torch.empty((rows, cols), dtype=torch.float16, device=device)
     bf = torch.empty((rows, cols), dtype=torch.bfloat16, device=device) if want_bf else None
-    return Planes(hi, lo, rows, cols, "f16f6", bf)
+    return Planes(hi, lo, rows, cols, "f16x2", bf)
 
 
-def f16f6_encode(x2d: torch.Tensor, want_bf=False) -> Planes:
-    """fp32 [rows, cols] -> f16f6 operand planes (egv_f16f6_encode)."""
+def f16x2_encode(x2d: torch.Tensor, role: int, want_bf=False) -> Planes:
+    """fp32 [rows, cols] -> f16x2 operand planes (egv_f16x2_encode); role 0 = first operand (activations), 1 = second (weights)."""
     _need_cuda(x2d)
     rows, cols = x2d.shape
-    pl = empty_planes_f16f6(rows, cols, x2d.device, want_bf)
-    check(_lib.lib().egv_f16f6_encode(_p(x2d), x2d.stride(0), rows, cols, _p(pl.hi), _p(pl.lo), _p(pl.bf), pl.ld, _stream(x2d)),
-          "egv_f16f6_encode")
+    pl = empty_planes_f16x2(rows, cols, x2d.device, want_bf)
+    check(_lib.lib().egv_f16x2_encode(_p(x2d), x2d.stride(0), rows, cols, _p(pl.hi), _p(pl.lo), _p(pl.bf), pl.ld, int(role),
+                                      _stream(x2d)), "egv_f16x2_encode")
     return pl
 
 
-def f16f6_encode_multi(jobs, prepare=False):
-    """One launch for many weights.  jobs: (x2d [rows, cols] fp32, h16 address, slots address, ldo).  prepare: as split_f32_multi."""
+def f16x2_encode_multi(jobs, prepare=False):
+    """One launch for many WEIGHTS (second-operand role).  jobs: (x2d [rows, cols] fp32, plane-1 address, plane-2 address, ldo).
+    prepare: as split_f32_multi."""
     n = len(jobs)
     if n == 0:
         return None
@@ -470,11 +471,11 @@ def f16f6_encode_multi(jobs, prepare=False):
         _need_cuda(j[0])
     args = (n, vp(*[j[0].data_ptr() for j in jobs]), i64(*[j[0].stride(0) for j in jobs]),
             i32(*[j[0].shape[0] for j in jobs]), i32(*[j[0].shape[1] for j in jobs]),
-            vp(*[j[1] for j in jobs]), vp(*[j[2] for j in jobs]), i64(*[j[3] for j in jobs]))
-    fn = _lib.lib().egv_f16f6_encode_multi
+            vp(*[j[1] for j in jobs]), vp(*[j[2] for j in jobs]), i64(*[j[3] for j in jobs]), 1)
+    fn = _lib.lib().egv_f16x2_encode_multi
 
     def run(stream):
-        check(fn(*args, stream), "egv_f16f6_encode_multi")
+        check(fn(*args, stream), "egv_f16x2_encode_multi")
     if prepare:
         return run
     run(_stream(jobs[0][0]))
@@ -533,10 +534,10 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     ec = DEFAULT if ec is None else ec
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
-    if (a.fmt == "f16f6") != (passes == 2) or a.fmt != b.fmt:
+    if (a.fmt == "f16x2") != (passes == 2) or a.fmt != b.fmt:
         raise ValueError(f"gemm_nt: operand formats {a.fmt} / {b.fmt} do not go with passes = {passes}")
     out_fmt = 0
-    if out_planes is not None and out_planes.fmt == "f16f6":
+    if out_planes is not None and out_planes.fmt == "f16x2":
         out_fmt = 1
     if ksplit is None:
         ksplit = 1 if passes == 2 else auto_ksplit_nt(M, N, K)
@@ -584,14 +585,14 @@ SMALL_SPLITK = int(os.environ.get("EGV_SMALL_SPLITK", "1"))   # 0: off (A/B diag
 
 
 def uses_big_gemm(M, N, K, passes=None):
-    """Mirror of the kernel choice in csrc/gemm_nt.hip (gemm_variant) for NT problems without split-K (f16f6 operands, passes = 2,
+    """Mirror of the kernel choice in csrc/gemm_nt.hip (gemm_variant) for NT problems without split-K (f16x2 operands, passes = 2,
     always take the big-tile kernel when it can run the shape at all)."""
     if passes == 2:
-        return f16f6_gemm_ok(M, N, K)
+        return f16x2_gemm_ok(M, N, K)
     return M >= 256 and N >= 256 and K % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
 
 
-def f16f6_gemm_ok(M, N, K):
+def f16x2_gemm_ok(M, N, K):
     """Can egv_gemm_nt(passes = 2) run this NT shape?  (one 256 x 256 tile at least, 64-deep k-tiles)"""
     return M >= 256 and N >= 256 and K % 64 == 0
 
@@ -720,7 +721,7 @@ def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, 
                   rows=None, ldx=None, want_bf=False):
     """rows of x2d (optionally x2d + x_add) -> (Planes | None, y_f32 | None, mean, rstd, sum | None).
     `rows`/`ldx` allow strided row selection (e.g. only the CLS row of every clip).
-    passes == 2: the output is written in the f16f6 operand format (`want_bf`: with the bf16 plane the backward reads)."""
+    passes == 2: the output is written in the f16x2 operand format, first-operand role (`want_bf`: with the bf16 plane the backward reads)."""
     _need_cuda(x2d, gamma, beta)
     cols = x2d.shape[-1]
     rows = x2d.shape[0] if rows is None else rows
@@ -728,12 +729,12 @@ def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, 
     dev = x2d.device
     if passes == 2:
         if x_add is not None or want_sum or want_f32 or not want_planes:
-            raise ValueError("layernorm_fwd: the f16f6 form writes operand planes only")
-        pl = empty_planes_f16f6(rows, cols, dev, want_bf)
+            raise ValueError("layernorm_fwd: the f16x2 form writes operand planes only")
+        pl = empty_planes_f16x2(rows, cols, dev, want_bf)
         mean = torch.empty(rows, dtype=torch.float32, device=dev)
         rstd = torch.empty(rows, dtype=torch.float32, device=dev)
-        check(_lib.lib().egv_layernorm_fwd_f16f6(_p(x2d), ldx, _p(gamma), _p(beta), float(eps), rows, cols, _p(pl.hi), _p(pl.lo),
-                                                 _p(pl.bf), pl.ld, _p(mean), _p(rstd), _stream(x2d)), "egv_layernorm_fwd_f16f6")
+        check(_lib.lib().egv_layernorm_fwd_f16x2(_p(x2d), ldx, _p(gamma), _p(beta), float(eps), rows, cols, _p(pl.hi), _p(pl.lo),
+                                                 _p(pl.bf), pl.ld, _p(mean), _p(rstd), _stream(x2d)), "egv_layernorm_fwd_f16x2")
         return pl, None, mean, rstd, None
     pl = empty_planes(rows, cols, passes, dev) if want_planes else None
     yf = torch.empty((rows, cols), dtype=torch.float32, device=dev) if want_f32 else None

@@ -22,12 +22,12 @@ def bump_epoch():
 
 
 class _Entry:
-    __slots__ = ("params", "ver", "pl", "p6", "tp", "ok_token", "ok_epoch", "ok_vers")
+    __slots__ = ("params", "ver", "pl", "p2", "tp", "ok_token", "ok_epoch", "ok_vers")
 
     def __init__(self, params):
-        # pl: split-bf16 planes W[N,K]; p6: the same weight in the f16f6 operand format (forward of the f16f6 mode); tp: split-bf16
+        # pl: split-bf16 planes W[N,K]; p2: the same weight in the f16x2 operand format, second-operand role (forward of the f16x2 mode); tp: split-bf16
         # W^T[K,N] (dgrad).  An entry owns whichever of the three its callers have asked for so far.
-        self.params, self.ver, self.pl, self.p6, self.tp = params, None, None, None, None
+        self.params, self.ver, self.pl, self.p2, self.tp = params, None, None, None, None
         self.ok_token, self.ok_epoch, self.ok_vers = -1, -1, None
 
     def mark_valid(self, token):
@@ -51,13 +51,13 @@ class _Entry:
     def shapes_ok(self):
         n = sum(p.shape[0] for p in self.params)
         k = self.params[0][0].numel() if self.params[0].dim() > 1 else 1
-        own = [x for x in (self.pl, self.p6) if x is not None]
+        own = [x for x in (self.pl, self.p2) if x is not None]
         if self.tp is not None and (self.tp.rows, self.tp.cols) != (k, n):
             return False
         return (bool(own) or self.tp is not None) and all((x.rows, x.cols) == (n, k) for x in own)
 
     def has(self, need_t, fmt):
-        return (self.p6 if fmt == "f16f6" else self.pl) is not None and (self.tp is not None or not need_t)
+        return (self.p2 if fmt == "f16x2" else self.pl) is not None and (self.tp is not None or not need_t)
 
 
 class WeightCache:
@@ -66,7 +66,7 @@ class WeightCache:
         self._c_bias = {}
         self._token = 0
         self.param_structs = {}  # (id of a layer's first weight, direction) -> (plane objects, small-parameter addresses, C struct): the block / layer calls
-        self._prep = None        # (signature of the stale set, replay of the split launch, replay of the f16f6 launch, a parameter)
+        self._prep = None        # (signature of the stale set, replay of the split launch, replay of the f16x2 launch, a parameter)
 
     # -- one launch for every stale entry that already owns its planes
     def _stale(self, mark=False):
@@ -90,9 +90,9 @@ class WeightCache:
         # tables of the two multi-tensor launches are built once and replayed (what changes is the stream)
         def at(pl):
             return 0 if pl is None else (pl.hi.data_ptr(), pl.lo.data_ptr() if pl.lo is not None else 0)
-        sig = tuple((at(ent.pl), at(ent.tp), at(ent.p6), tuple(v[2] for v in ver)) for ent, ver in stale)   # every address in the tables
+        sig = tuple((at(ent.pl), at(ent.tp), at(ent.p2), tuple(v[2] for v in ver)) for ent, ver in stale)   # every address in the tables
         if self._prep is None or self._prep[0] != sig:
-            jobs, jobs6 = [], []
+            jobs, jobs2 = [], []
             for ent, _ in stale:
                 off = 0
                 for i, p in enumerate(ent.params):
@@ -115,14 +115,14 @@ class WeightCache:
                             thi = tlo = None
                             ldt, tcols = 0, n_i
                         jobs.append((w2, hi, lo, ldo, thi, tlo, ldt, tcols))
-                    if ent.p6 is not None:
-                        jobs6.append((w2, ent.p6.hi.data_ptr() + off * ent.p6.ld * 2, ent.p6.lo.data_ptr() + off * ent.p6.ld * 2, ent.p6.ld))
+                    if ent.p2 is not None:
+                        jobs2.append((w2, ent.p2.hi.data_ptr() + off * ent.p2.ld * 2, ent.p2.lo.data_ptr() + off * ent.p2.ld * 2, ent.p2.ld))
                     off += n_i
-            self._prep = (sig, ops.split_f32_multi(jobs, prepare=True), ops.f16f6_encode_multi(jobs6, prepare=True),
+            self._prep = (sig, ops.split_f32_multi(jobs, prepare=True), ops.f16x2_encode_multi(jobs2, prepare=True),
                           stale[0][0].params[0])
-        _, run_split, run_f6, any_param = self._prep
+        _, run_split, run_x2, any_param = self._prep
         st = ops._stream(any_param)
-        for run in (run_split, run_f6):
+        for run in (run_split, run_x2):
             if run is not None:
                 run(st)
         for ent, ver in stale:
@@ -146,7 +146,7 @@ class WeightCache:
     def _get(self, params, need_t: bool, fmt: str = "bf16"):
         key = id(params[0]) if len(params) == 1 else tuple(id(p) for p in params)
         ent = self._c.get(key)
-        out = lambda: (ent.p6 if fmt == "f16f6" else ent.pl, ent.tp)
+        out = lambda: (ent.p2 if fmt == "f16x2" else ent.pl, ent.tp)
         if ent is None:
             ent = self._c[key] = _Entry(list(params))
         elif ent.has(need_t, fmt) and ent.still_valid(self._token):
@@ -161,7 +161,7 @@ class WeightCache:
         w2 = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], dim=0) if len(params) > 1 \
             else params[0].detach().reshape(params[0].shape[0], -1)
         if not ent.shapes_ok():
-            ent.pl = ent.p6 = ent.tp = None
+            ent.pl = ent.p2 = ent.tp = None
         want_pl = fmt == "bf16" or ent.pl is not None
         want_t = need_t or ent.tp is not None
         if want_pl or want_t:
@@ -169,14 +169,14 @@ class WeightCache:
             pl, tp, _ = ops.split_f32(w2, 3, want_rowmajor=want_pl, want_transposed=want_t)
             ent.pl = pl if want_pl else None
             ent.tp = tp
-        if fmt == "f16f6" or ent.p6 is not None:
-            ent.p6 = ops.f16f6_encode(w2.contiguous())
+        if fmt == "f16x2" or ent.p2 is not None:
+            ent.p2 = ops.f16x2_encode(w2.contiguous(), role=1)
         ent.ver = ent.version()
         return out()
 
     def get(self, param: torch.Tensor, need_t: bool, fmt: str = "bf16"):
         """-> (Planes [N,K], Planes [K,N] | None).  `param` is [N, ...] (conv weights are flattened to [N, K]).
-        fmt 'f16f6': the [N,K] planes in the f16f6 operand format (the transposed planes are split-bf16 either way)."""
+        fmt 'f16x2': the [N,K] planes in the f16x2 operand format (second-operand role) (the transposed planes are split-bf16 either way)."""
         return self._get((param,), need_t, fmt)
 
     def get_cat(self, params, need_t: bool, fmt: str = "bf16"):

@@ -34,9 +34,9 @@ enum { EGV_ACT_NONE = 0, EGV_ACT_GELU = 1, EGV_ACT_GELU_BWD = 2, EGV_ACT_RELU_BW
  * Replaces nn.Linear / Conv2d-as-GEMM forward, dgrad and wgrad: model/video_transformer.py:41-50
  * (Mlp fc1/fc2), :70,76 (patch-embed conv), :88-89,103,135 (qkv/proj); HF DistilBERT q/k/v/out_lin,
  * ffn.lin1/lin2; model/model.py:72-79 (projections).  passes = 1: bf16 operands (hi planes only);
- * passes = 3: split-bf16 operands, fp32-grade product; passes = 2: "f16f6" operands (see egv_f16f6_encode: a_hi / b_hi are
- * fp16 planes, a_lo / b_lo MXFP6 slot planes; big-tile NT kernel only, lda % 32 == ldb % 32 == 0) -- one fp16 and one
- * block-scaled MXFP6 MFMA product, ~2^-14 relative.  Requirements: K % 32 == 0, N % 4 == 0,
+ * passes = 3: split-bf16 operands, fp32-grade product (three bf16 MFMA products); passes = 2: "f16x2" operands (see
+ * egv_f16x2_encode: a_hi / a_lo = the two fp16 planes of a first-operand encoding, b_hi / b_lo of a second-operand encoding;
+ * big-tile NT kernel only, un-split) -- the same fp32-grade product from TWO fp16 MFMA products.  Requirements: K % 32 == 0, N % 4 == 0,
  * lda % 8 == ldb % 8 == 0, 16-byte aligned base pointers.
  *  act = EGV_ACT_GELU      : v = gelu(v); if aux_out != NULL the pre-activation is stored there first
  *  act = EGV_ACT_GELU_BWD  : v *= gelu'(aux_in[m,n])           (fc2 dgrad -> dZ)
@@ -72,8 +72,8 @@ typedef struct egv_gemm_desc {
                        callers pass e.g. 248 so that the RCCL kernels of the overlapped gradient all-reduce find free CUs.
                        Multiples of 8 in [8, 256]; anything else is an invalid argument.  (Per call, not per process: the
                        library keeps no state between calls.)                                                         */
-  int32_t out_fmt;  /* format of (out_hi, out_lo): 0 = split-bf16 planes; 1 = the f16f6 operand format below (out_hi = fp16 plane,
-                       out_lo = MXFP6 slot plane; EGV_ACT_GELU of a passes == 2 product only: fc1 -> fc2 of the forward).           */
+  int32_t out_fmt;  /* format of (out_hi, out_lo): 0 = split-bf16 planes; 1 = the f16x2 operand format below, first-operand role
+                       (two fp16 planes; EGV_ACT_GELU of a passes == 2 product only: fc1 -> fc2 of the forward).                   */
   egv_bf16* out_bf; /* out_fmt == 1, optional: bf16(value) as a third plane [M, ldoh] -- the single-pass operand the backward GEMMs
                        (wgrad) read, since an fp16 plane cannot share an MFMA with bf16 gradients.                               */
 } egv_gemm_desc;
@@ -96,26 +96,27 @@ int egv_split_f32_multi(int32_t count, const float* const* x, const int64_t* ldx
 int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, int32_t rows, int32_t cols,
                          egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream);
 
-/* ---- the f16f6 operand format (forward GEMMs of the video tower; csrc/f6.h) -------------------------------------------
- * x ~= h + l:  h = fp16(x) (saturating), and two MXFP6 (E2M3, one E8M0 scale per 32 consecutive k-elements) copies c6 = mx6(x),
- * l6 = mx6(x - h);   A . B^T ~= A_h B_h + c6(A) l6(B) + l6(A) c6(B)  -- an fp16 MFMA plus one v_mfma_scale_f32_16x16x128_f8f6f4
- * per 32 k-elements (2 issue units where split-bf16 spends 3), product error ~2^-14 (embeddings 1.3e-4 against the 1e-3 bar).
- * An operand [rows, cols] (cols % 32 == 0) is two planes of 2 bytes per element, leading dimension ld (elements, % 32 == 0):
- *   h16   fp16 [rows, ld];
- *   slots per row and 32-element block b, 64 bytes at byte offset (row * ld + 32 b) * 2, as four 16-byte chunks:
- *         [c6 code bytes 0-15][l6 code bytes 0-15][c6 code bytes 16-23, c6 scale byte, 7 B pad][l6 code bytes 16-23, l6 scale, pad];
- *         a plane's 24 code bytes hold element i of the block at bits 6i .. 6i+5;  value = code x 2^(scale - 127).
- * bf (optional): bf16(x) [rows, ld], the operand of single-pass backward GEMMs.  Replaces nothing in the reference (fp32 there);
- * producers: this converter (weights, tests), egv_layernorm_fwd_f16f6, the EGV_ACT_GELU epilogue with out_fmt = 1.            */
-int egv_f16f6_encode(const float* x, int64_t ldx, int32_t rows, int32_t cols, uint16_t* h16, uint16_t* slots, egv_bf16* bf,
-                     int64_t ldo, void* stream);
-/* `count` weights in one launch (HOST arrays of device pointers / sizes): the once-per-optimizer-step refresh.              */
-int egv_f16f6_encode_multi(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
-                           uint16_t* const* h16, uint16_t* const* slots, const int64_t* ldo, void* stream);
-/* nn.LayerNorm (model/video_transformer.py:146,156,159 -> the qkv / fc1 Linears) with the output written in the f16f6 format
- * (+ optional bf16 plane); cols % 32 == 0, cols <= 1024; mean / rstd [rows] saved for egv_layernorm_bwd.                      */
-int egv_layernorm_fwd_f16f6(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int32_t rows,
-                            int32_t cols, uint16_t* y16, uint16_t* yslots, egv_bf16* ybf, int64_t ldy, float* mean, float* rstd,
+/* ---- the f16x2 operand format (forward GEMMs of the video tower; csrc/f16x2.h) ----------------------------------------------
+ * A fp32-grade product from TWO fp16 MFMA products instead of three bf16 ones.  With e = 2^-6:
+ *   first operand  (activations):  a1 = fp16((1 - e) a),  a2 = fp16(a - a1)
+ *   second operand (weights):      b1 = fp16(b),          b2 = fp16(b1 + (b - b1) / e)
+ *   A . B^T ~= A1 B1^T + A2 B2^T :  a2 b2 = (e a - rho)(b1 + (b - b1) / e) returns the e a b1 that a1 left out, carries b's residual
+ * and cancels a1's rounding error rho; the roundings that are not compensated are attenuated by e or 2^-12 / e (~2^-17 per product:
+ * 5.3e-6 on random operands where split-bf16 x3 gives 4.4e-6; embeddings 3.2e-5 from the fp32 oracle where it gives 2.7e-5).
+ * An operand [rows, cols] (cols % 8 == 0) is two fp16 planes [rows, ld] (ld % 8 == 0) -- the geometry of split-bf16 planes.
+ * bf (optional): bf16(x) [rows, ld], the operand of single-pass backward GEMMs.  role: 0 = first operand, 1 = second operand.
+ * Replaces nothing in the reference (fp32 there); producers: this converter (weights, tests), egv_layernorm_fwd_f16x2, the
+ * EGV_ACT_GELU epilogue with out_fmt = 1.  Range: fp16 (saturating at 65504; below ~4e-3 a2 loses relative, not absolute, accuracy):
+ * forward operands only.                                                                                                          */
+int egv_f16x2_encode(const float* x, int64_t ldx, int32_t rows, int32_t cols, uint16_t* p1, uint16_t* p2, egv_bf16* bf,
+                     int64_t ldo, int32_t role, void* stream);
+/* `count` tensors in one launch (HOST arrays of device pointers / sizes): the once-per-optimizer-step refresh of the weights.     */
+int egv_f16x2_encode_multi(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
+                           uint16_t* const* p1, uint16_t* const* p2, const int64_t* ldo, int32_t role, void* stream);
+/* nn.LayerNorm (model/video_transformer.py:146,156,159 -> the qkv / fc1 Linears) with the output written in the f16x2 format,
+ * first-operand role (+ optional bf16 plane); cols % 8 == 0, cols <= 1024; mean / rstd [rows] saved for egv_layernorm_bwd.       */
+int egv_layernorm_fwd_f16x2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int32_t rows,
+                            int32_t cols, uint16_t* y1, uint16_t* y2, egv_bf16* ybf, int64_t ldy, float* mean, float* rstd,
                             void* stream);
 
 /* ---- one call per SpaceTimeBlock ----------------------------------------------------------------------------------

@@ -9,6 +9,7 @@ fp32 emulation of what the MFMA path would compute from ROUNDED operands:
   bf16x3    : A_hi B_hi + A_hi B_lo + A_lo B_hi           (three bf16 products; lo = bf16(x - hi))
   fp16      : fp16(A) fp16(B)
   fp16+F    : as bf16+F with hi = fp16(x) (11 significant bits; saturating) and the residual taken against it
+  fp16x2[:S]: A1 B1 + A2 B2, A1 = fp16((1 - e) A), A2 = fp16(A - A1), B1 = fp16(B), B2 = fp16(B1 + (B - B1) / e), e = 2^-S   (two fp16 products)
   fp16~F[:S]: fp16(A) fp16(B) + F(A 2^-S) F(B_lo 2^S) + F(A_lo 2^S) F(B 2^-S)   with F a PLAIN fp8 format (e5m2 / e4m3), fixed scales
   bf16+F    : A_hi B_hi + q_F(A) q_F(B_lo) + q_F(A_lo) q_F(B)   with F an MX element format (e4m3 / e5m2 / e2m3 / e3m2 / e2m1):
               q_F = OCP-MX block quantisation, one E8M0 scale per 32 consecutive k-elements -- the operand form of gfx950's
@@ -94,6 +95,25 @@ class Scheme:
         al, bl = a - ah, b - bh
         if n == "bf16x3":
             return mm(ah, bh) + (mm(ah, bf16_hi(bl)) + mm(bf16_hi(al), bh))
+        if n.startswith("bf16x2"):               # the same two-product construction on bf16 planes ("bf16x2:5": e = 2^-5)
+            _, _, sh = n.partition(":")
+            e = 2.0 ** -int(sh or 5)
+            a1 = bf16_hi((1.0 - e) * a)
+            a2 = bf16_hi(a - a1)
+            b1 = bf16_hi(b)
+            b2 = bf16_hi(b1 + (b - b1) / e)
+            return mm(a1, b1) + mm(a2, b2)
+        if n.startswith("fp16x2"):               # TWO fp16 products: A1 B1 + A2 B2 with A1 = fp16((1 - e) A), A2 = fp16(A - A1),
+            # B1 = fp16(B), B2 = fp16(B1 + (B - B1) / e), e = 2^-S ("fp16x2", "fp16x2:6"): the second product carries e A B1 (which A1
+            # left out) AND A (B - B1); every rounding is either compensated or attenuated by e -> ~2^-17 relative per product
+            _, _, sh = n.partition(":")
+            e = 2.0 ** -int(sh or 6)
+            h = lambda x: x.clamp(-65504.0, 65504.0).to(torch.float16).float()
+            a1 = h((1.0 - e) * a)
+            a2 = h(a - a1)
+            b1 = h(b)
+            b2 = h(b1 + (b - b1) / e)
+            return mm(a1, b1) + mm(a2, b2)
         if n.startswith("fp16~"):                # fp16 main product + two PLAIN (unscaled) fp8 correction products with fixed
             # power-of-two scales: c = F(x 2^-S), l = F((x - fp16(x)) 2^S), so that c(A) l(B) + l(A) c(B) needs no rescaling and
             # accumulates straight into the main product's accumulator ("fp16~e5m2", "fp16~e5m2:6": S = 6 by default)

@@ -1,0 +1,147 @@
+"""The f16x2 forward format on a real MI355X (`pytest -m gpu`), piece by piece through the C ABI: the encoders against the host
+restatement BIT FOR BIT (tests/f16x2_ref.py), the LayerNorm and GELU-epilogue producers against fp64 math, and the two-fp16-product
+GEMM of egv_gemm_nt(passes = 2) against (a) the exact product of the encoded operands and (b) the fp32 product it stands for -- next
+to the three-product split-bf16 GEMM on the same operands.  End-to-end parity of the mode (embeddings / loss vs the reference goldens
+and the oracle) is in tests/test_gpu_model.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import f16x2_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from egovlp_amd import ops as _ops
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return _ops
+
+
+def _inputs(rows, cols, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, cols, generator=g) * scale
+    x *= torch.logspace(-2, 1, rows).unsqueeze(1)[torch.randperm(rows, generator=g)]        # rows of very different magnitude
+    return x
+
+
+def _check_planes(pl, x, role):
+    """device planes == host encoding of x, bit for bit (both fp16 planes and the bf16 plane)."""
+    p1, p2, bf = R.encode(x, role)
+    for name, got, want in (("plane 1", pl.hi, p1), ("plane 2", pl.lo, p2)) + ((("bf16 plane", pl.bf, bf),) if pl.bf is not None else ()):
+        bad = (got.cpu().view(torch.int16) != want.view(torch.int16)).nonzero()
+        assert bad.numel() == 0, (name, role, bad[:4].tolist(), [float(x[tuple(i)]) for i in bad[:4]])
+
+
+@pytest.mark.parametrize("role", [0, 1])
+def test_encode_is_bit_exact(ops, role):
+    for rows, cols, seed in ((64, 256, 1), (333, 96, 2), (1000, 768, 3), (17, 8, 4)):
+        x = _inputs(rows, cols, seed)
+        if rows > 20:   # the corners: zeros, a saturating value, fp16 subnormals, ties
+            x[0] = 0.0
+            x[1, 5] = 1.0e5
+            x[2] = x[2] * 1e-7
+            x[3, :8] = torch.tensor([1.0, 1.0 + 2 ** -11, 1.0 + 2 ** -10, 0.5 + 2 ** -12, -1.0, 65504.0, -65520.0, 2 ** -14])
+        pl = ops.f16x2_encode(x.cuda(), role, want_bf=True)
+        torch.cuda.synchronize()
+        _check_planes(pl, x, role)
+
+
+def test_encode_multi_is_the_weight_encoding(ops):
+    xs = [_inputs(768, 768, 11, 0.05), _inputs(2304, 768, 12, 0.05), _inputs(96, 3072, 13, 0.02)]
+    pls = [ops.empty_planes_f16x2(x.shape[0], x.shape[1], "cuda") for x in xs]
+    dev = [x.cuda() for x in xs]
+    ops.f16x2_encode_multi([(d, p.hi.data_ptr(), p.lo.data_ptr(), p.ld) for d, p in zip(dev, pls)])
+    torch.cuda.synchronize()
+    for x, p in zip(xs, pls):
+        _check_planes(p, x, 1)
+
+
+@pytest.mark.parametrize("cols", [768, 1024, 64])
+def test_layernorm_writes_the_format(ops, cols):
+    rows = 777
+    g = torch.Generator().manual_seed(cols)
+    x = _inputs(rows, cols, 20 + cols)
+    gamma, beta = 1.0 + 0.1 * torch.randn(cols, generator=g), 0.05 * torch.randn(cols, generator=g)
+    pl, _, mean, rstd, _ = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-6, 2, want_bf=True)
+    ref = F.layer_norm(x.double(), (cols,), gamma.double(), beta.double(), 1e-6)
+    assert rel(mean, x.double().mean(1)) < 1e-5 and rel(rstd, 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-6)) < 1e-5
+    assert rel(pl.hi.cpu().double() + pl.lo.cpu().double(), ref) < 2e-5      # a1 + a2 = the value to ~2^-17
+    assert rel(pl.hi.cpu().double() / (1.0 - R.E), ref) < 4e-4 and rel(pl.bf.cpu(), ref) < 4e-3
+    # and the bytes are the encoding of what the kernel normalised: re-encode the fp32 LayerNorm of the same device
+    _, yf, _, _, _ = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-6, 1, want_f32=True, want_planes=False)
+    p1, _, _ = R.encode(yf.cpu(), 0)
+    same = (pl.hi.cpu().view(torch.int16) == p1.view(torch.int16)).float().mean()
+    assert float(same) > 0.99                                      # summation order of the statistics differs in the last ulp
+
+
+@pytest.mark.parametrize("M,N,K", [(4200, 2304, 768), (3140, 768, 3072), (785, 256, 64), (25120, 768, 128), (25120, 2304, 768)])
+def test_gemm_f16x2_linear(ops, M, N, K):
+    a, w = _inputs(M, K, 31), _inputs(N, K, 32, 0.03)
+    g = torch.Generator().manual_seed(33)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    pa, pw = ops.f16x2_encode(a.cuda(), 0), ops.f16x2_encode(w.cuda(), 1)
+    exact = R.product(pa.hi.cpu(), pa.lo.cpu(), pw.hi.cpu(), pw.lo.cpu())
+    true = a.double() @ w.double().t()
+    # bias + residual -> fp32 (proj / fc2 form)
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(pa, pw, passes=2, bias=bias.cuda(), residual=res.cuda(), out_f32=out)
+    got = out.cpu().double() - bias.double() - res.double()
+    # the three-product split-bf16 GEMM on the same operands
+    out3 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(ops.split_f32(a.cuda(), 3)[0], ops.split_f32(w.cuda(), 3)[0], passes=3, out_f32=out3)
+    r_exact, r_true, r3 = rel(got, exact), rel(got, true), rel(out3, true)
+    print("f16x2 gemm M=%d N=%d K=%d: vs exact product of the encoded operands %.2e, vs fp32 product %.2e (bf16x3: %.2e)" % (M, N, K, r_exact, r_true, r3))
+    assert r_exact < 4e-6 and r_true < 2e-5 and r_true < 4 * r3 + 5e-6
+    # bias -> split-bf16 planes (qkv form)
+    pl = ops.empty_planes(M, N, 3, "cuda")
+    ops.gemm_nt(pa, pw, passes=2, bias=bias.cuda(), out_planes=pl)
+    assert rel(pl.float().cpu().double() - bias.double(), exact) < 2e-5
+
+
+def test_gemm_f16x2_mlp_with_gelu_handover(ops):
+    """fc1 -> GELU -> fc2 as the f16x2 mode runs it: the activation leaves the fc1 epilogue in the operand format (+ bf16 plane,
+    + saved gelu' as bf16) and is consumed by fc2 directly."""
+    M, D, Hd = 3140, 768, 3072
+    x, w1, w2 = _inputs(M, D, 41), _inputs(Hd, D, 42, 0.03), _inputs(D, Hd, 43, 0.02)
+    g = torch.Generator().manual_seed(44)
+    b1, b2 = 0.1 * torch.randn(Hd, generator=g), 0.1 * torch.randn(D, generator=g)
+    px, pw1, pw2 = ops.f16x2_encode(x.cuda(), 0), ops.f16x2_encode(w1.cuda(), 1), ops.f16x2_encode(w2.cuda(), 1)
+    h = ops.empty_planes_f16x2(M, Hd, "cuda", want_bf=True)
+    z = torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(px, pw1, passes=2, bias=b1.cuda(), act=ops.ACT_GELU, aux_out=z, out_planes=h, aux_is_grad=True)
+    pre = x.double() @ w1.double().t() + b1.double()
+    act = F.gelu(pre)
+    r_h = rel(h.hi.cpu().double() + h.lo.cpu().double(), act)
+    cdf = 0.5 * (1.0 + torch.erf(pre / 2 ** 0.5))
+    dgelu = cdf + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5
+    print("f16x2 gelu hand-over: a1 + a2 vs gelu %.2e, bf %.2e, saved gelu' %.2e" % (r_h, rel(h.bf.cpu(), act), rel(z.cpu(), dgelu)))
+    assert r_h < 3e-5 and rel(h.bf.cpu(), act) < 4e-3 and rel(z.cpu(), dgelu) < 4e-3
+    # the planes are the first-operand encoding of the activation the kernel computed (up to its last-ulp differences from fp64)
+    p1, _, _ = R.encode(act.float(), 0)
+    assert float((h.hi.cpu().view(torch.int16) == p1.view(torch.int16)).float().mean()) > 0.95
+    out = torch.empty(M, D, device="cuda")
+    ops.gemm_nt(h, pw2, passes=2, bias=b2.cuda(), out_f32=out)
+    ref = act @ w2.double().t() + b2.double()
+    print("f16x2 mlp: vs fp64 %.2e" % rel(out, ref))
+    assert rel(out, ref) < 3e-5
+
+
+def test_gemm_f16x2_rejects_what_it_cannot_run(ops):
+    from egovlp_amd._lib import EgovlpHipError
+    a, w = ops.f16x2_encode(_inputs(512, 256, 51).cuda(), 0), ops.f16x2_encode(_inputs(512, 256, 52).cuda(), 1)
+    out = torch.empty(512, 512, device="cuda")
+    with pytest.raises(ValueError):
+        ops.gemm_nt(a, ops.split_f32(_inputs(512, 256, 53).cuda(), 3)[0], passes=2, out_f32=out)      # mixed operand formats
+    small = ops.f16x2_encode(_inputs(128, 256, 54).cuda(), 0)
+    with pytest.raises(EgovlpHipError):
+        ops.gemm_nt(small, w, passes=2, out_f32=torch.empty(128, 512, device="cuda"))                  # below one big tile
+    with pytest.raises(EgovlpHipError):
+        ops.gemm_nt(a, w, passes=2, out_f32=out, ksplit=2)                                             # no split-K form

@@ -254,3 +254,37 @@ def test_block_parameter_structs_follow_the_weight_planes(model):
         assert all(b.w_hi[i] == a.w_hi[i] for i in (0, 1, 2, 3, 5))
     other = _model()
     assert other.exec_ctx.wc.param_structs is not ec.wc.param_structs and not other.exec_ctx.wc.param_structs
+
+
+def test_f16x2_mode_wiring(model):
+    """Precision 'f16x2' (two-fp16-product forward of the video blocks' qkv / fc1 / fc2 Linears, single-pass bf16 backward) through the
+    host code: the block calls carry fwd_passes = 2, the weights of those Linears are refreshed with ONE f16x2 multi-encode per step
+    (second-operand role) next to the split-bf16 refresh of everything else, every parameter receives a gradient."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.optim import AdamW
+    from egovlp_amd.trainer.trainer_egoclip import egoclip_step
+    opt = AdamW(model.parameters(), lr=3e-5)
+    ec = model.exec_ctx
+    with mock_hip() as calls:
+        ec.set_precision("f16x2")
+        try:
+            assert ec.precision_name() == ("f16x2", "bf16") and ec.fwd_passes == 2 and ec.fwd_passes_split == 3
+            for p in model.parameters():
+                p.grad = None
+            egoclip_step(model, EgoNCE(), opt, _batch(B=8, T=4), 1, 0)
+            calls.clear()
+            for p in model.parameters():
+                p.grad = None
+            egoclip_step(model, EgoNCE(), opt, _batch(B=8, T=4), 1, 0)
+            c = collections.Counter(calls)
+            ok = all(p.grad is not None and p.grad.shape == p.shape for p in model.parameters())
+            ent = ec.wc._c[id(model.video_model.blocks[0].mlp.fc1.weight)]
+            ent_proj = ec.wc._c[id(model.video_model.blocks[0].attn.proj.weight)]
+        finally:
+            ec.unset("fwd_passes", "bwd_passes")
+    assert c["egv_block_fwd"] == 12 and c["egv_block_bwd"] == 12 and c["egv_f16x2_encode_multi"] == 1 and c["egv_split_f32_multi"] == 1
+    assert ok
+    assert ent.p2 is not None and ent.p2.fmt == "f16x2" and ent.tp is not None        # forward planes f16x2, dgrad planes split-bf16
+    assert ent_proj.pl is not None and ent_proj.p2 is None                            # the proj Linears stay split-bf16
+    with pytest.raises(ValueError):
+        ec.set_precision("f16x2", "bf16x3")

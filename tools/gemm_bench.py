@@ -19,8 +19,11 @@ D, H3, HD = 768, 2304, 3072
 dev = "cuda"
 
 
-def rnd(r, c, p):
-    return ops.split_f32(torch.rand(r, c, device=dev) * 2 - 1, p)[0]
+def rnd(r, c, p, role=0):
+    x = torch.rand(r, c, device=dev) * 2 - 1
+    if p == 2:               # f16x2 operands: role 0 = first operand (activations), 1 = second (weights)
+        return ops.f16x2_encode(x, role)
+    return ops.split_f32(x, p)[0]
 
 
 def cases(P, Pb):
@@ -28,7 +31,7 @@ def cases(P, Pb):
     out = []
 
     def nt(name, m, n, k, p, kw=None):
-        a, b = rnd(m, k, p), rnd(n, k, p)
+        a, b = rnd(m, k, p, 0), rnd(n, k, p, 1)
         bias = torch.zeros(n, device=dev)
         if EPI != "real":
             if EPI == "bf16":
@@ -47,14 +50,15 @@ def cases(P, Pb):
 
     res = torch.rand(M, D, device=dev)
     o32 = torch.empty(M, D, device=dev)
-    qkv_pl = ops.empty_planes(M, H3, P, dev)
-    h_pl = ops.empty_planes(M, HD, P, dev)
+    Pa = 3 if P == 2 else P          # the f16x2 mode (P = 2): qkv / fc1 / fc2 forward as two fp16 products, proj / text split-bf16 x3
+    qkv_pl = ops.empty_planes(M, H3, Pa, dev)
+    h_pl = ops.empty_planes_f16x2(M, HD, dev, want_bf=True) if P == 2 else ops.empty_planes(M, HD, P, dev)
     z = torch.empty(M, HD, device=dev, dtype=torch.bfloat16 if Pb == 1 else torch.float32)
     zin = (torch.rand(M, HD, device=dev) * 4 - 2).to(z.dtype)
     dz_pl = ops.empty_planes(M, HD, Pb, dev)
     dx_pl = ops.empty_planes(M, D, Pb, dev)
     nt("qkv   fwd", M, H3, D, P, kw=lambda bias: dict(bias=bias, out_planes=qkv_pl))
-    nt("proj  fwd", M, D, D, P, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
+    nt("proj  fwd", M, D, D, Pa, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
     nt("fc1   fwd", M, HD, D, P, kw=lambda bias: dict(bias=bias, act=ops.ACT_GELU, aux_out=z, out_planes=h_pl, aux_is_grad=Pb == 1))
     nt("fc2   fwd", M, D, HD, P, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
     nt("fc2 dgrad", M, HD, D, Pb, kw=lambda bias: dict(act=ops.ACT_GELU_BWD, aux_in=zin, out_planes=dz_pl, aux_is_grad=Pb == 1))
@@ -65,7 +69,7 @@ def cases(P, Pb):
     tn("proj wgrad", D, D, M, Pb)
     tn("fc1 wgrad", HD, D, M, Pb)
     tn("fc2 wgrad", D, HD, M, Pb)
-    nt("text  lin", 1024, D, D, P, kw=lambda bias: dict(bias=bias, out_f32=torch.empty(1024, D, device=dev)))
+    nt("text  lin", 1024, D, D, Pa, kw=lambda bias: dict(bias=bias, out_f32=torch.empty(1024, D, device=dev)))
     tn("text wgrad", D, D, 1024, Pb)
     return out
 
