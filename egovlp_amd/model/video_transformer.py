@@ -94,6 +94,15 @@ def _take_grad_planes(g_out, g2d, Pb):
     return ops.split_f32(g2d, Pb)[0]
 
 
+def f16x2_block_ok(M, D, Hd, train):
+    """Can a block of this size run its qkv / fc1 / fc2 Linears in the f16x2 format?  (the big-tile kernel for the three products, and
+    -- the fc1 epilogue of that format saves gelu' as bf16 -- for the single-pass fc2 dgrad that reads it back; smaller blocks run
+    split-bf16 x3)"""
+    if not (ops.f16x2_gemm_ok(M, 3 * D, D) and ops.f16x2_gemm_ok(M, Hd, D) and ops.f16x2_gemm_ok(M, D, Hd)):
+        return False
+    return not train or ops.uses_big_gemm(M, Hd, D, 1)
+
+
 class _SpaceTimeBlockFn(torch.autograd.Function):
     """SpaceTimeBlock.forward, model/video_transformer.py:163-177:
          t  = timeattn(norm3(x));  tr = x + t
@@ -119,7 +128,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         # 'f16x2': the LayerNorm -> qkv / fc1 and fc1 -> fc2 hand-overs are in the f16x2 operand format (two fp16 products instead of
         # three bf16 ones, big-tile kernel only); attention and the proj Linears keep split-bf16 three-product operands (Pa).  Token
         # counts too small for the big-tile kernel (toy geometries) run the block in bf16x3.
-        if P == 2 and not (ops.f16x2_gemm_ok(M, 3 * D, D) and ops.f16x2_gemm_ok(M, Hd, D) and ops.f16x2_gemm_ok(M, D, Hd)):
+        if P == 2 and not f16x2_block_ok(M, D, Hd, train):
             P = 3
         fx2 = P == 2
         Pa = 3 if fx2 else P
@@ -223,7 +232,7 @@ def block_calls_ok(ec: ExecContext, M, D, Hd):
     the block un-split and at least one 256-wide tile: the per-kernel path covers the toy shapes)"""
     if not ec.block_calls or ec.kernel_timer is not None or ec.bwd_passes > ec.fwd_passes:
         return False
-    if ec.fwd_passes == 2 and not (ops.f16x2_gemm_ok(M, 3 * D, D) and ops.f16x2_gemm_ok(M, Hd, D) and ops.f16x2_gemm_ok(M, D, Hd)):
+    if ec.fwd_passes == 2 and not f16x2_block_ok(M, D, Hd, True):
         return False
     if D < 256 or Hd < 256 or D % 64 or Hd % 64 or M < 256:
         return False
@@ -414,8 +423,10 @@ class _PatchTokensFn(torch.autograd.Function):
         Pb = ec.bwd_passes
         ec.poll_backward()              # every block's gradients are final here
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
-        _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False, params=(ctx.proj_w,), ec=ec)
         K = ctx.wshape[1] * ctx.wshape[2] * ctx.wshape[3]
+        # a zero-padded K (ViT-L/14: 588 -> 640) is cut off dW right here, on THIS stream: that wgrad must not run on a side stream
+        # (bench.py's grad_rel_err had this gradient 100 % off in config 5 with the wgrad side streams on, rounds 3 - 4)
+        _, d_w, d_b = _lin_bwd(d_pe, ctx.a, None, Pb, need_dx=False, params=(ctx.proj_w,), ec=ec, allow_side=(ctx.a.cols == K))
         if d_w.shape[1] != K:
             d_w = d_w[:, :K].contiguous()      # drop the zero-padded k columns
         return None, None, None, d_w.view(ctx.wshape), d_b, d_cls, d_pos, d_tmp

@@ -538,6 +538,40 @@ def test_weight_gradients_on_the_side_stream_are_the_same_gradients(full, which)
         m.eval()
 
 
+def test_padded_patch_embedding_gradient_with_the_wgrad_side_stream():
+    """ViT-L/14's patch embedding contracts over K = 3 x 14 x 14 = 588, zero-padded to 640 for the k-tile; the padding is cut off
+    the weight gradient by an ATen copy on the node's stream, so THAT wgrad must stay on it: with the wgrad side streams on (as
+    bench.py and the trainer run) the copy raced with the side-stream GEMM and the gradient came out 100 % wrong (bench.py's
+    grad_rel_err of config 5, rounds 3 - 4).  One ViT-L/14-shaped block, side stream off vs on."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.model.model import FrozenInTime
+    torch.manual_seed(0)
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "custom", "num_frames": 4, "pretrained": True,
+                                   "time_init": "rand", "arch_kwargs": dict(img_size=224, patch_size=14, embed_dim=1024, depth=1, num_heads=16)},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text",
+                                  "config": dict(vocab_size=30522, dim=768, n_layers=1, n_heads=12, hidden_dim=3072)},
+                     projection="minimal", load_checkpoint="").cuda().train()
+    m.text_model.set_dropout(0.0, 0.0)
+    m.exec_ctx.set_precision("bf16x3", "bf16")
+    batch = to_dev(synth_batch(4, T=4, L=16, seed=5))
+    w = m.video_model.patch_embed.proj.weight
+
+    def grad(side):
+        m.exec_ctx.set(wgrad_side_stream=side)
+        for p in m.parameters():
+            p.grad = None
+        te, ve = m(batch)
+        EgoNCE().fused(te, ve, batch["noun_vec"], batch["verb_vec"]).backward()
+        torch.cuda.synchronize()
+        return w.grad.clone()
+
+    ref = grad(False)
+    assert float(ref.abs().max()) > 0
+    for _ in range(3):
+        r = rel(grad(True), ref)
+        assert r < 1e-4, r
+
+
 def test_retrieval_heads_match_the_reference_golden(full, golden_dir):
     """§8(f4) consumers of the encoders: compute_text_tokens (NLQ / MQ feature dumps), forward(video_only=True) (OSCC / PNR
     heads, feature dumps) and the dual-softmax retrieval similarity of run/test_epic.py, against outputs of the reference."""
