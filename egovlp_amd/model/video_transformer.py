@@ -368,9 +368,12 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         grads = torch.empty(gtot, dtype=torch.float32, device=dev)
         d_x = torch.empty((M, D), dtype=torch.float32, device=dev)
         dx_pl = ops.empty_planes(M, D, Pb, dev)
-        for st in {s_ for s_ in streams if s_ is not None}:      # the side streams read / write these allocations of the main stream
-            for t in (ctx.arena, barena, grads) + ((g_pl.hi,) if g_hi is not None else ()):
+        used = {s_ for s_ in streams if s_ is not None}          # the side streams read / write these allocations of the main stream
+        for st in used:
+            for t in (grads,) + ((g_pl.hi,) if g_hi is not None else ()):
                 t.record_stream(st)
+        if used:
+            ec.hold_until_join(ctx.arena, barena)               # the multi-GB arenas: held until the join instead (see there)
         prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2)
         P6 = C.c_void_p * 6
         io = BlockBwdIO(G.data_ptr(), g_hi, g_lo, x2.data_ptr(), ctx.arena.data_ptr(), barena.data_ptr(),

@@ -14,7 +14,8 @@ opt = AdamW(model.parameters(), lr=3e-5)
 # the streams of the default bench.py run: text tower and weight gradients on side streams, main stream high priority
 model.exec_ctx.set(wgrad_side_stream=os.environ.get("EGV_HOST_SIDE", "1") == "1", text_side_stream=os.environ.get("EGV_HOST_SIDE", "1") == "1")
 torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
-b = synth_batch(32, T=4, L=32, seed=1234)
+HB, HT = int(os.environ.get("EGV_HOST_B", 32)), int(os.environ.get("EGV_HOST_T", 4))     # BASELINE config 4: 16 / 16
+b = synth_batch(HB, T=HT, L=32, seed=1234)
 data = {"video": b["video"].cuda(), "text": {k: v.cuda() for k, v in b["text"].items()}, "noun_vec": b["noun_vec"].cuda(), "verb_vec": b["verb_vec"].cuda()}
 for _ in range(3):
     egoclip_step(model, EgoNCE(), opt, data)
