@@ -162,3 +162,34 @@ def test_host_lead_is_bounded():
     ec.set(max_steps_in_flight=0)
     ec.begin_step()
     assert len(ec._inflight) == 2          # untouched
+
+
+def test_arenas_are_released_at_the_join_and_the_pool_stops_growing():
+    """With the weight gradients on side streams the block calls hold their arenas until the side streams are joined (end of backward)
+    instead of record_stream-ing them: nothing is held after a step, and the pool stops growing after the first steps."""
+    from egovlp_amd import ops
+    B, T, n, D = 8, 4, 196, 768
+    blks = [_block(D, seed=i) for i in range(3)]
+    ec = ops.new_context()
+    ec.set_precision("f16x2")
+    ec.set(wgrad_side_stream=True)
+    x = torch.randn(B, 1 + T * n, D, device="cuda")
+    reserved = []
+    for step in range(6):
+        for b in blks:
+            for p in b.parameters():
+                p.grad = None
+        ec.begin_step()
+        h = x.clone().requires_grad_(True)
+        y = h
+        for b in blks:
+            y = b(y, B, T, n, ec)
+        from egovlp_amd.model import video_transformer as vt
+        assert isinstance(y.grad_fn, vt._SpaceTimeBlockCFn._backward_cls)
+        y.backward(torch.ones_like(y) * 1e-3)
+        assert not ec._side["held"] and not ec._side["dirty"]            # the engine callback joined and released
+        reserved.append(torch.cuda.memory_reserved())
+    torch.cuda.synchronize()
+    # the arenas (1.1 GB each here) come back at every join; what may still trickle in during the first steps are the small
+    # record_stream-ed gradient buffers of a host that runs ahead (measured: + 0.37 GB once, at the third step)
+    assert reserved[-1] == reserved[-2] == reserved[-3] and reserved[-1] - reserved[0] < (1 << 30), reserved
