@@ -42,6 +42,8 @@
 //       one extra MFMA per A-fragment against an all-ones fragment.
 // bf16x3 (fp32-grade) products run as three k-segments over the split planes, (A_hi,B_lo), (A_lo,B_hi), (A_hi,B_hi),
 // into the same accumulators: one code path, the small terms first.
+// f16x2 (fp32-grade from TWO products, csrc/f16x2.h): the same planes-in-pairs stage layout with fp16 planes, passes (A_2,B_2),
+// (A_1,B_1) on the fp16 MFMA -- the forward of the video blocks' qkv / fc1 / fc2 Linears in the benchmarked mode.
 // The last tile row/column is shifted inwards (m0 = M - BM) instead of being predicated: the overlapping rows are
 // computed twice with bit-identical results, so the duplicate stores are benign and no lane ever needs a clamp.
 #include <cstdlib>
