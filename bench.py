@@ -494,6 +494,10 @@ def main():
         "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
                    "parallelism": f"dp{world}", "precision": "/".join(ec.precision_name()),
+                   "mfma_products": "forward: " + {"f16x2": "qkv / fc1 / fc2 of the video blocks 2 x fp16 MFMA (f16x2 operands), proj / attention / "
+                                                            "text tower / heads 3 x bf16 MFMA",
+                                                   "bf16x3": "3 x bf16 MFMA per product", "bf16": "1 x bf16 MFMA per product"}[ec.precision_name()[0]]
+                                    + "; backward: " + {"bf16x3": "3 x", "bf16": "1 x"}[ec.precision_name()[1]] + " bf16 MFMA per product; fp32 accumulation",
                    "text_dropout": args.text_dropout,
                    "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
                                # what differs between the N = 1 and the N > 1 step: one wgrad stream and a 248-workgroup
