@@ -46,7 +46,7 @@ TINY_TEXT = {"model": "distilbert-base-uncased", "pretrained": True, "input": "t
              "config": dict(vocab_size=30522, dim=128, n_layers=2, n_heads=2, hidden_dim=256)}
 
 
-def _worker(rank, world, port, out, exchange, tiny=False, B=2):
+def _worker(rank, world, port, out, exchange, tiny=False, B=2, precision=("bf16x3", "bf16"), T=2):
     for p in (HERE, os.path.dirname(HERE)):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -76,9 +76,9 @@ def _worker(rank, world, port, out, exchange, tiny=False, B=2):
                         **({"bucket_mb": 1.0} if tiny else {}))
     w0 = _digest(p for p in model.parameters())
     ec.set(backward_poll=sync.poll, gemm_grid=248)
-    ec.set_precision("bf16x3", "bf16")
+    ec.set_precision(*precision)
     opt = AdamW(model.parameters(), lr=3e-5)
-    b = synth_batch(B, T=2, L=16, seed=3, rank=rank, **({"res": 32} if tiny else {}))
+    b = synth_batch(B, T=T, L=16, seed=3, rank=rank, **({"res": 32} if tiny else {}))
     data = {"video": b["video"], "text": b["text"], "noun_vec": b["noun_vec"], "verb_vec": b["verb_vec"]}
     steps = []
     gathered = []
@@ -109,7 +109,8 @@ def _worker(rank, world, port, out, exchange, tiny=False, B=2):
                           "grads": _digest(p.grad for p in model.parameters()),
                           "first": float(next(model.parameters()).grad.reshape(-1)[0]),
                           "gemm_calls": calls.count("egv_gemm_nt"), "adamw": calls.count("egv_adamw_multi"),
-                          "text_layers": calls.count("egv_text_layer_bwd")})
+                          "text_layers": calls.count("egv_text_layer_bwd"), "blocks": calls.count("egv_block_bwd"),
+                          "x2_refresh": calls.count("egv_f16x2_encode_multi")})
     torch.save({"w0": w0, "steps": steps, "gathered": gathered, "slices": [int(x) for x in getattr(sync, "slice_elems", [])]},
                os.path.join(out, f"rank{rank}.pt"))
     dist.destroy_process_group()
@@ -157,3 +158,22 @@ def test_eight_rank_step_on_a_toy_model(tmp_path):
     for x in r:
         assert x["gathered"] and all(g[0][0] == world * B and g[1][0] == world * B and g[2][0] == world * B and g[3][0] == world * B
                                      for g in x["gathered"]), x["gathered"][:1]
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_step_in_the_benchmarked_mode(tmp_path):
+    """The data-parallel step as bench.py --gpus 2 runs it: precision f16x2 (two-fp16-product forward of the video blocks' Linears,
+    single-pass backward) at a token count where the 12 SpaceTimeBlocks and the 6 DistilBERT layers go through their one-call-per-
+    direction C entry points (B = 8, T = 4 per rank: M = 6 280), buckets leaving from the polls inside the block backward calls."""
+    world = 2
+    mp.spawn(_worker, args=(world, 29711, str(tmp_path), "direct", False, 8, ("f16x2",), 4), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"rank{i}.pt"), weights_only=False) for i in range(world)]
+    assert r[0]["w0"] == r[1]["w0"]
+    for step in range(2):
+        a, b = r[0]["steps"][step], r[1]["steps"][step]
+        assert a["grads"] == b["grads"] and a["buckets"] == b["buckets"] >= 5
+        for x in (a, b):
+            # the first step builds the f16x2 weight planes one by one at first use; from then on ONE multi-encode per step refreshes them
+            assert x["blocks"] == 12 and x["text_layers"] == 6 and x["x2_refresh"] == (1 if step else 0)
+            assert x["during"] >= x["buckets"] - 1, x
+            assert x["gemm_calls"] == 2 + 2 * 3            # patch embedding (forward + wgrad) and the two heads: everything else is inside the calls
