@@ -134,7 +134,7 @@ def trajectory_drift(model, loss_fn, make_opt, steps=20, B=8, T=4, L=32, modes=(
     from egovlp_amd.synth import synth_batch
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
     ec = model.exec_ctx
-    saved_prec = (ec._s.get("fwd_passes"), ec._s.get("bwd_passes"))
+    saved_prec = (ec._s.get("fwd_passes"), ec._s.get("bwd_passes"), ec._s.get("f16_single"))
     pd, pa = model.text_model.config.dropout, model.text_model.config.attention_dropout
     model.text_model.set_dropout(0.0, 0.0)
     was_training = model.training
@@ -160,7 +160,7 @@ def trajectory_drift(model, loss_fn, make_opt, steps=20, B=8, T=4, L=32, modes=(
         elif mode == "bf16x3":
             ec.set_precision("bf16x3", "bf16x3")
         else:
-            ec.set_precision(mode)            # "f16x2": two-fp16-product forward of the video blocks' Linears, bf16 backward
+            ec.set_precision(mode)            # "f16x2" / "f16mix": fp16-product forward of the video blocks' Linears, bf16 backward
         opt = make_opt(model.parameters())
         losses = [egoclip_step(model, loss_fn, opt, b) for b in batches]
         with torch.no_grad():
@@ -195,9 +195,11 @@ def trajectory_drift(model, loss_fn, make_opt, steps=20, B=8, T=4, L=32, modes=(
     model.load_state_dict(sd0)
     weights.bump_epoch()
     model.text_model.set_dropout(pd, pa)
-    ec.unset("fwd_passes", "bwd_passes")
+    ec.unset("fwd_passes", "bwd_passes", "f16_single")
     if saved_prec[0] is not None:
         ec.set(fwd_passes=saved_prec[0], bwd_passes=saved_prec[1])
+    if saved_prec[2] is not None:
+        ec.set(f16_single=saved_prec[2])
     model.train(was_training)
     return out
 
@@ -248,9 +250,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--arch", default="base_patch16_224")
-    ap.add_argument("--precision", default=os.environ.get("EGOVLP_PRECISION", "f16x2"),
-                    help="f16x2 (default: forward fp32-grade = embeddings and loss inside the 1e-3 parity bar -- the video blocks' qkv / fc1 / fc2 "
-                         "Linears as TWO fp16 products, everything else three bf16 products --, backward single-pass bf16) | "
+    ap.add_argument("--precision", default=os.environ.get("EGOVLP_PRECISION", "f16mix"),
+                    help="f16mix (default: embeddings and loss inside the 1e-3 parity bar with a margin of 2 -- the video blocks' qkv / fc1 / fc2 "
+                         "Linears as TWO fp16 products in the first quarter of the tower and ONE behind it, everything else three bf16 "
+                         "products --, backward single-pass bf16) | f16x2 (round 4: two fp16 products in every block, fp32-grade forward) | "
                          "mixed (the same with three bf16 products everywhere in the forward) | "
                          "bf16 (single pass everywhere, fast mode) | bf16x3 (fp32-grade everywhere)")
     ap.add_argument("--text-dropout", type=float, default=0.1, help="DistilBERT dropout / attention_dropout in the timed step "
@@ -446,7 +449,7 @@ def main():
         big = {k: v for k, v in g_all["shapes"].items() if k.startswith("gemm_big ")}
         g = {"shapes": big, "launches": sum(v["launches"] for v in big.values()), "seconds": sum(v["seconds"] for v in big.values()),
              "flops": sum(v["flops"] for v in big.values())}
-        g["issue_flops"] = sum(v["flops"] * (3 if k.endswith("x3") else 1) for k, v in big.items())
+        g["issue_flops"] = sum(v["flops"] * (3 if k.endswith("x3") else (2 if k.endswith("x2") else 1)) for k, v in big.items())
         ach = g["flops"] / g["seconds"] / 1e12
         shapes = sorted(g_all["shapes"].items(), key=lambda kv: -kv[1]["seconds"])
         table = [{"shape": k, "launches_per_step": v["launches"] // 2, "avg_us": round(v["seconds"] / v["launches"] * 1e6, 1),
@@ -490,11 +493,17 @@ def main():
                   f"clip-pairs/sec (whole node), {T}f/224^2 {args.arch} + 32-tok text, B={B}/GPU, train step (fwd+gather+EgoNCE+bwd+AdamW)",
         "value": round(pairs, 2), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
+        "dtype": {"f16mix": "fp16 (forward Linears of the video blocks) + bf16 (attention, proj, text tower, backward) MFMA operands, fp32 accumulate",
+                  "f16x2": "fp16 (forward Linears of the video blocks) + bf16 (attention, proj, text tower, backward) MFMA operands, fp32 accumulate"
+                  }.get(ec.precision_name()[0], "bf16"), "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
         "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
                    "parallelism": f"dp{world}", "precision": "/".join(ec.precision_name()),
-                   "mfma_products": "forward: " + {"f16x2": "qkv / fc1 / fc2 of the video blocks 2 x fp16 MFMA (f16x2 operands), proj / attention / "
+                   "mfma_products": "forward: " + {"f16mix": "qkv / fc1 / fc2 of the video blocks: 2 x fp16 MFMA (f16x2 operands) in blocks [0, k), 1 x fp16 MFMA "
+                                                             "in blocks [k, depth), k = " + json.dumps(ec.f16_single_policy(len(model.video_model.blocks)))
+                                                             + " (per-block precision policy, profiles/r05_precision_table.txt); proj / attention / text tower / "
+                                                             "heads 3 x bf16 MFMA",
+                                                   "f16x2": "qkv / fc1 / fc2 of the video blocks 2 x fp16 MFMA (f16x2 operands), proj / attention / "
                                                             "text tower / heads 3 x bf16 MFMA",
                                                    "bf16x3": "3 x bf16 MFMA per product", "bf16": "1 x bf16 MFMA per product"}[ec.precision_name()[0]]
                                     + "; backward: " + {"bf16x3": "3 x", "bf16": "1 x"}[ec.precision_name()[1]] + " bf16 MFMA per product; fp32 accumulation",
@@ -555,7 +564,7 @@ def main():
                        "note": "HIP events on the compute stream; grad_sync_exposed = wait for the bucket all-reduces that "
                                "backward did not hide + unpack; ms_per_step_rank_* are each rank's own untimed-barrier clock"}
     # ---- and over a TRAJECTORY: 20 optimisation steps at B = 8 in this mode vs the fp32-grade backward, same init, same batches
-    if args.precision in ("mixed", "f16x2") and not args.no_trajectory and world == 1 and (T, args.arch) == (4, "base_patch16_224"):
+    if args.precision in ("mixed", "f16x2", "f16mix") and not args.no_trajectory and world == 1 and (T, args.arch) == (4, "base_patch16_224"):
         out["trajectory"] = trajectory_drift(model, loss_fn, lambda ps: AdamW(ps, lr=3e-5), modes=("bf16x3", args.precision))
         opt = AdamW(model.parameters(), lr=3e-5)        # fresh optimizer state for the legs below (weights were restored)
     if args.precision != "bf16" and not args.no_fast_mode:

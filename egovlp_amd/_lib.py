@@ -47,7 +47,8 @@ class GemmDesc(C.Structure):
 class BlockGeom(C.Structure):
     """egv_block_geom."""
     _fields_ = [("B", i32), ("T", i32), ("n", i32), ("H", i32), ("D", i32), ("Hd", i32),
-                ("fwd_passes", i32), ("bwd_passes", i32), ("train", i32), ("z_bf16", i32), ("eps", f32), ("grid_cap", i32)]
+                ("fwd_passes", i32), ("bwd_passes", i32), ("train", i32), ("z_bf16", i32), ("eps", f32), ("grid_cap", i32),
+                ("f16_single", i32)]
 
 
 class BlockParams(C.Structure):

@@ -52,6 +52,7 @@ bool geom_ok(const egv_block_geom& g) {
   if (g.B <= 0 || g.T <= 0 || g.n <= 0 || g.H <= 0 || g.D != g.H * 64 || g.Hd <= 0 || g.D % 32 || g.Hd % 32) return false;
   if (g.fwd_passes < 1 || g.fwd_passes > 3 || (g.bwd_passes != 1 && g.bwd_passes != 3) || g.bwd_passes > g.fwd_passes) return false;
   if (g.fwd_passes == 2 && (g.bwd_passes != 1 || (g.train && !g.z_bf16))) return false;   // f16x2 forward: single-pass bf16 backward
+  if (g.f16_single < 0 || g.f16_single > 7 || (g.f16_single && g.fwd_passes != 2)) return false;
   return true;
 }
 
@@ -64,23 +65,25 @@ FwdLayout fwd_layout(const egv_block_geom& g) {
   auto plane = [&](int64_t cols) { return b.take(o.M * cols * 2); };
   auto plane_lo = [&](int64_t cols) { return lo ? b.take(o.M * cols * 2) : (int64_t)-1; };
   auto plane_bf = [&](int64_t cols) { return bf ? b.take(o.M * cols * 2) : (int64_t)-1; };
-  L.n3_hi = plane(o.D); L.n3_lo = plane_lo(o.D);
+  // f16x2 forward with single-product Linears (g.f16_single): their first operand is ONE plain fp16 plane
+  const bool q1 = (g.f16_single & 4) != 0;
+  L.n3_hi = plane(o.D); L.n3_lo = q1 ? (int64_t)-1 : plane_lo(o.D);
   L.mean3 = b.take(o.M * 4); L.rstd3 = b.take(o.M * 4);
   L.qkvt_hi = plane(3 * o.D); L.qkvt_lo = plane_lo(3 * o.D);
   L.at_hi = plane(o.D); L.at_lo = plane_lo(o.D);
   L.lse_t = b.take((int64_t)g.B * g.H * o.S * 4);
   L.work_t = b.take(egv_divided_attn_fwd_work_floats(g.B, g.T, g.n, g.H, 1) * 4);
   L.tr = b.take(o.M * o.D * 4);
-  L.n1_hi = plane(o.D); L.n1_lo = plane_lo(o.D);
+  L.n1_hi = plane(o.D); L.n1_lo = q1 ? (int64_t)-1 : plane_lo(o.D);
   L.mean1 = b.take(o.M * 4); L.rstd1 = b.take(o.M * 4);
   L.qkvs_hi = plane(3 * o.D); L.qkvs_lo = plane_lo(3 * o.D);
   L.as_hi = plane(o.D); L.as_lo = plane_lo(o.D);
   L.lse_s = b.take((int64_t)g.B * g.H * o.S * 4);
   L.work_s = b.take(egv_divided_attn_fwd_work_floats(g.B, g.T, g.n, g.H, 0) * 4);
   L.sr = b.take(o.M * o.D * 4);
-  L.n2_hi = plane(o.D); L.n2_lo = plane_lo(o.D);
+  L.n2_hi = plane(o.D); L.n2_lo = (g.f16_single & 1) ? (int64_t)-1 : plane_lo(o.D);
   L.mean2 = b.take(o.M * 4); L.rstd2 = b.take(o.M * 4);
-  L.h_hi = plane(o.Hd); L.h_lo = plane_lo(o.Hd);
+  L.h_hi = plane(o.Hd); L.h_lo = (g.f16_single & 2) ? (int64_t)-1 : plane_lo(o.Hd);
   L.z = g.train ? b.take(o.M * o.Hd * (g.z_bf16 ? 2 : 4)) : (int64_t)-1;
   L.n3_bf = plane_bf(o.D); L.n1_bf = plane_bf(o.D); L.n2_bf = plane_bf(o.D); L.h_bf = plane_bf(o.Hd);
   L.total = b.off;
@@ -204,6 +207,7 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   const int32_t M = (int32_t)o.M, D = (int32_t)o.D, Hd = (int32_t)o.Hd;
   for (int i = 0; i < 6; ++i)
     if (!p.w_hi[i] || (P != 1 && !p.w_lo[i])) return EGV_ERR_ARG;
+  const int P_fc1 = (g.f16_single & 1) ? 4 : P, P_fc2 = (g.f16_single & 2) ? 4 : P, P_qkv = (g.f16_single & 4) ? 4 : P;   // 4: ONE fp16 product
   char* A = (char*)arena;
   // LayerNorm -> operand planes of the qkv / fc1 Linears: split-bf16, or f16x2 (first-operand role, + the bf16 copy the backward reads)
   auto ln = [&](const float* in, const float* gw, const float* gb, egv_bf16* y_hi, egv_bf16* y_lo, int64_t bf_off, float* mean, float* rstd) -> int {
@@ -224,7 +228,7 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   // ---- temporal attention branch (:166-167)
   EGV_TRY(ln(x, p.n3w, p.n3b, n3_hi, n3_lo, L.n3_bf, at<float>(A, L.mean3), at<float>(A, L.rstd3)));
   {
-    egv_gemm_desc d = nt_desc(n3_hi, n3_lo, D, p.w_hi[0], p.w_lo[0], p.ldw[0], M, 3 * D, D, P, g.grid_cap);
+    egv_gemm_desc d = nt_desc(n3_hi, n3_lo, D, p.w_hi[0], p.w_lo[0], p.ldw[0], M, 3 * D, D, P_qkv, g.grid_cap);
     d.bias = p.bias[0]; d.out_hi = qt_hi; d.out_lo = qt_lo; d.ldoh = 3 * D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
@@ -237,7 +241,7 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   // ---- spatial attention branch (:168-171; the residual is the block INPUT x, :171)
   EGV_TRY(ln(tr, p.n1w, p.n1b, n1_hi, n1_lo, L.n1_bf, at<float>(A, L.mean1), at<float>(A, L.rstd1)));
   {
-    egv_gemm_desc d = nt_desc(n1_hi, n1_lo, D, p.w_hi[2], p.w_lo[2], p.ldw[2], M, 3 * D, D, P, g.grid_cap);
+    egv_gemm_desc d = nt_desc(n1_hi, n1_lo, D, p.w_hi[2], p.w_lo[2], p.ldw[2], M, 3 * D, D, P_qkv, g.grid_cap);
     d.bias = p.bias[2]; d.out_hi = qs_hi; d.out_lo = qs_lo; d.ldoh = 3 * D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
@@ -250,9 +254,10 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   // ---- MLP (:175, :46-52): exact-erf GELU in the fc1 epilogue
   EGV_TRY(ln(sr, p.n2w, p.n2b, n2_hi, n2_lo, L.n2_bf, at<float>(A, L.mean2), at<float>(A, L.rstd2)));
   {
-    egv_gemm_desc d = nt_desc(n2_hi, n2_lo, D, p.w_hi[4], p.w_lo[4], p.ldw[4], M, Hd, D, P, g.grid_cap);
+    egv_gemm_desc d = nt_desc(n2_hi, n2_lo, D, p.w_hi[4], p.w_lo[4], p.ldw[4], M, Hd, D, P_fc1, g.grid_cap);
     d.bias = p.bias[4]; d.act = EGV_ACT_GELU; d.out_hi = h_hi; d.out_lo = h_lo; d.ldoh = Hd;
-    if (P == 2) { d.out_fmt = 1; d.out_bf = at<egv_bf16>(A, L.h_bf); }     // h in the f16x2 format (+ bf16 copy when training)
+    // h as fp16 operand planes (+ bf16 copy when training): the f16x2 format, or one plain plane when fc2 runs a single product
+    if (P == 2) { d.out_fmt = P_fc2 == 4 ? 2 : 1; d.out_bf = at<egv_bf16>(A, L.h_bf); }
     if (g.train) {
       d.aux_out = at<float>(A, L.z); d.ldaux = Hd;
       d.aux_bf16 = g.z_bf16 ? 2 : 0;      // bf16: gelu'(z) itself (the backward is single-pass), else the fp32 pre-activation
@@ -260,7 +265,7 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   {
-    egv_gemm_desc d = nt_desc(h_hi, h_lo, Hd, p.w_hi[5], p.w_lo[5], p.ldw[5], M, D, Hd, P, g.grid_cap);
+    egv_gemm_desc d = nt_desc(h_hi, h_lo, Hd, p.w_hi[5], p.w_lo[5], p.ldw[5], M, D, Hd, P_fc2, g.grid_cap);
     d.bias = p.bias[5]; d.residual = sr; d.ldr = D; d.out_f32 = out; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }

@@ -55,6 +55,14 @@ __device__ __forceinline__ void f16x2_encode8(const float (&v)[8], u32x4_t& p1, 
     p2[e] = f16x2_pack(h2[2 * e], h2[2 * e + 1]);
   }
 }
+// eight consecutive values -> ONE 16-byte piece of plain fp16(value) (saturating): the operand of a single-fp16-product GEMM
+// (egv_gemm_nt passes == 4) -- the Linears whose share of the 1e-3 parity budget allows one product (the per-op table)
+__device__ __forceinline__ u32x4_t f16_piece8(const float (&v)[8]) {
+  u32x4_t p;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p[e] = f16x2_pack((_Float16)f16x2_clamp(v[2 * e]), (_Float16)f16x2_clamp(v[2 * e + 1]));
+  return p;
+}
 __device__ __forceinline__ u32x4_t bf16_piece8(const float (&v)[8]) {
   return (u32x4_t){f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]), f32x2_to_bf16x2(v[4], v[5]), f32x2_to_bf16x2(v[6], v[7])};
 }

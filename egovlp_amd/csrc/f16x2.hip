@@ -104,10 +104,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_f16x2_kernel(
         y[e] = (v[i][0][e] - mean) * rstd * g0[e] + b0[e];
         y[4 + e] = (v[i][1][e] - mean) * rstd * g1[e] + b1[e];
       }
-      u32x4_t o1, o2;
-      f16x2_encode8<0>(y, o1, o2);
-      egv_store<EGV_NT_LN>(y1 + (long)row * ldy + p * 8, o1);
-      egv_store<EGV_NT_LN>(y2 + (long)row * ldy + p * 8, o2);
+      if (y2) {
+        u32x4_t o1, o2;
+        f16x2_encode8<0>(y, o1, o2);
+        egv_store<EGV_NT_LN>(y1 + (long)row * ldy + p * 8, o1);
+        egv_store<EGV_NT_LN>(y2 + (long)row * ldy + p * 8, o2);
+      } else {                          // ONE plane of plain fp16: the consumer runs a single fp16 product
+        egv_store<EGV_NT_LN>(y1 + (long)row * ldy + p * 8, f16_piece8(y));
+      }
       if (ybf) egv_store<EGV_NT_LN>(ybf + (long)row * ldy + p * 8, bf16_piece8(y));
     }
   }
@@ -168,7 +172,7 @@ extern "C" int egv_f16x2_encode_multi(int32_t count, const float* const* x, cons
 extern "C" int egv_layernorm_fwd_f16x2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int32_t rows,
                                        int32_t cols, uint16_t* y1, uint16_t* y2, egv_bf16* ybf, int64_t ldy, float* mean,
                                        float* rstd, void* stream) {
-  if (!x || !gamma || !beta || !y1 || !y2 || rows <= 0 || cols <= 0 || cols % 8 != 0 || cols > 1024 || ldx % 4 != 0 || ldy % 8 != 0)
+  if (!x || !gamma || !beta || !y1 || rows <= 0 || cols <= 0 || cols % 8 != 0 || cols > 1024 || ldx % 4 != 0 || ldy % 8 != 0)
     return EGV_ERR_ARG;
   const dim3 grid((rows + 3) / 4), block(256);
   hipStream_t s = (hipStream_t)stream;

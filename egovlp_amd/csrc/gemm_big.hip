@@ -44,6 +44,8 @@
 // into the same accumulators: one code path, the small terms first.
 // f16x2 (fp32-grade from TWO products, csrc/f16x2.h): the same planes-in-pairs stage layout with fp16 planes, passes (A_2,B_2),
 // (A_1,B_1) on the fp16 MFMA -- the forward of the video blocks' qkv / fc1 / fc2 Linears in the benchmarked mode.
+// f16 (ONE fp16 product, passes == 4): the plain single-plane loop on the fp16 opcode, A = fp16(activation), B = fp16(weight) (plane
+// 1 of the weight's f16x2 encoding) -- the forward Linears whose share of the parity budget allows it (fc2; fc1 in the later blocks).
 // The last tile row/column is shifted inwards (m0 = M - BM) instead of being predicated: the overlapping rows are
 // computed twice with bit-identical results, so the duplicate stores are benign and no lane ever needs a clamp.
 #include <cstdlib>
@@ -66,8 +68,9 @@ enum { EPI_RAW = 0,      // store the accumulators (split-K partial slab, or pla
        EPI_GELU = 2,     // + bias, pre-activation -> aux_out, gelu -> fp32 and/or planes
        EPI_GELU_BWD = 3, // * gelu'(aux_in) -> fp32 and/or planes
        EPI_GENERIC = 4,  // everything at run time (alpha, ReLU', ...)
-       EPI_GELU_X2 = 5 };// EPI_GELU with the activation written in the f16x2 operand format (csrc/f16x2.h, first-operand role): two
-                         // fp16 planes [+ bf16 plane for the backward], the saved gelu' as bf16 -- fc1 forward of the f16x2 mode
+       EPI_GELU_X2 = 5 };// EPI_GELU with the activation written as fp16 operand planes -- out_fmt 1: the f16x2 format (csrc/f16x2.h,
+                         // first-operand role, two planes); out_fmt 2: ONE plane of plain fp16 (the consumer runs a single fp16 product)
+                         // -- [+ bf16 plane for the backward], the saved gelu' as bf16: fc1 forward of the f16x2 mode
 
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
 typedef __attribute__((ext_vector_type(8))) short s16x8v;
@@ -200,15 +203,18 @@ __device__ __forceinline__ void epilogue4(const egv_gemm_desc& p, f32x4_t v, int
 // and the short ones in its last: M = 25 120 x N = 2304 is 53 + 32 bands = 765 tiles = 5 + 5 + 4 units per workgroup where 79
 // bands of 320 rows are 711 tiles = 3 rounds of 5 (-6.7 %); N = 3072: 5 + 5 + 5 + 4 instead of 4 x 5 (-5 %).
 // PROD: 0 = one product per k-tile from single planes (plain loops), 3 = fused bf16x3 (A_hi B_lo + A_lo B_hi + A_hi B_hi on the bf16
-// MFMA), 2 = f16x2 (A_1 B_1 + A_2 B_2 on the fp16 MFMA, csrc/f16x2.h): the same loop with one pass less and the other opcode.
+// MFMA), 2 = f16x2 (A_1 B_1 + A_2 B_2 on the fp16 MFMA, csrc/f16x2.h): the same loop with one pass less and the other opcode;
+// 1 = the plain NT loop on the fp16 opcode (single fp16 planes).
 template <int MF, bool TN, int EPI, int PROD, bool MIXED = false>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p, const int dbg_arg, const int nb5_arg) {
   constexpr bool X2 = PROD == 2;
-  constexpr bool F3 = PROD != 0;      // the fused stage layout ([A_hi | A_lo | B_hi | B_lo] x 64 B, 32-deep k-tiles)
+  constexpr bool H1 = PROD == 1;      // plain loop, fp16 opcode
+  constexpr bool F3 = PROD >= 2;      // the fused stage layout ([A_hi | A_lo | B_hi | B_lo] x 64 B, 32-deep k-tiles)
   constexpr bool IS_GELU = EPI == EPI_GELU || EPI == EPI_GELU_X2;
-  static_assert(PROD == 0 || PROD == 2 || PROD == 3, "");
+  static_assert(PROD >= 0 && PROD <= 3, "");
+  static_assert(!TN || PROD == 0, "weight gradients are single bf16 products");
   static_assert(!MIXED || (F3 && MF == 5 && !TN), "mixed row bands: the fused NT instances with 320-row tiles");
-  static_assert(EPI != EPI_GELU_X2 || X2, "f16x2 outputs are produced by the f16x2 instances only");
+  static_assert(EPI != EPI_GELU_X2 || X2 || H1, "fp16 operand outputs are produced by the fp16 instances only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef EGV_DIAG
   const int dbg = dbg_arg;      // `make diag` build only (tools/gemm_trace.py, tools/gemm_bench.py with EGV_GEMM_DBG)
@@ -663,6 +669,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       //   phase 5: B(7)                phase 6: -               (B two phases ahead, A(k-step 1) four)
       // The DMA of k-tile t+1 (into the stage freed by the barrier that ended t-1) is issued by waves 0-3 over phases
       // 0-3, a few pieces each: a burst of all NP blocks the issuing wave ~1300 cycles on the 64 B/clk L1->LDS path.
+      auto mma1 = [&](const bf16x8_t& b, const bf16x8_t& a, f32x4_t c) -> f32x4_t {
+        if constexpr (H1) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+      };
       auto k_tile = [&](const int t) {
         const bool HN = t + 1 < nt;            // wave-uniform: scalar branches around the DMA issue and the hand-over
         const int sb = (t & 1) * STAGE;
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           tie(Bq[PH % 3][1]);
           if constexpr (c == 0) static_for<0, MF>([&](auto Ic) { tie(A[ks][decltype(Ic)::value]); });
           __builtin_amdgcn_sched_barrier(0);
-          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[PH % 3][0], A[ks][0], acc[0][c * NC], 0, 0, 0);
+          acc[0][c * NC] = mma1(Bq[PH % 3][0], A[ks][0], acc[0][c * NC]);
           if (PH == 2 * NCH - 1 && HN) {
             __builtin_amdgcn_sched_barrier(0);
             // k-tile t+1 (this wave's DMA pieces) landed; every read of stage t&1 by this wave has returned (lgkmcnt(0) above)
@@ -726,9 +736,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           for (int jj = 0; jj < NC; ++jj)
 #pragma unroll
             for (int i = 0; i < MF; ++i)
-              if (jj + i > 0)
-                acc[i][c * NC + jj] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[PH % 3][jj], A[ks][i], acc[i][c * NC + jj], 0, 0, 0);
+              if (jj + i > 0) acc[i][c * NC + jj] = mma1(Bq[PH % 3][jj], A[ks][i], acc[i][c * NC + jj]);
           __builtin_amdgcn_sched_barrier(0);
         });
       };
@@ -1082,10 +1090,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           if constexpr (EPI == EPI_GELU_X2) {
             // the activation in the f16x2 operand format (first-operand role): two fp16 planes [+ the bf16 copy]
             const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            u32x4_t o1, o2;
-            f16x2_encode8<0>(vv, o1, o2);
-            egv_store16<PSITE>(dh, o1);
-            egv_store16<PSITE>(dh + dlo, o2);
+            if (p.out_fmt == 2) {       // ONE plane of plain fp16: the consumer runs a single fp16 product
+              egv_store16<PSITE>(dh, f16_piece8(vv));
+            } else {
+              u32x4_t o1, o2;
+              f16x2_encode8<0>(vv, o1, o2);
+              egv_store16<PSITE>(dh, o1);
+              egv_store16<PSITE>(dh + dlo, o2);
+            }
             if (dbf) egv_store16<PSITE>(dh + dbf, bf16_piece8(vv));
           } else {
             uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
@@ -1220,47 +1232,54 @@ int pick_mixed_bands(const egv_gemm_desc& p, int grid) {
 
 template <int MF, bool TN, int PROD = 0>
 int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
-  if (p.ksplit > 1 || TN) {
-    if (PROD == 2 || p.out_fmt != 0) return EGV_ERR_ARG;            // f16x2: forward products only (un-split, NT)
-    return launch_big<MF, TN, EPI_RAW, PROD>(p, s);                 // split-K slab / wgrad: plain fp32 output
-  }
-  if constexpr (PROD == 2) {
-    // f16x2 output (fc1 -> fc2 of the forward): GELU epilogue only, planes only
-    if (p.out_fmt == 1 && (p.act != EGV_ACT_GELU || p.alpha != 1.0f || !p.out_hi || !p.out_lo || p.residual || p.out_f32 ||
-                           (p.aux_out && !p.aux_bf16) || p.ldoh % 8 != 0))
+  // fp16 operand outputs (fc1 -> fc2 of the forward): GELU epilogue of an fp16 product only, planes only; 1 = f16x2 (two planes), 2 = one plain plane
+  if (p.out_fmt != 0) {
+    if (!(PROD == 1 || PROD == 2) || (p.out_fmt != 1 && p.out_fmt != 2)) return EGV_ERR_ARG;
+    if (p.act != EGV_ACT_GELU || p.alpha != 1.0f || !p.out_hi || (p.out_fmt == 1 && !p.out_lo) || p.residual || p.out_f32 ||
+        (p.aux_out && !p.aux_bf16) || p.ldoh % 8 != 0 || p.ksplit > 1 || TN)
       return EGV_ERR_ARG;
-  } else {
-    if (p.out_fmt != 0) return EGV_ERR_ARG;
   }
-  if constexpr (PROD != 0 && MF == 5 && !TN) {
-    // the two multi-round forward shapes of the step (qkv: plane outputs; fc1: GELU + planes + saved gelu') with mixed row bands
-    const int cap = p.grid_cap > 0 ? p.grid_cap : 256;
-    const int nb5 = pick_mixed_bands(p, cap);
-    if (nb5 >= 0 && p.alpha == 1.0f) {
-      if (p.act == EGV_ACT_NONE && (p.bias || p.residual || p.out_hi)) return launch_big<5, false, EPI_LINEAR, PROD, true>(p, s, nb5);
-      if (p.act == EGV_ACT_GELU) {
-        if constexpr (PROD == 2) {
-          if (p.out_fmt == 1) return launch_big<5, false, EPI_GELU_X2, 2, true>(p, s, nb5);
+  if constexpr (PROD == 1) {
+    // ONE fp16 product: the two forward epilogues of the step that use it (fc2: bias + residual -> fp32; fc1: GELU -> fp16 operand planes)
+    if (p.ksplit > 1 || TN || p.alpha != 1.0f) return EGV_ERR_ARG;
+    if (p.act == EGV_ACT_NONE) return launch_big<MF, false, EPI_LINEAR, 1>(p, s);
+    if (p.act == EGV_ACT_GELU && p.out_fmt != 0) return launch_big<MF, false, EPI_GELU_X2, 1>(p, s);
+    return EGV_ERR_ARG;
+  } else {
+    if (p.ksplit > 1 || TN) {
+      if (PROD == 2) return EGV_ERR_ARG;                              // f16x2: forward products only (un-split, NT)
+      return launch_big<MF, TN, EPI_RAW, PROD>(p, s);                 // split-K slab / wgrad: plain fp32 output
+    }
+    if constexpr (PROD != 0 && MF == 5 && !TN) {
+      // the two multi-round forward shapes of the step (qkv: plane outputs; fc1: GELU + planes + saved gelu') with mixed row bands
+      const int cap = p.grid_cap > 0 ? p.grid_cap : 256;
+      const int nb5 = pick_mixed_bands(p, cap);
+      if (nb5 >= 0 && p.alpha == 1.0f) {
+        if (p.act == EGV_ACT_NONE && (p.bias || p.residual || p.out_hi)) return launch_big<5, false, EPI_LINEAR, PROD, true>(p, s, nb5);
+        if (p.act == EGV_ACT_GELU) {
+          if constexpr (PROD == 2) {
+            if (p.out_fmt != 0) return launch_big<5, false, EPI_GELU_X2, 2, true>(p, s, nb5);
+          }
+          return launch_big<5, false, EPI_GELU, PROD, true>(p, s, nb5);
         }
-        return launch_big<5, false, EPI_GELU, PROD, true>(p, s, nb5);
       }
     }
-  }
-  if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
-    if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, PROD>(p, s);
-    return launch_big<MF, false, EPI_LINEAR, PROD>(p, s);
-  }
-  if (p.alpha == 1.0f && p.act == EGV_ACT_GELU) {
-    if constexpr (PROD == 2) {
-      if (p.out_fmt == 1) return launch_big<MF, false, EPI_GELU_X2, 2>(p, s);
+    if (p.alpha == 1.0f && p.act == EGV_ACT_NONE) {
+      if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, PROD>(p, s);
+      return launch_big<MF, false, EPI_LINEAR, PROD>(p, s);
     }
-    return launch_big<MF, false, EPI_GELU, PROD>(p, s);
-  }
-  if constexpr (PROD == 2) {
-    return EGV_ERR_ARG;                                             // the forward of the step uses nothing else
-  } else {
-    if (p.alpha == 1.0f && p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD, PROD>(p, s);
-    return launch_big<MF, false, EPI_GENERIC, PROD>(p, s);
+    if (p.alpha == 1.0f && p.act == EGV_ACT_GELU) {
+      if constexpr (PROD == 2) {
+        if (p.out_fmt != 0) return launch_big<MF, false, EPI_GELU_X2, 2>(p, s);
+      }
+      return launch_big<MF, false, EPI_GELU, PROD>(p, s);
+    }
+    if constexpr (PROD == 2) {
+      return EGV_ERR_ARG;                                             // the forward of the step uses nothing else
+    } else {
+      if (p.alpha == 1.0f && p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD, PROD>(p, s);
+      return launch_big<MF, false, EPI_GENERIC, PROD>(p, s);
+    }
   }
 }
 
@@ -1307,6 +1326,7 @@ int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant) {
   f3 = f3 && f3_env != 0;
 #endif
   if (p.passes == 2) return mf == 5 ? launch_epi<5, false, 2>(p, s) : launch_epi<4, false, 2>(p, s);      // f16x2
+  if (p.passes == 4) return mf == 5 ? launch_epi<5, false, 1>(p, s) : launch_epi<4, false, 1>(p, s);      // one fp16 product
   if (f3) return mf == 5 ? launch_epi<5, false, 3>(p, s) : launch_epi<4, false, 3>(p, s);
   if (mf == 5) return launch_epi<5, false>(p, s);
   return launch_epi<4, false>(p, s);

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue_kernel(const egv_g
 static int gemm_variant(const egv_gemm_desc& p) {
   const bool big_ok = egv_gemm_big_supports(p);
   if (p.trans) return big_ok ? 3 : -1;
-  if (p.passes == 2) return big_ok ? 3 : -1;   // f16x2 operands: the big-tile kernel is the only one that multiplies them
+  if (p.passes == 2 || p.passes == 4) return big_ok ? 3 : -1;   // fp16 operands (f16x2 / one plain plane): the big-tile kernel is the only one that multiplies them
   // big tiles only when there are enough of them to occupy the chip (DistilBERT's M = 1024 GEMMs make 12)
   const long big_tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
   if (big_ok && big_tiles >= 128) return 3;
@@ -250,9 +250,9 @@ static int gemm_variant(const egv_gemm_desc& p) {
 extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const egv_gemm_desc& p = *d;
   if (!p.a_hi || !p.b_hi) return EGV_ERR_ARG;
-  if (p.passes != 1 && p.passes != 2 && p.passes != 3) return EGV_ERR_ARG;
-  if (p.passes >= 2 && (!p.a_lo || !p.b_lo)) return EGV_ERR_ARG;
-  if (p.out_fmt != 0 && p.out_fmt != 1) return EGV_ERR_ARG;
+  if (p.passes < 1 || p.passes > 4) return EGV_ERR_ARG;
+  if ((p.passes == 2 || p.passes == 3) && (!p.a_lo || !p.b_lo)) return EGV_ERR_ARG;
+  if (p.out_fmt < 0 || p.out_fmt > 2) return EGV_ERR_ARG;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EGV_ERR_ARG;
   if (p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return EGV_ERR_ARG;
   if (!p.trans && p.K % BK != 0) return EGV_ERR_ARG;
@@ -262,8 +262,9 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   const int variant = gemm_variant(p);
   if (variant < 0) return EGV_ERR_ARG;
   if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // bf16 aux: gemm_big GELU epilogues only
-  // f16x2 operands / outputs (csrc/f16x2.h): the big-tile NT kernel only, un-split
-  if ((p.passes == 2 || p.out_fmt != 0) && (variant < 3 || p.trans || p.passes != 2 || p.ksplit > 1)) return EGV_ERR_ARG;
+  // fp16 operands / outputs (csrc/f16x2.h; passes 2 = f16x2, 4 = one plain fp16 plane): the big-tile NT kernel only, un-split
+  if ((p.passes == 2 || p.passes == 4 || p.out_fmt != 0) && (variant < 3 || p.trans || (p.passes != 2 && p.passes != 4) || p.ksplit > 1))
+    return EGV_ERR_ARG;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);

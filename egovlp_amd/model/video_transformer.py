@@ -115,7 +115,8 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
                 n3w, n3b, tqkv_w, tqkv_b, tproj_w, tproj_b,
                 n1w, n1b, sqkv_w, sqkv_b, sproj_w, sproj_b,
                 n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
-        B, T, n, H, eps = geom
+        B, T, n, H, eps = geom[:5]
+        single = geom[5] if len(geom) > 5 else 0     # ops.F16_SINGLE_BITS: Linears of THIS block that run ONE fp16 product (f16x2 mode)
         S = 1 + T * n
         D = x.shape[-1]
         M = B * S
@@ -133,36 +134,40 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         fx2 = P == 2
         Pa = 3 if fx2 else P
         wf = "f16x2" if fx2 else "bf16"
+        if not fx2:
+            single = 0
+        s_fc1, s_fc2, s_qkv = bool(single & 1), bool(single & 2), bool(single & 4)
+        P_qkv, P_fc1, P_fc2 = (4 if s_qkv else P), (4 if s_fc1 else P), (4 if s_fc2 else P)
 
         def W(p, fmt="bf16"):
             return wc.get(p, need_t=False, fmt=fmt)[0]
 
         # ---- temporal attention branch (:166-167)
-        n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P, want_bf=train)
+        n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P, want_bf=train, single=s_qkv)
         qkv_t = ops.empty_planes(M, 3 * D, Pa, dev)      # qkv never exists in fp32: the attention kernels read planes
-        ops.gemm_nt(n3, W(tqkv_w, wf), passes=P, bias=tqkv_b, out_planes=qkv_t, ec=ec)
+        ops.gemm_nt(n3, W(tqkv_w, wf), passes=P_qkv, bias=tqkv_b, out_planes=qkv_t, ec=ec)
         a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, Pa)
         tr = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(a_t, W(tproj_w), passes=Pa, bias=tproj_b, residual=x2, out_f32=tr, ec=ec)
         # ---- spatial attention branch (:168-171)
-        n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P, want_bf=train)
+        n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P, want_bf=train, single=s_qkv)
         qkv_s = ops.empty_planes(M, 3 * D, Pa, dev)
-        ops.gemm_nt(n1, W(sqkv_w, wf), passes=P, bias=sqkv_b, out_planes=qkv_s, ec=ec)
+        ops.gemm_nt(n1, W(sqkv_w, wf), passes=P_qkv, bias=sqkv_b, out_planes=qkv_s, ec=ec)
         a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, Pa)
         sr = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(a_s, W(sproj_w), passes=Pa, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
         # ---- MLP (:175, Mlp.forward :46-52), exact-erf GELU fused into the fc1 epilogue
-        n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P, want_bf=train)
-        h = ops.empty_planes_f16x2(M, Hd, dev, want_bf=train) if fx2 else ops.empty_planes(M, Hd, P, dev)
+        n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P, want_bf=train, single=s_fc1)
+        h = ops.empty_planes_f16x2(M, Hd, dev, want_bf=train, single=s_fc2) if fx2 else ops.empty_planes(M, Hd, P, dev)
         # saved for backward: the fp32 pre-activation z in the all-bf16x3 parity mode; when backward runs single-pass bf16
         # anyway, gelu'(z) itself as bf16 -- the epilogue has Phi(z) and phi(z) in registers, the buffer is half the bytes,
         # and the fc2-dgrad epilogue becomes one multiply instead of a second erf evaluation over 77 M elements
         z_dtype = torch.bfloat16 if (ec.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D, P)) else torch.float32
         z = torch.empty((M, Hd), dtype=z_dtype, device=dev) if train else None
-        ops.gemm_nt(n2, W(fc1_w, wf), passes=P, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
+        ops.gemm_nt(n2, W(fc1_w, wf), passes=P_fc1, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
                     aux_is_grad=z is not None and z_dtype == torch.bfloat16, ec=ec)
         out = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(h, W(fc2_w, wf), passes=P, bias=fc2_b, residual=sr, out_f32=out, ec=ec)
+        ops.gemm_nt(h, W(fc2_w, wf), passes=P_fc2, bias=fc2_b, residual=sr, out_f32=out, ec=ec)
 
         if train:
             ctx.geom, ctx.ec, ctx.P = geom, ec, P
@@ -176,7 +181,7 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         (x2, mean3, rstd3, lse_t, tr, mean1, rstd1, lse_s, sr, mean2, rstd2, z,
          n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w) = ctx.saved_tensors
         n3, a_t, n1, a_s, n2, h, qkv_t, qkv_s = ctx.planes
-        B, T, n, H, eps = ctx.geom
+        B, T, n, H, eps = ctx.geom[:5]
         ec = ctx.ec
         wc = ec.wc
         Pb = ec.bwd_passes
@@ -239,9 +244,9 @@ def block_calls_ok(ec: ExecContext, M, D, Hd):
     return all(ops.auto_ksplit_nt(*sh) == 1 for sh in ((M, 3 * D, D), (M, D, D), (M, Hd, D), (M, D, Hd), (M, D, 3 * D)))
 
 
-def _block_geom(B, T, n, H, D, Hd, P, Pb, train, z_bf16, eps, grid):
+def _block_geom(B, T, n, H, D, Hd, P, Pb, train, z_bf16, single, eps, grid):
     from .._lib import BlockGeom
-    return BlockGeom(B, T, n, H, D, Hd, P, Pb, int(train), int(z_bf16), float(eps), int(grid))
+    return BlockGeom(B, T, n, H, D, Hd, P, Pb, int(train), int(z_bf16), float(eps), int(grid), int(single))
 
 
 _X2_FMTS = ("f16x2", "bf16", "f16x2", "bf16", "f16x2", "f16x2")     # f16x2 mode: qkv / fc1 / fc2 weights in the f16x2 format, proj split-bf16
@@ -281,17 +286,18 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
                 n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b):
         import ctypes as C
         from .. import _lib
-        B, T, n, H, eps = geom
+        B, T, n, H, eps = geom[:5]
         S = 1 + T * n
         D = x.shape[-1]
         M = B * S
         Hd = fc1_w.shape[0]
         P, Pb = ec.fwd_passes, ec.bwd_passes
+        single = (geom[5] if len(geom) > 5 else 0) if P == 2 else 0     # ops.F16_SINGLE_BITS of this block
         dev = x.device
         x2 = x.contiguous().view(M, D)
         train = any(ctx.needs_input_grad)
         z_bf16 = Pb == 1 and ops.uses_big_gemm(M, Hd, D, P)
-        key = (B, T, n, H, D, Hd, P, Pb, train, z_bf16)
+        key = (B, T, n, H, D, Hd, P, Pb, train, z_bf16, single)
         g = _block_geom(*key, eps, ec.gemm_grid)
         ent = _BLOCK_CACHE.get(key)
         if ent is None:
@@ -321,7 +327,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         from .._lib import BlockBwdIO
         saved = ctx.saved_tensors
         x2, ln, biases, weights = saved[0], saved[1:7], saved[7:13], saved[13:19]
-        B, T, n, H, D, Hd, P, Pb, train, z_bf16 = ctx.key
+        B, T, n, H, D, Hd, P, Pb, train, z_bf16, single = ctx.key
         ec = ctx.ec
         ec.poll_backward()              # gradients of the blocks behind this one are final: the data-parallel exchange may start
         Pb_now = ec.bwd_passes
@@ -370,8 +376,11 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         dx_pl = ops.empty_planes(M, D, Pb, dev)
         used = {s_ for s_ in streams if s_ is not None}          # the side streams read / write these allocations of the main stream
         for st in used:
-            for t in (grads,) + ((g_pl.hi,) if g_hi is not None else ()):
-                t.record_stream(st)
+            # the handed-over gradient planes are allocations of the block behind this one: BOTH planes (a bf16x3 backward reads the lo
+            # plane in the fc2 weight gradient on a side stream as well)
+            for t in (grads,) + ((g_pl.hi, g_pl.lo) if g_hi is not None else ()):
+                if t is not None:
+                    t.record_stream(st)
         if used:
             ec.hold_until_join(ctx.arena, barena)               # the multi-GB arenas: held until the join instead (see there)
         prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2)
@@ -535,7 +544,9 @@ class SpaceTimeBlock(nn.Module):
         self.attention_style = attention_style
 
     def forward(self, x, B, T, n, ec):
-        geom = (B, T, n, self.num_heads, self.norm1.eps)
+        # which Linears of THIS block run one fp16 product in the f16x2 mode: the model's precision policy (ops.single_product_policy)
+        single = ec.f16_single_mask(getattr(self, "layer_index", None), getattr(self, "depth", None)) if ec.fwd_passes == 2 else 0
+        geom = (B, T, n, self.num_heads, self.norm1.eps, single)
         fn = _SpaceTimeBlockCFn if block_calls_ok(ec, B * (1 + T * n), x.shape[-1], self.mlp.fc1.weight.shape[0]) else _SpaceTimeBlockFn
         return fn.apply(
             x, geom, ec,
@@ -577,6 +588,8 @@ class SpaceTimeTransformer(nn.Module):
                            qk_scale=qk_scale, norm_layer=norm_layer, time_init=time_init,
                            attention_style=attention_style)
             for _ in range(depth)])
+        for i, blk in enumerate(self.blocks):
+            blk.layer_index, blk.depth = i, depth     # the precision policy is per block (ExecContext.f16_single_mask)
         self.norm = norm_layer(embed_dim)
         self.pre_logits = nn.Identity()
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()

@@ -39,7 +39,12 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # operands in the f16x2 format (include/egovlp_hip.h, csrc/f16x2.h) -- the accuracy of the three-product split-bf16 scheme at two
 # thirds of its MFMA work; attention, the proj Linears, the patch embedding, the text tower and the heads stay split-bf16
 # three-product.
+# Inside the f16x2 mode a Linear may run ONE fp16 product (passes code 4: plain fp16(activation) x fp16(weight), 2^-11 per operand) where
+# its share of the 1e-3 parity budget allows it: an error injected late in the tower reaches the embedding almost unamplified, one
+# injected in the first blocks is amplified by everything behind it, so the policy is "op X runs single-product from block k_X on"
+# (setting `f16_single`, see single_product_policy and profiles/r05_precision_table.txt).
 _PASSES = {"bf16x3": 3, "bf16": 1, "f16x2": 2}
+F16_SINGLE_BITS = {"fc1": 1, "fc2": 2, "qkv": 4}
 _PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16x2"}
 _HARD_DEFAULTS = {
     "fwd_passes": 3, "bwd_passes": 3,
@@ -66,7 +71,39 @@ _HARD_DEFAULTS = {
     # allocator retries (a device synchronisation each).  Two steps of lead keep the GPU fed (the host needs ~10 ms per step) and
     # bound the memory.  0: no limit.
     "max_steps_in_flight": int(os.environ.get("EGV_MAX_STEPS_IN_FLIGHT", "2")),
+    # fwd_passes == 2: which Linears of which video blocks run ONE fp16 product.  "none": every qkv / fc1 / fc2 keeps its two products
+    # (precision 'f16x2', round 4's benchmarked mode); "auto": single_product_policy(depth) (precision 'f16mix': what the per-op /
+    # per-block table allows inside 5e-4); or "fc2:3,fc1:3,qkv:3" / a dict {"fc2": first single-product block, ...} (absent op: never).
+    "f16_single": "none",
 }
+
+
+def single_product_policy(depth):
+    """-> {"fc2": k, "fc1": k, "qkv": k}: the op runs ONE fp16 product in blocks [k, depth), two before.  k = depth / 4: the first
+    quarter of the tower keeps two products.  profiles/r05_precision_table.txt (CPU oracle, operands rounded as the hardware rounds
+    them; video-embedding error of the whole model against fp32): a single-product Linear costs (0.65 .. 0.9)e-4 in the later blocks
+    but 2.4e-4 (fc1 / fc2) .. 9.4e-4 (qkv) in block 0, and the contributions add in quadrature -- with k = depth / 4: ViT-B/16 T = 4
+    4.4e-4, T = 16 4.0e-4, ViT-L/14 3.6e-4 (north_star's bar: 1e-3; text tower untouched, 2.7e-5)."""
+    k = -(-depth // 4)
+    return {"fc2": k, "fc1": k, "qkv": k}
+
+
+def parse_f16_single(spec, depth):
+    """The `f16_single` setting -> {"op": first single-product block} (empty: none)."""
+    if spec is None or spec == "none" or spec == "":
+        return {}
+    if spec == "auto":
+        return single_product_policy(depth)
+    if isinstance(spec, str):        # "fc2:0,fc1:4,qkv:6"
+        out = {}
+        for part in spec.split(","):
+            op, _, k = part.partition(":")
+            out[op.strip()] = int(k)
+        spec = out
+    unknown = set(spec) - set(F16_SINGLE_BITS)
+    if unknown:
+        raise ValueError(f"f16_single: unknown ops {sorted(unknown)} (known: {sorted(F16_SINGLE_BITS)})")
+    return dict(spec)
 
 
 class ExecContext:
@@ -81,6 +118,7 @@ class ExecContext:
         self._inflight = []                             # events of the steps the host has enqueued (see _throttle)
         self.flow_wait_s = 0.0                          # seconds the host has waited in _throttle so far
         self._wc = None
+        self._pol_cache = {}
 
     # ---- settings (inherited) ------------------------------------------------------------------------------------------
     def get(self, key):
@@ -109,14 +147,23 @@ class ExecContext:
 
     def set_precision(self, fwd: str = "bf16x3", bwd: Optional[str] = None):
         """'bf16x3' = split-bf16, three MFMA products, fp32-grade (meets the 1e-3 parity bar); 'bf16' = single pass;
-        'f16x2' (forward only, with a single-pass 'bf16' backward) = two fp16 products, fp32-grade like 'bf16x3' (3e-5 on the embeddings)."""
+        'f16x2' (forward only, with a single-pass 'bf16' backward) = two fp16 products, fp32-grade like 'bf16x3' (3e-5 on the embeddings);
+        'f16mix' = 'f16x2' in the first quarter of the video blocks, ONE fp16 product in their qkv / fc1 / fc2 Linears behind it (4e-4)."""
+        single = "none"
+        if fwd == "f16mix":
+            # 'f16mix' (the benchmarked mode of round 5) = 'f16x2' with ONE fp16 product where the parity budget allows it
+            # (single_product_policy); EGV_F16_SINGLE overrides the policy (A/B runs: "none", "fc2:0", "fc2:3,fc1:3,qkv:3")
+            fwd, single = "f16x2", os.environ.get("EGV_F16_SINGLE", "auto")
         bwd = bwd if bwd is not None else ("bf16" if fwd == "f16x2" else fwd)
-        if bwd == "f16x2" or (fwd == "f16x2" and bwd != "bf16"):
-            raise ValueError("'f16x2' is a forward format; it pairs with the single-pass 'bf16' backward")
-        return self.set(fwd_passes=_PASSES[fwd], bwd_passes=_PASSES[bwd])
+        if bwd in ("f16x2", "f16mix") or (fwd == "f16x2" and bwd != "bf16"):
+            raise ValueError("'f16x2' / 'f16mix' are forward formats; they pair with the single-pass 'bf16' backward")
+        return self.set(fwd_passes=_PASSES[fwd], bwd_passes=_PASSES[bwd], f16_single=single)
 
     def precision_name(self):
-        return _PASSES_INV[self.fwd_passes], _PASSES_INV[self.bwd_passes]
+        fwd = _PASSES_INV[self.fwd_passes]
+        if fwd == "f16x2" and self.get("f16_single") not in (None, "none", ""):
+            fwd = "f16mix"
+        return fwd, _PASSES_INV[self.bwd_passes]
 
     fwd_passes = property(lambda self: self.get("fwd_passes"))
     # what every forward product OUTSIDE the video blocks' qkv / fc1 / fc2 Linears runs with (patch embedding, text tower, heads,
@@ -129,7 +176,25 @@ class ExecContext:
     backward_poll = property(lambda self: self.get("backward_poll"))
     kernel_timer = property(lambda self: self.get("kernel_timer"))
     block_calls = property(lambda self: self.get("block_calls"))
+    f16_single = property(lambda self: self.get("f16_single"))
     max_steps_in_flight = property(lambda self: self.get("max_steps_in_flight"))
+
+    def f16_single_mask(self, layer, depth):
+        """Bit mask (F16_SINGLE_BITS) of the Linears of video block `layer` (of `depth`) that run ONE fp16 product in the f16x2 mode."""
+        if layer is None or depth is None:
+            return 0
+        key = (self.get("f16_single") if not isinstance(self.get("f16_single"), dict) else id(self.get("f16_single")), depth)
+        pol = self._pol_cache.get(key)
+        if pol is None:
+            pol = self._pol_cache[key] = parse_f16_single(self.get("f16_single"), depth)
+        m = 0
+        for op, k in pol.items():
+            if layer >= k:
+                m |= F16_SINGLE_BITS[op]
+        return m
+
+    def f16_single_policy(self, depth):
+        return parse_f16_single(self.get("f16_single"), depth)
 
     def poll_backward(self):
         fn = self.get("backward_poll")
@@ -421,8 +486,9 @@ class Planes:
     lo: Optional[torch.Tensor]       # bf16 [rows, ld] or None (passes == 1)            | fmt 'f16x2': fp16 plane 2 [rows, ld]
     rows: int
     cols: int                        # logical columns (<= ld)
-    fmt: str = "bf16"                # 'bf16' (split planes) or 'f16x2' (include/egovlp_hip.h: egv_f16x2_encode; role: first / second operand)
-    bf: Optional[torch.Tensor] = None  # fmt 'f16x2' only: bf16(value) [rows, ld], what the single-pass backward GEMMs read
+    fmt: str = "bf16"                # 'bf16' (split planes), 'f16x2' (include/egovlp_hip.h: egv_f16x2_encode; role: first / second operand)
+                                     # or 'f16' (ONE plane of plain fp16 in `hi`, lo = None: the first operand of a single-fp16-product GEMM)
+    bf: Optional[torch.Tensor] = None  # fmt 'f16x2' / 'f16' only: bf16(value) [rows, ld], what the single-pass backward GEMMs read
 
     @property
     def ld(self):
@@ -439,7 +505,7 @@ class Planes:
         if self.fmt == "bf16":
             return self
         if self.bf is None:
-            raise ValueError("this f16x2 operand was produced without its bf16 plane (forward outside a training step)")
+            raise ValueError("this fp16 operand was produced without its bf16 plane (forward outside a training step)")
         return Planes(self.bf, None, self.rows, self.cols)
 
 
@@ -451,14 +517,14 @@ def empty_planes(rows, cols, passes, device, ld=None, zero=False):
     return Planes(hi, lo, rows, cols)
 
 
-def empty_planes_f16x2(rows, cols, device, want_bf=False):
-    """Uninitialised f16x2 operand planes [rows, cols] (cols % 8 == 0)."""
+def empty_planes_f16x2(rows, cols, device, want_bf=False, single=False):
+    """Uninitialised f16x2 operand planes [rows, cols] (cols % 8 == 0); `single`: ONE plain fp16 plane (fmt 'f16')."""
     if cols % 8:
         raise ValueError("f16x2 operands come in 16-byte pieces (cols % 8 == 0)")
     hi = torch.empty((rows, cols), dtype=torch.float16, device=device)
-    lo = torch.empty((rows, cols), dtype=torch.float16, device=device)
+    lo = None if single else torch.empty((rows, cols), dtype=torch.float16, device=device)
     bf = torch.empty((rows, cols), dtype=torch.bfloat16, device=device) if want_bf else None
-    return Planes(hi, lo, rows, cols, "f16x2", bf)
+    return Planes(hi, lo, rows, cols, "f16" if single else "f16x2", bf)
 
 
 def f16x2_encode(x2d: torch.Tensor, role: int, want_bf=False) -> Planes:
@@ -545,13 +611,14 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     ec = DEFAULT if ec is None else ec
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
-    if (a.fmt == "f16x2") != (passes == 2) or a.fmt != b.fmt:
+    # passes 4: ONE fp16 product -- A a plain fp16 plane ('f16'), B the weight's f16x2 encoding (its plane 1 IS fp16(W))
+    if (a.fmt == "f16x2") != (passes == 2) or (a.fmt == "f16") != (passes == 4) or b.fmt != ("f16x2" if passes in (2, 4) else "bf16"):
         raise ValueError(f"gemm_nt: operand formats {a.fmt} / {b.fmt} do not go with passes = {passes}")
     out_fmt = 0
-    if out_planes is not None and out_planes.fmt == "f16x2":
-        out_fmt = 1
+    if out_planes is not None and out_planes.fmt != "bf16":
+        out_fmt = 2 if out_planes.fmt == "f16" else 1
     if ksplit is None:
-        ksplit = 1 if passes == 2 else auto_ksplit_nt(M, N, K)
+        ksplit = 1 if passes in (2, 4) else auto_ksplit_nt(M, N, K)
     aux = aux_in if aux_in is not None else aux_out
     aux_bf16 = int(aux is not None and aux.dtype == torch.bfloat16)
     if aux_is_grad:
@@ -574,9 +641,9 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * K,
-                   lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt"), passes,
+                   lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt"), 1 if passes == 4 else passes,
                    key=("gemm_big " if ksplit <= 1 and uses_big_gemm(M, N, K, passes) else "gemm_nt(128x128) ")
-                   + f"NT M={M} N={N} K={K} x{passes}")
+                   + f"NT M={M} N={N} K={K} " + ("x1 fp16" if passes == 4 else f"x{passes}"))
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt")
 
@@ -596,9 +663,9 @@ SMALL_SPLITK = int(os.environ.get("EGV_SMALL_SPLITK", "1"))   # 0: off (A/B diag
 
 
 def uses_big_gemm(M, N, K, passes=None):
-    """Mirror of the kernel choice in csrc/gemm_nt.hip (gemm_variant) for NT problems without split-K (f16x2 operands, passes = 2,
+    """Mirror of the kernel choice in csrc/gemm_nt.hip (gemm_variant) for NT problems without split-K (fp16 operands, passes = 2 / 4,
     always take the big-tile kernel when it can run the shape at all)."""
-    if passes == 2:
+    if passes in (2, 4):
         return f16x2_gemm_ok(M, N, K)
     return M >= 256 and N >= 256 and K % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 128
 
@@ -729,10 +796,11 @@ def relu_split(x2d: torch.Tensor, passes) -> Planes:
 
 # --------------------------------------------------------------------------------------------- LayerNorm
 def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, want_f32=False, want_planes=True,
-                  rows=None, ldx=None, want_bf=False):
+                  rows=None, ldx=None, want_bf=False, single=False):
     """rows of x2d (optionally x2d + x_add) -> (Planes | None, y_f32 | None, mean, rstd, sum | None).
     `rows`/`ldx` allow strided row selection (e.g. only the CLS row of every clip).
-    passes == 2: the output is written in the f16x2 operand format, first-operand role (`want_bf`: with the bf16 plane the backward reads)."""
+    passes == 2: the output is written in the f16x2 operand format, first-operand role (`want_bf`: with the bf16 plane the backward
+    reads); `single`: as ONE plane of plain fp16 instead (the consumer runs a single fp16 product)."""
     _need_cuda(x2d, gamma, beta)
     cols = x2d.shape[-1]
     rows = x2d.shape[0] if rows is None else rows
@@ -741,7 +809,7 @@ def layernorm_fwd(x2d, gamma, beta, eps, passes, *, x_add=None, want_sum=False, 
     if passes == 2:
         if x_add is not None or want_sum or want_f32 or not want_planes:
             raise ValueError("layernorm_fwd: the f16x2 form writes operand planes only")
-        pl = empty_planes_f16x2(rows, cols, dev, want_bf)
+        pl = empty_planes_f16x2(rows, cols, dev, want_bf, single=single)
         mean = torch.empty(rows, dtype=torch.float32, device=dev)
         rstd = torch.empty(rows, dtype=torch.float32, device=dev)
         check(_lib.lib().egv_layernorm_fwd_f16x2(_p(x2d), ldx, _p(gamma), _p(beta), float(eps), rows, cols, _p(pl.hi), _p(pl.lo),

@@ -36,7 +36,10 @@ enum { EGV_ACT_NONE = 0, EGV_ACT_GELU = 1, EGV_ACT_GELU_BWD = 2, EGV_ACT_RELU_BW
  * ffn.lin1/lin2; model/model.py:72-79 (projections).  passes = 1: bf16 operands (hi planes only);
  * passes = 3: split-bf16 operands, fp32-grade product (three bf16 MFMA products); passes = 2: "f16x2" operands (see
  * egv_f16x2_encode: a_hi / a_lo = the two fp16 planes of a first-operand encoding, b_hi / b_lo of a second-operand encoding;
- * big-tile NT kernel only, un-split) -- the same fp32-grade product from TWO fp16 MFMA products.  Requirements: K % 32 == 0, N % 4 == 0,
+ * big-tile NT kernel only, un-split) -- the same fp32-grade product from TWO fp16 MFMA products; passes = 4: ONE fp16 MFMA product of
+ * plain fp16 planes (a_hi = fp16(A), b_hi = fp16(B) = plane 1 of a second-operand f16x2 encoding; a_lo / b_lo ignored; big-tile NT
+ * kernel only, un-split; epilogues: bias + residual -> fp32 / split planes, or EGV_ACT_GELU -> out_fmt 1 / 2) -- 2^-11 per operand:
+ * for the Linears whose share of the 1e-3 parity budget allows it.  Requirements: K % 32 == 0, N % 4 == 0,
  * lda % 8 == ldb % 8 == 0, 16-byte aligned base pointers.
  *  act = EGV_ACT_GELU      : v = gelu(v); if aux_out != NULL the pre-activation is stored there first
  *  act = EGV_ACT_GELU_BWD  : v *= gelu'(aux_in[m,n])           (fc2 dgrad -> dZ)
@@ -73,8 +76,9 @@ typedef struct egv_gemm_desc {
                        Multiples of 8 in [8, 256]; anything else is an invalid argument.  (Per call, not per process: the
                        library keeps no state between calls.)                                                         */
   int32_t out_fmt;  /* format of (out_hi, out_lo): 0 = split-bf16 planes; 1 = the f16x2 operand format below, first-operand role
-                       (two fp16 planes; EGV_ACT_GELU of a passes == 2 product only: fc1 -> fc2 of the forward).                   */
-  egv_bf16* out_bf; /* out_fmt == 1, optional: bf16(value) as a third plane [M, ldoh] -- the single-pass operand the backward GEMMs
+                       (two fp16 planes); 2 = ONE plane of plain fp16 in out_hi (out_lo unused): the operand of a passes == 4
+                       consumer.  1 / 2: EGV_ACT_GELU of a passes == 2 or 4 product only (fc1 -> fc2 of the forward).             */
+  egv_bf16* out_bf; /* out_fmt != 0, optional: bf16(value) as a further plane [M, ldoh] -- the single-pass operand the backward GEMMs
                        (wgrad) read, since an fp16 plane cannot share an MFMA with bf16 gradients.                               */
 } egv_gemm_desc;
 int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
@@ -114,7 +118,8 @@ int egv_f16x2_encode(const float* x, int64_t ldx, int32_t rows, int32_t cols, ui
 int egv_f16x2_encode_multi(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
                            uint16_t* const* p1, uint16_t* const* p2, const int64_t* ldo, int32_t role, void* stream);
 /* nn.LayerNorm (model/video_transformer.py:146,156,159 -> the qkv / fc1 Linears) with the output written in the f16x2 format,
- * first-operand role (+ optional bf16 plane); cols % 8 == 0, cols <= 1024; mean / rstd [rows] saved for egv_layernorm_bwd.       */
+ * first-operand role (+ optional bf16 plane); y2 == NULL: ONE plane of plain fp16 in y1 instead (the operand of a passes == 4
+ * product); cols % 8 == 0, cols <= 1024; mean / rstd [rows] saved for egv_layernorm_bwd.                                          */
 int egv_layernorm_fwd_f16x2(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, int32_t rows,
                             int32_t cols, uint16_t* y1, uint16_t* y2, egv_bf16* ybf, int64_t ldy, float* mean, float* rstd,
                             void* stream);
@@ -133,6 +138,10 @@ typedef struct egv_block_geom {
   int32_t fwd_passes, bwd_passes, train, z_bf16;
   float eps;
   int32_t grid_cap;     /* as egv_gemm_desc.grid_cap */
+  int32_t f16_single;   /* fwd_passes == 2 only: which Linears of THIS block run ONE fp16 product (egv_gemm_nt passes == 4) instead of
+                           the two of the f16x2 format -- bit 0: fc1 (norm2 then writes one plain fp16 plane), bit 1: fc2 (the GELU
+                           epilogue of fc1 then writes h as one plain fp16 plane), bit 2: both qkv Linears (norm3 / norm1 write one
+                           plain fp16 plane).  0 elsewhere.  Which blocks may is the caller's precision policy.        */
 } egv_block_geom;
 typedef struct egv_block_params {                 /* weight index: 0 timeattn.qkv, 1 timeattn.proj, 2 attn.qkv, 3 attn.proj, 4 fc1, 5 fc2 */
   const float *n3w, *n3b, *n1w, *n1b, *n2w, *n2b; /* LayerNorm affine (norm3 = temporal, norm1 = spatial, norm2 = MLP)              */

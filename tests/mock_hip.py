@@ -62,6 +62,8 @@ def _make_mock(calls):
 
         def cb(*a, _name=name, _ret=ret):
             calls.append(_name)
+            if _name == "egv_block_fwd" and hasattr(calls, "block_single"):     # the per-block precision policy the host passed down
+                calls.block_single.append(int(C.cast(a[0], C.POINTER(_lib.BlockGeom)).contents.f16_single))
             if _name == "egv_block_grad_layout":
                 return grad_layout(*a)
             if _name == "egv_text_layer_grad_layout":
@@ -79,7 +81,12 @@ def _make_mock(calls):
 def mock_hip():
     """with mock_hip() as calls: ...  -- `calls` is the list of C-ABI entry points invoked, in order."""
     from egovlp_amd import _lib, ops
-    calls = []
+
+    class _Calls(list):
+        """the call log; `.block_single`: egv_block_geom.f16_single of every egv_block_fwd call, in order"""
+
+    calls = _Calls()
+    calls.block_single = []
     saved = (_lib._lib, ops._stream, ops._need_cuda)
     _lib._lib = _make_mock(calls)
     ops._stream = lambda t=None: None

@@ -60,6 +60,10 @@ def main():
                                                      "bf16+e2m1", "bf16+e2m1/e4m3", "bf16+e2m3/e4m3"])
     ap.add_argument("--scaling", default="ceil")
     ap.add_argument("--per-op", action="store_true")
+    ap.add_argument("--per-op-fp16", action="store_true",
+                    help="ONE fp16 product for one op kind (and unions) on top of the f16x2 mode (VERDICT r04 next-1a)")
+    ap.add_argument("--per-block-fp16", action="store_true",
+                    help="fc2 in ONE fp16 product in every block, fc1 in ONE fp16 product in a subset of the blocks")
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
     if a.threads:
@@ -79,6 +83,34 @@ def main():
         for kind in ("patch", "qkv", "qk", "pv", "proj", "fc1", "fc2", "text_lin", "text_qk", "text_pv", "head"):
             te, ve, l = run(sd, batch, vcfg, Policy(default="bf16x3", **{kind: "bf16"}))
             print(f"{'bf16x3, ' + kind + '=bf16':34s} {rel(te, rt):10.2e} {rel(ve, rv):10.2e} {abs(l - rl):10.2e}", flush=True)
+    if a.per_op_fp16:
+        base = dict(qkv="fp16x2:6", fc1="fp16x2:6", fc2="fp16x2:6")
+        print("# base = the f16x2 mode (video blocks' qkv / fc1 / fc2 in two fp16 products, bf16x3 elsewhere); listed kinds in ONE fp16 product")
+        rows = [(k,) for k in ("patch", "qkv", "qk", "pv", "proj", "fc1", "fc2", "text_lin", "text_qk", "text_pv", "head")]
+        rows += [("fc1", "fc2"), ("fc1", "fc2", "pv"), ("fc1", "fc2", "proj"), ("fc1", "fc2", "pv", "proj"),
+                 ("fc1", "fc2", "pv", "proj", "qk"), ("fc1", "fc2", "pv", "proj", "qk", "qkv"),
+                 ("text_lin", "text_qk", "text_pv"), ("fc2", "text_lin", "text_qk", "text_pv"),
+                 ("fc1", "fc2", "text_lin", "text_qk", "text_pv")]
+        for kinds in rows:
+            pol = dict(base)
+            pol.update({k: "fp16" for k in kinds})
+            t0 = time.time()
+            te, ve, l = run(sd, batch, vcfg, Policy(default="bf16x3", **pol))
+            print(f"{'f16x2, fp16 x1: ' + ' + '.join(kinds):58s} {rel(te, rt):10.2e} {rel(ve, rv):10.2e} {abs(l - rl):10.2e}   {time.time() - t0:.0f}",
+                  flush=True)
+    if a.per_block_fp16:
+        base = dict(qkv="fp16x2:6", fc1="fp16x2:6", fc2="fp16")
+        dep = vcfg.depth
+        print("# base = f16x2 mode with fc2 in ONE fp16 product in every block; fc1 in ONE fp16 product in the listed blocks only")
+        sets = [("none", []), ("last quarter", range(dep - dep // 4, dep)), ("last half", range(dep // 2, dep)),
+                ("first half", range(0, dep // 2)), ("last two thirds", range(dep // 3, dep)), ("all", range(dep))]
+        for label, blocks in sets:
+            pol = dict(base)
+            pol.update({f"fc1@{b}": "fp16" for b in blocks})
+            t0 = time.time()
+            te, ve, l = run(sd, batch, vcfg, Policy(default="bf16x3", **pol))
+            print(f"{'fc2 x1 everywhere, fc1 x1 in: ' + label:58s} {rel(te, rt):10.2e} {rel(ve, rv):10.2e} {abs(l - rl):10.2e}   {time.time() - t0:.0f}",
+                  flush=True)
 
 
 if __name__ == "__main__":

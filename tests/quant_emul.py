@@ -144,7 +144,12 @@ class Policy:
         self.default = Scheme(default, scaling)
         self.per_kind = {k: Scheme(v, scaling) for k, v in per_kind.items()}
 
-    def __call__(self, kind):
+    def __call__(self, kind, block=None):
+        """`block`: index of the video block the Linear belongs to -- a per-block entry "fc1@7" overrides the kind's."""
+        if block is not None:
+            s = self.per_kind.get(f"{kind}@{block}")
+            if s is not None:
+                return s
         return self.per_kind.get(kind, self.default)
 
 
@@ -189,8 +194,12 @@ class _FProxy:
         return getattr(F, k)
 
     def linear(self, x, w, b=None):
-        kind = _kind_of(self._hook.names.get(id(w)))
-        y = self._hook.policy(kind).bmm(x, w)
+        name = self._hook.names.get(id(w))
+        kind = _kind_of(name)
+        blk = None
+        if name is not None and ".blocks." in name:
+            blk = int(name.split(".blocks.")[1].split(".")[0])
+        y = self._hook.policy(kind, blk).bmm(x, w)
         return y if b is None else y + b
 
     def conv2d(self, x, w, b=None, stride=1):    # the patch embed (kernel = stride): a GEMM over unfolded patches

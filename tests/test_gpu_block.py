@@ -74,6 +74,85 @@ def test_block_calls_equal_the_per_kernel_path(mode, side, geom):
     assert exact["mlp.fc2.weight"] and exact["mlp.fc2.bias"] and exact["mlp.fc1.weight"], exact     # upstream of any atomics
 
 
+@pytest.mark.parametrize("policy", ["none", "fc2:0", "fc1:0,fc2:0", "qkv:0", "fc2:0,fc1:0,qkv:0"])
+@pytest.mark.parametrize("geom", [(8, 4, 196), (2, 16, 196)])
+def test_block_calls_equal_the_per_kernel_path_in_the_fp16_modes(policy, geom):
+    """The same comparison for the fp16-product forwards: 'f16x2' (policy "none": two fp16 products in qkv / fc1 / fc2) and the
+    per-block single-product choices of 'f16mix' (egv_block_geom.f16_single: ONE fp16 product in fc2 / fc1 / both qkv Linears, their
+    first operand one plain fp16 plane).  Backward: single-pass bf16 on the bf16 copies."""
+    from egovlp_amd import ops
+    B, T, n = geom
+    D = 768
+    blk = _block(D)
+    blk.layer_index, blk.depth = 5, 12
+    ec = ops.new_context()
+    ec.set_precision("f16x2")
+    ec.set(f16_single=policy)
+    want = sum(ops.F16_SINGLE_BITS[o.split(":")[0]] for o in policy.split(",")) if policy != "none" else 0
+    assert ec.f16_single_mask(5, 12) == want
+    torch.manual_seed(5)
+    x = torch.randn(B, 1 + T * n, D, device="cuda")
+    g = torch.randn(B, 1 + T * n, D, device="cuda") * 0.1
+    y_c, dx_c, gr_c, used_c = _run(blk, ec, x, g, B, T, n, True, False)
+    y_k, dx_k, gr_k, used_k = _run(blk, ec, x, g, B, T, n, False, False)
+    assert used_c == {"c": 1, "k": 0} and used_k == {"c": 0, "k": 1}
+    assert torch.equal(y_c, y_k)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    diffs = {"dx": rel(dx_c, dx_k), **{k: rel(gr_c[k], gr_k[k]) for k in gr_k}}
+    assert all(v < 1e-4 for v in diffs.values()), diffs
+    assert diffs["mlp.fc2.weight"] == 0.0 and diffs["mlp.fc1.weight"] == 0.0, diffs
+    # and against the all-bf16x3 forward of the same block: a single-product Linear is 2^-11-grade, the two-product form 2^-17-grade
+    ec3 = ops.new_context()
+    ec3.set_precision("bf16x3", "bf16")
+    y_3, _, _, _ = _run(blk, ec3, x, g, B, T, n, True, False)
+    r = rel(y_c, y_3)
+    print("fp16 block, policy %s: output vs the bf16x3 forward %.2e" % (policy, r))
+    assert r < (2e-5 if want == 0 else 6e-4), r
+
+
+def test_plane_handover_between_blocks_with_a_three_pass_backward_on_side_streams():
+    """Advisor (round 4): with a bf16x3 backward the gradient planes handed from block to block are TWO allocations (hi, lo), and the
+    fc2 weight gradient reads both on a side stream -- both must be recorded for it.  Three blocks, bf16x3 / bf16x3, wgrad side
+    streams: the hand-over is taken (hits), and the gradients equal those of the same chain without side streams."""
+    from egovlp_amd import ops
+    from egovlp_amd.model import video_transformer as vt
+    B, T, n, D = 8, 4, 196, 768
+    blks = [_block(D, seed=i) for i in range(3)]
+    torch.manual_seed(3)
+    x = torch.randn(B, 1 + T * n, D, device="cuda")
+    g = torch.randn(B, 1 + T * n, D, device="cuda") * 0.1
+
+    def chain(side):
+        ec = ops.new_context()
+        ec.set_precision("bf16x3", "bf16x3")
+        ec.set(wgrad_side_stream=side)
+        for b in blks:
+            for p in b.parameters():
+                p.grad = None
+        ec.begin_step()
+        h = x.clone().requires_grad_(True)
+        y = h
+        for b in blks:
+            y = b(y, B, T, n, ec)
+        y.backward(g)
+        ec.join_side_stream()
+        torch.cuda.synchronize()
+        return h.grad.clone(), [{k: p.grad.clone() for k, p in b.named_parameters()} for b in blks]
+
+    hits0 = vt.PLANE_HANDOFF["hit"]
+    dx_s, gr_s = chain(True)
+    assert vt.PLANE_HANDOFF["hit"] - hits0 == 2            # blocks 1 and 0 take the planes of the block behind them
+    dx_m, gr_m = chain(False)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    worst = max([rel(dx_s, dx_m)] + [rel(a[k], b[k]) for a, b in zip(gr_s, gr_m) for k in a])
+    print("three blocks, bf16x3 backward, side streams vs main stream: worst relative difference %.1e" % worst)
+    assert worst < 1e-5, worst
+
+
 def test_block_calls_are_the_default_and_leave_no_copies():
     """The whole video tower steps through the block calls by default; the parameter gradients it hands to autograd are views of one
     buffer per block (stolen by AccumulateGrad, no copy): their storages coincide."""

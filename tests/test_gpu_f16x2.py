@@ -134,6 +134,75 @@ def test_gemm_f16x2_mlp_with_gelu_handover(ops):
     assert rel(out, ref) < 3e-5
 
 
+def _f16_plane(ops, x):
+    """ONE plane of plain fp16(x): the first operand of a single-fp16-product GEMM (egv_gemm_nt passes == 4)."""
+    return ops.Planes(x.cuda().to(torch.float16).contiguous(), None, x.shape[0], x.shape[1], "f16")
+
+
+@pytest.mark.parametrize("M,N,K", [(4200, 2304, 768), (3140, 768, 3072), (785, 256, 64), (25120, 768, 3072), (25120, 3072, 768)])
+def test_gemm_single_fp16_product(ops, M, N, K):
+    """egv_gemm_nt(passes = 4): fp16(A) x fp16(W) on the fp16 MFMA, fp32 accumulate -- equal to the exact product of the rounded
+    operands, 2^-11-grade against the fp32 product.  The weight operand is the f16x2 encoding (its plane 1 IS fp16(W))."""
+    a, w = _inputs(M, K, 31), _inputs(N, K, 32, 0.03)
+    g = torch.Generator().manual_seed(33)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    pa, pw = _f16_plane(ops, a), ops.f16x2_encode(w.cuda(), 1)
+    exact = pa.hi.cpu().double() @ pw.hi.cpu().double().t()
+    true = a.double() @ w.double().t()
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(pa, pw, passes=4, bias=bias.cuda(), residual=res.cuda(), out_f32=out)           # fc2 form
+    got = out.cpu().double() - bias.double() - res.double()
+    r_exact, r_true = rel(got, exact), rel(got, true)
+    print("single fp16 product M=%d N=%d K=%d: vs exact product of the rounded operands %.2e, vs fp32 product %.2e" % (M, N, K, r_exact, r_true))
+    assert r_exact < 4e-6 and 5e-5 < r_true < 6e-4
+    pl = ops.empty_planes(M, N, 3, "cuda")
+    ops.gemm_nt(pa, pw, passes=4, bias=bias.cuda(), out_planes=pl)                              # qkv form: split-bf16 planes out
+    assert rel(pl.float().cpu().double() - bias.double(), exact) < 2e-5
+
+
+@pytest.mark.parametrize("cols", [768, 1024])
+def test_layernorm_writes_one_plain_fp16_plane(ops, cols):
+    rows = 777
+    g = torch.Generator().manual_seed(cols)
+    x = _inputs(rows, cols, 20 + cols)
+    gamma, beta = 1.0 + 0.1 * torch.randn(cols, generator=g), 0.05 * torch.randn(cols, generator=g)
+    pl, _, mean, rstd, _ = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-6, 2, want_bf=True, single=True)
+    assert pl.fmt == "f16" and pl.lo is None and pl.hi.dtype == torch.float16
+    ref = F.layer_norm(x.double(), (cols,), gamma.double(), beta.double(), 1e-6)
+    assert rel(pl.hi.cpu(), ref) < 4e-4 and rel(pl.bf.cpu(), ref) < 4e-3
+    _, yf, _, _, _ = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-6, 1, want_f32=True, want_planes=False)
+    same = (pl.hi.cpu().view(torch.int16) == yf.cpu().to(torch.float16).view(torch.int16)).float().mean()
+    assert float(same) > 0.99
+
+
+@pytest.mark.parametrize("fc1_single", [False, True])
+def test_single_product_mlp_with_gelu_handover(ops, fc1_single):
+    """fc1 -> GELU -> fc2 with fc2 (and optionally fc1) as ONE fp16 product: the fc1 epilogue (two- or one-product instance) writes
+    the activation as ONE plain fp16 plane (out_fmt 2, + bf16 plane, + saved gelu'), fc2 consumes it."""
+    M, D, Hd = 3140, 768, 3072
+    x, w1, w2 = _inputs(M, D, 41), _inputs(Hd, D, 42, 0.03), _inputs(D, Hd, 43, 0.02)
+    g = torch.Generator().manual_seed(44)
+    b1, b2 = 0.1 * torch.randn(Hd, generator=g), 0.1 * torch.randn(D, generator=g)
+    pw1, pw2 = ops.f16x2_encode(w1.cuda(), 1), ops.f16x2_encode(w2.cuda(), 1)
+    px = _f16_plane(ops, x) if fc1_single else ops.f16x2_encode(x.cuda(), 0)
+    h = ops.empty_planes_f16x2(M, Hd, "cuda", want_bf=True, single=True)
+    z = torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(px, pw1, passes=4 if fc1_single else 2, bias=b1.cuda(), act=ops.ACT_GELU, aux_out=z, out_planes=h, aux_is_grad=True)
+    pre = x.double() @ w1.double().t() + b1.double()
+    act = F.gelu(pre)
+    cdf = 0.5 * (1.0 + torch.erf(pre / 2 ** 0.5))
+    dgelu = cdf + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5
+    r_h = rel(h.hi.cpu(), act)
+    print("single-product mlp (fc1 single: %s): h vs gelu %.2e, bf %.2e, saved gelu' %.2e" % (fc1_single, r_h, rel(h.bf.cpu(), act), rel(z.cpu(), dgelu)))
+    assert r_h < (8e-4 if fc1_single else 4e-4) and rel(h.bf.cpu(), act) < 4e-3 and rel(z.cpu(), dgelu) < 4e-3
+    out = torch.empty(M, D, device="cuda")
+    ops.gemm_nt(h, pw2, passes=4, bias=b2.cuda(), out_f32=out)
+    exact = h.hi.cpu().double() @ pw2.hi.cpu().double().t() + b2.double()
+    ref = act @ w2.double().t() + b2.double()
+    print("single-product mlp: fc2 vs the exact product of its operands %.2e, vs fp64 %.2e" % (rel(out, exact), rel(out, ref)))
+    assert rel(out, exact) < 4e-6 and rel(out, ref) < 1.5e-3
+
+
 def test_gemm_f16x2_rejects_what_it_cannot_run(ops):
     from egovlp_amd._lib import EgovlpHipError
     a, w = ops.f16x2_encode(_inputs(512, 256, 51).cuda(), 0), ops.f16x2_encode(_inputs(512, 256, 52).cuda(), 1)
@@ -145,3 +214,10 @@ def test_gemm_f16x2_rejects_what_it_cannot_run(ops):
         ops.gemm_nt(small, w, passes=2, out_f32=torch.empty(128, 512, device="cuda"))                  # below one big tile
     with pytest.raises(EgovlpHipError):
         ops.gemm_nt(a, w, passes=2, out_f32=out, ksplit=2)                                             # no split-K form
+    one = _f16_plane(ops, _inputs(512, 256, 55))
+    with pytest.raises(ValueError):
+        ops.gemm_nt(one, w, passes=2, out_f32=out)                                                     # one plane is not an f16x2 operand
+    with pytest.raises(EgovlpHipError):
+        ops.gemm_nt(one, w, passes=4, out_f32=out, ksplit=2)                                           # single product: un-split only
+    with pytest.raises(EgovlpHipError):
+        ops.gemm_nt(one, w, passes=4, act=ops.ACT_GELU, out_f32=out)                                   # its GELU form writes fp16 operand planes only

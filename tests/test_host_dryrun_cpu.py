@@ -288,3 +288,33 @@ def test_f16x2_mode_wiring(model):
     assert ent_proj.pl is not None and ent_proj.p2 is None                            # the proj Linears stay split-bf16
     with pytest.raises(ValueError):
         ec.set_precision("f16x2", "bf16x3")
+
+
+def test_f16mix_mode_wiring(model):
+    """Precision 'f16mix' (the benchmarked mode): the per-block single-product policy reaches the C block calls -- the first quarter of
+    the video blocks keeps two fp16 products (f16_single 0), the rest run fc1 / fc2 / both qkv Linears as ONE (bits 1 | 2 | 4) --, a
+    policy string overrides it, 'f16x2' switches it off again; the weights are the same f16x2 planes either way."""
+    from egovlp_amd import ops
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.optim import AdamW
+    from egovlp_amd.trainer.trainer_egoclip import egoclip_step
+    opt = AdamW(model.parameters(), lr=3e-5)
+    ec = model.exec_ctx
+    assert ops.single_product_policy(12) == {"fc2": 3, "fc1": 3, "qkv": 3} and ops.single_product_policy(24)["qkv"] == 6
+    seen = {}
+    with mock_hip() as calls:
+        try:
+            for name, setup in (("f16mix", lambda: ec.set_precision("f16mix")),
+                                ("policy", lambda: ec.set(f16_single="fc2:0,fc1:6")),
+                                ("f16x2", lambda: ec.set_precision("f16x2"))):
+                setup()
+                for p in model.parameters():
+                    p.grad = None
+                del calls.block_single[:]
+                egoclip_step(model, EgoNCE(), opt, _batch(B=8, T=4), 1, 0)
+                seen[name] = (list(calls.block_single), ec.precision_name())
+        finally:
+            ec.unset("fwd_passes", "bwd_passes", "f16_single")
+    assert seen["f16mix"] == ([0, 0, 0] + [7] * 9, ("f16mix", "bf16")), seen["f16mix"]
+    assert seen["policy"] == ([2] * 6 + [3] * 6, ("f16mix", "bf16")), seen["policy"]
+    assert seen["f16x2"] == ([0] * 12, ("f16x2", "bf16")), seen["f16x2"]
