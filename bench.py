@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the secondary with_h2d_uint8 measurement")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-dp-leg", action="store_true", help="skip the secondary leg that runs the N > 1 step policy (process group, RCCL "
+                    "gather, hook-free gradient exchange, ONE wgrad stream, 248-workgroup GEMM grid) at world size 1")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 20-step loss / parameter drift comparison of the "
                     "benchmarked precision mode against the all-bf16x3 (fp32-grade gradient) run")
     ap.add_argument("--gemm-grid", type=int, default=0, help="persistent workgroups of the big GEMM (default: 256 at N=1, "
@@ -273,9 +275,6 @@ def main():
     ap.add_argument("--main-priority", type=int, default=int(os.environ.get("EGV_MAIN_PRIO", "0")),
                     help="1: run the step on a HIGH-priority HIP stream (the wgrad / text side streams keep the default priority: "
                          "their workgroups fill the CUs the main stream's kernels leave free instead of competing with them)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("EGV_GRAPH_STEP", "0")),
-                    help="1: the whole step (forward, loss, backward, AdamW; all three streams) is captured into a HIP graph once and "
-                         "replayed (egovlp_amd.graph.GraphedTrainStep; single GPU): one launch per step instead of ~840")
     ap.add_argument("--rccl-channels", type=int, default=0, help="N>1: cap RCCL at this many channels (= workgroups) via "
                     "NCCL_MAX_NCHANNELS, e.g. 8 to match the CUs the 248-workgroup GEMM grid leaves free (default: RCCL's choice)")
     ap.add_argument("--grad-exchange", default=os.environ.get("EGV_GRAD_EXCHANGE", "direct"), choices=["direct", "allreduce"],
@@ -367,22 +366,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    graphed = {}
-
     def one_step():
-        if args.graph and world == 1 and not use_dist and ec.kernel_timer is None:
-            from egovlp_amd.graph import GraphedTrainStep
-            key = ec.precision_name()
-            if key not in graphed:          # one graph per precision mode (the secondary fast-mode leg re-captures)
-                for g_ in graphed.values():
-                    g_.disable()
-                graphed.clear()
-                graphed[key] = GraphedTrainStep(model, loss_fn, opt)
-            return graphed[key](data)
         return egoclip_step(net, loss_fn, opt, data, world, rank, grad_sync=grad_sync)
 
     def measure(steps, warmup):
-        for _ in range(max(warmup, 3) if args.graph else warmup):     # graphed: 2 eager steps + the capture before the clock starts
+        for _ in range(warmup):
             one_step()
         barrier()
         t0 = time.perf_counter()
@@ -425,9 +413,6 @@ def main():
         idle.append((time.perf_counter() - t0_) * 1e3)
     torch.cuda.synchronize()
     HOST["enqueue_idle_ms"] = min(idle)
-    for g_ in graphed.values():           # the instrumented legs below run eagerly
-        g_.disable()
-    graphed.clear()
     ms = dt / args.steps * 1e3
     pairs = world * B * args.steps / dt
 
@@ -513,8 +498,7 @@ def main():
                                # GEMM grid under a process group, two wgrad streams and 256 workgroups without
                                "wgrad_streams": (ops._wgrad_stream_count() if args.wgrad_side else 0), "gemm_grid": grid,
                                "main_stream_high_priority": bool(args.main_priority),
-                               "max_steps_in_flight": int(ec.max_steps_in_flight),
-                               "step_replayed_from_hip_graph": bool(args.graph and world == 1 and not use_dist)}},
+                               "max_steps_in_flight": int(ec.max_steps_in_flight)}},
         "loss": round(loss_val, 5),
         # caching-allocator state after the timed loop: reserved HBM and how often an allocation had to free cached blocks and retry
         # (each retry synchronises the device: a host that runs many steps ahead holds that many steps' workspaces)
@@ -572,9 +556,6 @@ def main():
         # outside the parity bar, reported for reference only -- `value` above is the parity-mode number)
         set_precision("bf16")
         dt2, loss2 = measure(args.steps, max(args.warmup, 2))
-        for g_ in graphed.values():
-            g_.disable()
-        graphed.clear()
         out["fast_mode_bf16"] = {"value": round(world * B * args.steps / dt2, 2), "unit": "clip-pairs/s",
                                  "ms_per_step": round(dt2 / args.steps * 1e3, 3), "loss": round(loss2, 5),
                                  "step_mfma_frac": None if key not in FWD_GFLOP_PER_PAIR else round(
@@ -613,6 +594,37 @@ def main():
                                                             + 4 * (batch["noun_vec"].numel() + batch["verb_vec"].numel())),
                                  "input": "decoded uint8 frames + token ids / masks / noun-verb vectors in pinned host memory, copied one "
                                           "batch ahead on a copy stream; normalisation fused into the patch gather", "loss": round(float(lossh), 5)}
+    if world == 1 and not use_dist and not args.no_dp_leg:
+        # secondary, clearly labelled: the step exactly as `world > 1` configures it -- RCCL process group, fused embedding
+        # all-gather, hook-free bf16 gradient exchange (`--grad-exchange`) launched from the backward polls, ONE wgrad side stream, the
+        # GEMM grid capped at 248 workgroups -- on the one GPU there is: what the data-parallel machinery costs before any byte crosses
+        # a link.  No scaling claim: gpurun boxes have one GPU.
+        from egovlp_amd.dist import Bf16GradSync
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ["EGV_FORCE_GATHER"] = "1"
+        use_dist = True
+        grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
+                                 exchange=args.grad_exchange)
+        ec.set(backward_poll=grad_sync.poll, gemm_grid=248)
+        ec.reset_side_streams()                 # one wgrad stream under a process group (ops._wgrad_stream_count)
+        dt3, loss3 = measure(args.steps, max(args.warmup, 3))
+        out["dp_policy_at_world_size_1"] = {
+            "value": round(B * args.steps / dt3, 2), "unit": "clip-pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+            "loss": round(loss3, 5), "gemm_grid": 248, "wgrad_streams": ops._wgrad_stream_count() if args.wgrad_side else 0,
+            "gradient_exchange": args.grad_exchange, "buckets": int(grad_sync.stats.get("buckets", 0)),
+            "launched_during_backward": int(grad_sync.stats.get("launched_during_backward", 0)),
+            "what": "the N > 1 step policy (RCCL process group, fused all-gather, hook-free bf16 gradient exchange, one wgrad stream, "
+                    "248-workgroup GEMM grid) at world size 1 on this GPU; `value` above is the N = 1 policy"}
+        ec.set(backward_poll=None, gemm_grid=grid)
+        grad_sync = None
+        os.environ.pop("EGV_FORCE_GATHER", None)
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        use_dist = False
+        ec.reset_side_streams()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

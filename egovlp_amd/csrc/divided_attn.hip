@@ -1,5 +1,6 @@
 // C-ABI entry points of divided space-time attention (VarAttention core, model/video_transformer.py:104-133).
-// Patch queries run in the space (MFMA) or time (VALU) kernel; the clip's CLS query row (:109-112) rides along in every
+// Patch queries run in the space kernels (attn_mfma_fwd / _bwd.hip) or the time kernels (attn_time_mfma.hip) -- both on the matrix
+// cores since round 4 --; the clip's CLS query row (:109-112) rides along in every
 // group of those kernels (see attn_small.hip) and is finished by tiny combine / delta / finish kernels.
 #include "common.h"
 #include "egovlp_hip.h"

@@ -312,6 +312,13 @@ class ExecContext:
             sd["dirty"] = False
         sd["held"].clear()
 
+    def reset_side_streams(self):
+        """Forget the wgrad side streams (after joining them): the next weight gradient re-creates them under the CURRENT policy
+        (ops._wgrad_stream_count: two streams in a single-process run, one as soon as a process group exists)."""
+        self.join_side_stream()
+        sd = self._side
+        sd["stream"], sd["extra"], sd["load"], sd["events"], sd["rr"] = None, [], None, None, 0
+
     def hold_until_join(self, *tensors):
         """Keep main-stream allocations that side-stream kernels read or write alive until the next join_side_stream().  The
         alternative, Tensor.record_stream, parks a freed block behind an event of the side stream: it comes back to the pool only

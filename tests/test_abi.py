@@ -36,29 +36,62 @@ def test_ctypes_prototypes_match_header_symbol_set():
     assert sorted(_lib.PROTOTYPES.keys()) == declared_symbols()
 
 
-def test_gemm_desc_layout_matches_header(tmp_path):
-    """Compile the header with the host C compiler and compare sizeof / offsetof of every field of egv_gemm_desc
-    with the ctypes mirror the Python host side uses."""
-    import shutil
-    import subprocess
+ABI_STRUCTS = {"egv_gemm_desc": "GemmDesc", "egv_block_geom": "BlockGeom", "egv_block_params": "BlockParams",
+               "egv_block_bwd_io": "BlockBwdIO", "egv_text_geom": "TextGeom", "egv_text_params": "TextParams"}
+
+
+def test_gemm_desc_pinned_offsets():
+    """The descriptor every GEMM call passes: size and the offsets the documentation quotes."""
     from egovlp_amd._lib import GemmDesc
     assert ctypes.sizeof(GemmDesc) == 208
     assert GemmDesc.M.offset == 48 and GemmDesc.bias.offset == 72 and GemmDesc.partial.offset == 168
     assert GemmDesc.trans.offset == 176 and GemmDesc.aux_bf16.offset == 180 and GemmDesc.colsum.offset == 184 and GemmDesc.grid_cap.offset == 192
     assert GemmDesc.out_fmt.offset == 196 and GemmDesc.out_bf.offset == 200
+
+
+def test_every_abi_struct_layout_matches_header(tmp_path):
+    """Compile the header with the host C compiler and compare sizeof / offsetof of EVERY field of ALL SIX structs of the C ABI
+    (egv_gemm_desc, egv_block_geom / _params / _bwd_io, egv_text_geom / _params) with the ctypes mirrors the Python host side
+    passes; the struct declarations in the header and the mirrors must also name the same fields in the same order."""
+    import shutil
+    import subprocess
+    from egovlp_amd import _lib
     if shutil.which("gcc") is None:
         pytest.skip("no host C compiler")
-    fields = [f[0] for f in GemmDesc._fields_]
+    hdr = open(os.path.join(ROOT, "include", "egovlp_hip.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "egovlp_hip.h"', 'int main(void){']
+    for cname, pyname in ABI_STRUCTS.items():
+        mirror = getattr(_lib, pyname)
+        fields = [f[0] for f in mirror._fields_]
+        # field names as the header declares them, in order
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr_nc, flags=re.S).group(1)
+        declared = []
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if not stmt:
+                continue
+            first = True
+            for part in stmt.split(","):
+                toks = re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part.split("[")[0])
+                declared.append(toks[-1])
+                first = False
+        assert declared == fields, (cname, declared, fields)
+        lines.append('printf("%%zu\\n", sizeof(%s));' % cname)
+        lines += ['printf("%%zu\\n", offsetof(%s, %s));' % (cname, f) for f in fields]
+    lines.append("return 0;}")
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "egovlp_hip.h"\nint main(void){\n'
-                   'printf("%zu\\n", sizeof(egv_gemm_desc));\n'
-                   + "".join('printf("%%zu\\n", offsetof(egv_gemm_desc, %s));\n' % f for f in fields)
-                   + "return 0;}\n")
+    src.write_text("\n".join(lines) + "\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert out[0] == ctypes.sizeof(GemmDesc)
-    assert out[1:] == [getattr(GemmDesc, f).offset for f in fields]
+    i = 0
+    for cname, pyname in ABI_STRUCTS.items():
+        mirror = getattr(_lib, pyname)
+        fields = [f[0] for f in mirror._fields_]
+        assert out[i] == ctypes.sizeof(mirror), (cname, out[i], ctypes.sizeof(mirror))
+        assert out[i + 1:i + 1 + len(fields)] == [getattr(mirror, f).offset for f in fields], cname
+        i += 1 + len(fields)
 
 
 def test_product_raises_without_gpu_tensors():

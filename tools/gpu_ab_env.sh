@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $O; REPS=$2; shift; shift
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg"
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg --no-dp-leg"
 for rep in $(seq 1 $REPS); do
   for spec in "$@"; do
     E="${spec%%--*}"; F="${spec#*--}"; [ "$F" == "$spec" ] && F=""

@@ -7,7 +7,7 @@ if [ -n "$K" ]; then
   ( timeout 1200 python -m pytest tests -m gpu -q -x -k "$K" 2>&1 | grep -v "amdgpu\|^$" | tail -40 ) > $O/pytest_subset.txt 2>&1
   tail -3 $O/pytest_subset.txt
 fi
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg"
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg --no-dp-leg"
 for rep in 1 2 3; do
   for sfx in "$@"; do
     L=egovlp_amd/libegovlp_hip.so; [ "$sfx" != "main" ] && L=egovlp_amd/libegovlp_hip_$sfx.so
@@ -17,7 +17,7 @@ for rep in 1 2 3; do
 done
 cat $O/ab.txt
 rm -rf /tmp/prof_ab
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ab -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg --wgrad-side 0 ) > $O/prof.log 2>&1
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ab -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg --no-dp-leg --wgrad-side 0 ) > $O/prof.log 2>&1
 f=$(find /tmp/prof_ab -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python tools/trace_stats.py $f 3 $O/kernel_stats_timed_mixed.csv >> $O/prof.log 2>&1
 head -30 $O/kernel_stats_timed_mixed.csv | cut -c1-150

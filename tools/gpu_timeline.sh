@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; mkdir -p $O
 rm -rf /tmp/prof_tl
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg ) > $O/prof.log 2>&1
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-fast-mode --no-trajectory --no-h2d-leg --no-dp-leg ) > $O/prof.log 2>&1
 f=$(find /tmp/prof_tl -name "*kernel_trace.csv" | head -1)
 head -1 $f > $O/header.txt
 python tools/timeline.py $f 24 30 > $O/timeline.txt 2>&1
