@@ -26,6 +26,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime initi
 import torch
 import torch.distributed as dist
 
+import ctypes
+_libc = ctypes.CDLL(None)     # fflush(NULL): native code (RCCL) writes to stdout through C stdio
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -603,6 +606,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+        # RCCL prints a version banner through C stdio on stdout when its first communicator comes up: this leg's stdout goes to
+        # stderr, so that the ONE JSON line stays the only thing on stdout
+        sys.stdout.flush()
+        _libc.fflush(None)
+        saved_fd1 = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         os.environ["EGV_FORCE_GATHER"] = "1"
         use_dist = True
@@ -625,8 +634,13 @@ def main():
         dist.destroy_process_group()
         use_dist = False
         ec.reset_side_streams()
+        sys.stdout.flush()
+        _libc.fflush(None)
+        os.dup2(saved_fd1, 1)
+        os.close(saved_fd1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    _libc.fflush(None)        # anything native code buffered on stdout (RCCL's banner at N > 1) goes out BEFORE the line
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

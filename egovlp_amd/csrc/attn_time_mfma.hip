@@ -139,6 +139,34 @@ __device__ __forceinline__ void store4(bf16_t* __restrict__ ph, bf16_t* __restri
 #endif
 }
 
+// ---- output rows through LDS (round 5).  A lane of an output tile owns 4 channels of ONE token row (8 bytes of each plane): stored
+// directly, a wave instruction wrote 16 x 32-byte segments of 16 different 128-byte rows, four instructions per row and plane.  The
+// 16 x 64 tile of a plane is staged in the wave's own LDS instead (the image layout: 128-B rows, 16-B chunk XOR (row & 7); LDS
+// operations of a wave execute in order, so no barrier) and leaves as whole rows: lane -> (row 8 it + (l >> 3), chunk l & 7), one
+// 16-byte store per lane, 8 lanes per 128-byte row.  -DEGV_TMF_OLD_STORES: the direct 8-byte stores (A/B builds).
+__device__ __forceinline__ void stage4(char* sh, char* sl, int p, int col, const f32x4_t& v, float scale) {
+  uint32_t h0, h1, l0, l1;
+  split_bf16x2(v[0] * scale, v[1] * scale, h0, l0);
+  split_bf16x2(v[2] * scale, v[3] * scale, h1, l1);
+  const int off = att_off(p, col);
+  *(u32x2_t*)(sh + off) = (u32x2_t){h0, h1};
+  if (sl) *(u32x2_t*)(sl + off) = (u32x2_t){l0, l1};
+}
+// rows of the staged tile -> plane rows: element offset of row r = (tok0 + row_token(r)) * ts + col0
+template <int TP, int SITE>
+__device__ __forceinline__ void flush_rows(const char* sh, const char* sl, bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long tok0, long ts,
+                                           long col0, int T, int n, int i0, int lane) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = 8 * it + (lane >> 3), chunk = lane & 7;
+    if (!row_valid<TP>(row, T, n, i0)) continue;
+    const long o = (tok0 + row_token<TP>(row, T, n, i0)) * ts + col0 + chunk * 8;
+    const int lo = row * ATT_ROW_BYTES + ((chunk ^ (row & 7)) << 4);
+    egv_store<SITE>(ph + o, *(const u32x4_t*)(sh + lo));
+    if (pl) egv_store<SITE>(pl + o, *(const u32x4_t*)(sl + lo));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------ forward
 template <int PASSES, int TP>
 __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql, int B, int T,
@@ -147,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
   constexpr int NPL = PASSES == 3 ? 2 : 1;
   constexpr int LOCS = 16 / TP;                      // locations per wave
   constexpr int WAVE_LDS = NPL * 2 * IMG17;          // Q and K images; the V image (NPL * IMG20, smaller or equal... see static_assert) reuses the space
-  static_assert(NPL * IMG20 <= WAVE_LDS + 1024, "");
+  static_assert(NPL * IMG20 + NPL * 2048 <= WAVE_LDS + 1024, "V images + the output staging rows");
   __shared__ __attribute__((aligned(128))) char smem[4][WAVE_LDS + 1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int units = (n + LOCS - 1) / LOCS;
@@ -265,9 +293,16 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
     o0 = att_mma<PASSES>(ah, al, b0h, b0l, o0);
     o1 = att_mma<PASSES>(ah, al, b1h, b1l, o1);
+#ifdef EGV_TMF_OLD_STORES
     if (qv) store4(out_hi, out_lo, otok * HD + (long)h * HD64 + 16 * c + 4 * g, o0, inv0);
+#else
+    stage4(base + NPL * IMG20, PASSES == 3 ? base + NPL * IMG20 + 2048 : nullptr, p, 16 * c + 4 * g, o0, inv0);
+#endif
     if (cls_col) *(f32x4_t*)(w + 16 * c + 4 * g) = o1;
   }
+#ifndef EGV_TMF_OLD_STORES
+  flush_rows<TP, EGV_NT_ATTN_OUT>(base + NPL * IMG20, base + NPL * IMG20 + 2048, out_hi, PASSES == 3 ? out_lo : nullptr, (long)b * S, HD, (long)h * HD64, T, n, i0, lane);
+#endif
   if (g == 0 && qv && lse) lse[((long)b * H + h) * S + row_token<TP>(p, T, n, i0)] = m0 + __logf(l0);
   if (g == 0 && cls_col) {
     w[64] = m1;
@@ -412,6 +447,43 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
     }
     const long gtok = ((long)b * S + ptok) * ts + (long)h * HD64;
     const bool cls_col = p < LOCS;                                  // columns of the CLS query's partial (masked columns hold zeros)
+#ifndef EGV_TMF_OLD_STORES
+    // dQ, dK, dV one after the other through the (no longer needed) V images as staging rows; whole 128-byte rows out (flush_rows)
+    char* const sth = base + 3 * IMG20;
+    char* const stl = PASSES == 3 ? base + (3 * IMG20 + IMG17) + 3 * IMG20 : nullptr;
+    static_assert(IMG17 >= 2048, "");
+    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8_t kth = frag_rows20(kim[0], 16 * c, lane), ktl = PASSES == 3 ? frag_rows20(kim[LO], 16 * c, lane) : kth;
+      const f32x4_t dq = att_mma<PASSES>(kth, ktl, dq0h, dq0l, z);      // rows = channels 16c + 4g + j, columns = frame queries
+      const f32x4_t dqc = att_mma<PASSES>(kth, ktl, dq1h, dq1l, z);     // columns c < LOCS: the CLS query's partials, one per location
+      stage4(sth, stl, p, 16 * c + 4 * g, dq, 0.125f);
+      if (cls_col) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&red[wave][16 * c + 4 * g + j], dqc[j]);
+      }
+    }
+    flush_rows<TP, EGV_NT_TIME_BWD>(sth, stl, gh, gl, (long)b * S, ts, (long)h * HD64, T, n, i0, lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8_t qth = frag_rows20(qim[0], 16 * c, lane), qtl = PASSES == 3 ? frag_rows20(qim[LO], 16 * c, lane) : qth;
+      const f32x4_t dk = att_mma<PASSES>(qth, qtl, dk0h, dk0l, z);      // columns = frame keys
+      const f32x4_t dkc = att_mma<PASSES>(qth, qtl, dk1h, dk1l, z);     // column 0: the CLS key's partial
+      stage4(sth, stl, p, 16 * c + 4 * g, dk, 0.125f);
+      if (p == 0) *(f32x4_t*)&red[wave][64 + 16 * c + 4 * g] = dkc;
+    }
+    flush_rows<TP, EGV_NT_TIME_BWD>(sth, stl, gh, gl, (long)b * S, ts, (long)h * HD64 + HD, T, n, i0, lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8_t gth = frag_rows20(gim[0], 16 * c, lane), gtl = PASSES == 3 ? frag_rows20(gim[LO], 16 * c, lane) : gth;
+      const f32x4_t dv = att_mma<PASSES>(gth, gtl, pv0h, pv0l, z);
+      const f32x4_t dvc = att_mma<PASSES>(gth, gtl, pv1h, pv1l, z);
+      stage4(sth, stl, p, 16 * c + 4 * g, dv, 1.0f);
+      if (p == 0) *(f32x4_t*)&red[wave][128 + 16 * c + 4 * g] = dvc;
+    }
+    flush_rows<TP, EGV_NT_TIME_BWD>(sth, stl, gh, gl, (long)b * S, ts, (long)h * HD64 + 2 * HD, T, n, i0, lane);
+#else
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bf16x8_t kth = frag_rows20(kim[0], 16 * c, lane), ktl = PASSES == 3 ? frag_rows20(kim[LO], 16 * c, lane) : kth;
@@ -439,6 +511,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
         *(f32x4_t*)&red[wave][128 + 16 * c + 4 * g] = dvc;
       }
     }
+#endif
   }
   __syncthreads();
   for (int x = threadIdx.x; x < 192; x += 64 * WPB) {

@@ -64,6 +64,9 @@ def main():
                     help="ONE fp16 product for one op kind (and unions) on top of the f16x2 mode (VERDICT r04 next-1a)")
     ap.add_argument("--per-block-fp16", action="store_true",
                     help="fc2 in ONE fp16 product in every block, fc1 in ONE fp16 product in a subset of the blocks")
+    ap.add_argument("--sensitivity", action="store_true", help="ONE op kind (qkv / fc1 / fc2) in ONE block in one fp16 product, everything else f16x2")
+    ap.add_argument("--policy", nargs="*", default=[], metavar="K_FC2,K_FC1,K_QKV",
+                    help="the op runs ONE fp16 product from that block on, two before (egovlp_amd.ops.single_product_policy: depth / 4 each)")
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
     if a.threads:
@@ -111,6 +114,25 @@ def main():
             te, ve, l = run(sd, batch, vcfg, Policy(default="bf16x3", **pol))
             print(f"{'fc2 x1 everywhere, fc1 x1 in: ' + label:58s} {rel(te, rt):10.2e} {rel(ve, rv):10.2e} {abs(l - rl):10.2e}   {time.time() - t0:.0f}",
                   flush=True)
+    x2 = dict(qkv="fp16x2:6", fc1="fp16x2:6", fc2="fp16x2:6")
+    if a.sensitivity:
+        te, ve, l = run(sd, batch, vcfg, Policy(default="bf16x3", **x2))
+        print(f"# {a.config}: base f16x2 video {rel(ve, rv):.3e}", flush=True)
+        for op in ("qkv", "fc1", "fc2"):
+            for b in range(0, vcfg.depth, 1 if vcfg.depth <= 12 else 2):
+                pol = dict(x2)
+                pol[f"{op}@{b}"] = "fp16"
+                te, ve, l = run(sd, batch, vcfg, Policy(default="bf16x3", **pol))
+                print(f"{op}@{b:<3d} video {rel(ve, rv):.3e} dloss {abs(l - rl):.2e}", flush=True)
+    for spec in a.policy:
+        k2, k1, kq = [int(x) for x in spec.split(",")]
+        pol = dict(x2)
+        for op, k in (("fc2", k2), ("fc1", k1), ("qkv", kq)):
+            for b in range(k, vcfg.depth):
+                pol[f"{op}@{b}"] = "fp16"
+        te, ve, l = run(sd, batch, vcfg, Policy(default="bf16x3", **pol))
+        print(f"{a.config}: one fp16 product from block fc2 >= {k2}, fc1 >= {k1}, qkv >= {kq} (two products before; bf16x3 elsewhere):  "
+              f"text {rel(te, rt):.2e} video {rel(ve, rv):.2e} dloss {abs(l - rl):.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -12,8 +12,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egovlp_amd import ops  # noqa: E402
 
-passes_list = [int(sys.argv[1])] if len(sys.argv) > 1 else [3, 1]
-bwd_passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+_MAIN = __name__ == "__main__"
+passes_list = [int(sys.argv[1])] if _MAIN and len(sys.argv) > 1 else [3, 1]
+bwd_passes = int(sys.argv[2]) if _MAIN and len(sys.argv) > 2 else 1
 EPI = os.environ.get("BENCH_EPI", "real")
 SINGLE = int(os.environ.get("BENCH_SINGLE", "0"))
 M = int(os.environ.get("BENCH_TOKENS", 32 * 785))
