@@ -14,6 +14,7 @@
 // the B operand of the next MFMA without any cross-lane movement.
 #pragma once
 #include "common.h"
+#include "f16x2.h"
 
 #define ATT_D 64
 #define ATT_ROW_BYTES 128
@@ -153,6 +154,13 @@ __device__ __forceinline__ f32x4_t att_mma(bf16x8_t ah, bf16x8_t al, bf16x8_t bh
 //  MODE_TEXT : separate q,k,v [B,L,H*64]; group = (b, h); nq = nk = L; key j masked if mask[b,j] == 0
 enum { MODE_SPACE = 0, MODE_TEXT = 2 };
 
+// one output pair in the two plane formats of the attention forward: hi = bf16 pair; lo = the bf16 residual pair (fmt 0) or the fp16
+// pair of the VALUES (fmt 1: the proj Linear behind this attention runs ONE fp16 product, egv_divided_attn_fwd mode bit 1)
+__device__ __forceinline__ void att_out2(float a, float b, int fmt, uint32_t& hi, uint32_t& lo) {
+  split_bf16x2(a, b, hi, lo);
+  if (fmt) lo = f16x2_pack((_Float16)f16x2_clamp(a), (_Float16)f16x2_clamp(b));
+}
+
 struct AttGeom {
   const float* q;    // MODE_TEXT: fp32 sources
   const float* k;
@@ -165,6 +173,8 @@ struct AttGeom {
   const long long* mask;  // MODE_TEXT only
   EgvDrop drop;           // MODE_TEXT only: attention-probability dropout (thresh == 0: none); element index
                           // ((b * H + h) * S + query) * S + key
+  int out_fmt;            // format of the output's second plane: 0 = the bf16 residual (split planes); 1 = fp16(value) -- the
+                          // operand of a single-fp16-product proj GEMM (the hi plane stays bf16(value) for the backward)
 };
 
 template <int MODE>

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         uint32_t h0, h1, l0, l1;
-        split_bf16x2(o[df][0] * inv, o[df][1] * inv, h0, l0);
-        split_bf16x2(o[df][2] * inv, o[df][3] * inv, h1, l1);
+        att_out2(o[df][0] * inv, o[df][1] * inv, g.out_fmt, h0, l0);
+        att_out2(o[df][2] * inv, o[df][3] * inv, g.out_fmt, h1, l1);
         const int d = df * 16 + 4 * gq;
         egv_store<EGV_NT_SPACE_ATTN>(oh + d, (u32x2_t){h0, h1});
         if (ol) egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         uint32_t h0, h1, l0, l1;
-        split_bf16x2(o[df][0] * inv, o[df][1] * inv, h0, l0);
-        split_bf16x2(o[df][2] * inv, o[df][3] * inv, h1, l1);
+        att_out2(o[df][0] * inv, o[df][1] * inv, g.out_fmt, h0, l0);
+        att_out2(o[df][2] * inv, o[df][3] * inv, g.out_fmt, h1, l1);
         const int d = df * 16 + 4 * gq;
         egv_store<EGV_NT_SPACE_ATTN>(oh + d, (u32x2_t){h0, h1});
         egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
@@ -290,7 +290,10 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
                float* cls_ws, hipStream_t s) {
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NKF * 16 * ATT_ROW_BYTES + NKF * 16 * sizeof(float);
-  if constexpr (MODE == MODE_SPACE && NKF == 14) {   // measured on ViT-B/16 (13 query tiles on 16 waves): 137 -> 130 us
+#ifndef EGV_STREAM18
+#define EGV_STREAM18 0      // A/B builds: the streaming kernel for ViT-L/14's 257-key groups as well (17 query tiles on 16 waves: two rounds)
+#endif
+  if constexpr (MODE == MODE_SPACE && (NKF == 14 || (NKF == 18 && EGV_STREAM18))) {   // measured on ViT-B/16 (13 query tiles on 16 waves): 137 -> 130 us
     if (passes == 3 && ol != nullptr) {
       auto kern = attn_fwd_stream3_kernel<NKF>;
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -330,8 +333,9 @@ static int dispatch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, b
 }
 
 int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, int T, int n, int H, int passes,
-                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, hipStream_t s) {
+                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, int out_fmt, hipStream_t s) {
   AttGeom g;
+  g.out_fmt = out_fmt;
   const long HD = (long)H * ATT_D;
   g.q = g.k = g.v = nullptr;
   g.ph = qkv_hi;
@@ -351,6 +355,7 @@ extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v,
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   if (passes == 3 && !out_lo) return EGV_ERR_ARG;
   AttGeom g;
+  g.out_fmt = 0;
   const long HD = (long)H * ATT_D;
   g.q = q; g.k = k; g.v = v;
   g.ph = g.pl = nullptr;

@@ -7,6 +7,7 @@
 // (Rounds 1 - 3 also had the vector-ALU time-attention kernels in this file; they lost to the matrix-core kernels at every T --
 // T = 4 in-step: 835 -> 846 pairs/s, profiles/r04n_* -- and were removed in round 4.)
 #include "common.h"
+#include "f16x2.h"
 #include "egovlp_hip.h"
 
 namespace {
@@ -19,7 +20,7 @@ constexpr int D = 64;
 // one LDS round merges the subs.
 __global__ __launch_bounds__(256) void attn_cls_combine_kernel(const float* __restrict__ ws, int G, int S, int H,
                                                               bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
-                                                              float* __restrict__ lse) {
+                                                              float* __restrict__ lse, int out_fmt) {
   __shared__ float sm[16], sl[16], so[16][64];
   const int t = threadIdx.x;
   const int sub = t >> 4, c4 = (t & 15) * 4;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void attn_cls_combine_kernel(const float* __re
     oo /= ll;
     bf16_t hh, lo2;
     split_bf16(oo, hh, lo2);
+    if (out_fmt) lo2 = __builtin_bit_cast(unsigned short, (_Float16)f16x2_clamp(oo));      // second plane = fp16(value)
     const long off = (long)b * S * H * D + (long)h * D + t;
     out_hi[off] = hh;
     if (out_lo) out_lo[off] = lo2;
@@ -103,14 +105,14 @@ __global__ __launch_bounds__(64) void attn_cls_finish_kernel(const float* __rest
 }  // namespace
 
 int egv_attn_time_mfma_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
-                                float* ws, hipStream_t s);
+                                float* ws, int out_fmt, hipStream_t s);
 int egv_attn_time_mfma_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
                                 const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s);
 
 int egv_attn_time_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol,
-                           float* lse, float* ws, hipStream_t s) {
+                           float* lse, float* ws, int out_fmt, hipStream_t s) {
   if (T > 16) return EGV_ERR_ARG;
-  return egv_attn_time_mfma_fwd_impl(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
+  return egv_attn_time_mfma_fwd_impl(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
 }
 
 int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
@@ -120,9 +122,9 @@ int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh
   return egv_attn_time_mfma_bwd_impl(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
 }
 
-int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse,
+int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse, int out_fmt,
                               hipStream_t s) {
-  EGV_LAUNCH(attn_cls_combine_kernel, dim3(B * H), dim3(256), 0, s, ws, G, S, H, oh, ol, lse);
+  EGV_LAUNCH(attn_cls_combine_kernel, dim3(B * H), dim3(256), 0, s, ws, G, S, H, oh, ol, lse, out_fmt);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

@@ -124,10 +124,10 @@ __device__ __forceinline__ f32x4_t mma2(const bf16x8_t (&ah)[2], const bf16x8_t 
   return att_mma<PASSES>(ah[1], al[1], bh[1], bl[1], c);
 }
 
-__device__ __forceinline__ void store4(bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long off, const f32x4_t& v, float scale) {
+__device__ __forceinline__ void store4(bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long off, const f32x4_t& v, float scale, int fmt = 0) {
   uint32_t h0, h1, l0, l1;
-  split_bf16x2(v[0] * scale, v[1] * scale, h0, l0);
-  split_bf16x2(v[2] * scale, v[3] * scale, h1, l1);
+  att_out2(v[0] * scale, v[1] * scale, fmt, h0, l0);
+  att_out2(v[2] * scale, v[3] * scale, fmt, h1, l1);
 #if defined(EGV_TMF_DBG) && EGV_TMF_DBG >= 1      // diagnostics build: everything but the plane stores
   asm volatile("" ::"v"(h0), "v"(h1), "v"(l0), "v"(l1));
 #elif defined(EGV_TMF_NT)
@@ -144,10 +144,10 @@ __device__ __forceinline__ void store4(bf16_t* __restrict__ ph, bf16_t* __restri
 // 16 x 64 tile of a plane is staged in the wave's own LDS instead (the image layout: 128-B rows, 16-B chunk XOR (row & 7); LDS
 // operations of a wave execute in order, so no barrier) and leaves as whole rows: lane -> (row 8 it + (l >> 3), chunk l & 7), one
 // 16-byte store per lane, 8 lanes per 128-byte row.  -DEGV_TMF_OLD_STORES: the direct 8-byte stores (A/B builds).
-__device__ __forceinline__ void stage4(char* sh, char* sl, int p, int col, const f32x4_t& v, float scale) {
+__device__ __forceinline__ void stage4(char* sh, char* sl, int p, int col, const f32x4_t& v, float scale, int fmt = 0) {
   uint32_t h0, h1, l0, l1;
-  split_bf16x2(v[0] * scale, v[1] * scale, h0, l0);
-  split_bf16x2(v[2] * scale, v[3] * scale, h1, l1);
+  att_out2(v[0] * scale, v[1] * scale, fmt, h0, l0);
+  att_out2(v[2] * scale, v[3] * scale, fmt, h1, l1);
   const int off = att_off(p, col);
   *(u32x2_t*)(sh + off) = (u32x2_t){h0, h1};
   if (sl) *(u32x2_t*)(sl + off) = (u32x2_t){l0, l1};
@@ -171,7 +171,7 @@ __device__ __forceinline__ void flush_rows(const char* sh, const char* sl, bf16_
 template <int PASSES, int TP>
 __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql, int B, int T,
                                                                  int n, int H, bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
-                                                                 float* __restrict__ lse, float* __restrict__ cls_ws) {
+                                                                 float* __restrict__ lse, float* __restrict__ cls_ws, int out_fmt) {
   constexpr int NPL = PASSES == 3 ? 2 : 1;
   constexpr int LOCS = 16 / TP;                      // locations per wave
   constexpr int WAVE_LDS = NPL * 2 * IMG17;          // Q and K images; the V image (NPL * IMG20, smaller or equal... see static_assert) reuses the space
@@ -294,9 +294,9 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
     o0 = att_mma<PASSES>(ah, al, b0h, b0l, o0);
     o1 = att_mma<PASSES>(ah, al, b1h, b1l, o1);
 #ifdef EGV_TMF_OLD_STORES
-    if (qv) store4(out_hi, out_lo, otok * HD + (long)h * HD64 + 16 * c + 4 * g, o0, inv0);
+    if (qv) store4(out_hi, out_lo, otok * HD + (long)h * HD64 + 16 * c + 4 * g, o0, inv0, out_fmt);
 #else
-    stage4(base + NPL * IMG20, PASSES == 3 ? base + NPL * IMG20 + 2048 : nullptr, p, 16 * c + 4 * g, o0, inv0);
+    stage4(base + NPL * IMG20, PASSES == 3 ? base + NPL * IMG20 + 2048 : nullptr, p, 16 * c + 4 * g, o0, inv0, out_fmt);
 #endif
     if (cls_col) *(f32x4_t*)(w + 16 * c + 4 * g) = o1;
   }
@@ -526,14 +526,14 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
 
 template <int TP>
 static int launch_fwd(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse, float* ws,
-                      hipStream_t s) {
+                      int out_fmt, hipStream_t s) {
   constexpr int LOCS = 16 / TP;
   const long waves = (long)B * ((n + LOCS - 1) / LOCS) * H;
   const dim3 grid((unsigned)((waves + 3) / 4));
   if (ql)
-    EGV_LAUNCH((attn_time_mfma_fwd_kernel<3, TP>), grid, dim3(256), 0, s, qh, ql, B, T, n, H, oh, ol, lse, ws);
+    EGV_LAUNCH((attn_time_mfma_fwd_kernel<3, TP>), grid, dim3(256), 0, s, qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt);
   else
-    EGV_LAUNCH((attn_time_mfma_fwd_kernel<1, TP>), grid, dim3(256), 0, s, qh, ql, B, T, n, H, oh, ol, lse, ws);
+    EGV_LAUNCH((attn_time_mfma_fwd_kernel<1, TP>), grid, dim3(256), 0, s, qh, ql, B, T, n, H, oh, ol, lse, ws, 0);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
@@ -554,10 +554,10 @@ static int launch_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, con
 }
 
 int egv_attn_time_mfma_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
-                                float* ws, hipStream_t s) {
-  if (T <= 4) return launch_fwd<4>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
-  if (T <= 8) return launch_fwd<8>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
-  return launch_fwd<16>(qh, ql, B, T, n, H, oh, ol, lse, ws, s);
+                                float* ws, int out_fmt, hipStream_t s) {
+  if (T <= 4) return launch_fwd<4>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
+  if (T <= 8) return launch_fwd<8>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
+  return launch_fwd<16>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
 }
 
 int egv_attn_time_mfma_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,

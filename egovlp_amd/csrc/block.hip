@@ -52,7 +52,7 @@ bool geom_ok(const egv_block_geom& g) {
   if (g.B <= 0 || g.T <= 0 || g.n <= 0 || g.H <= 0 || g.D != g.H * 64 || g.Hd <= 0 || g.D % 32 || g.Hd % 32) return false;
   if (g.fwd_passes < 1 || g.fwd_passes > 3 || (g.bwd_passes != 1 && g.bwd_passes != 3) || g.bwd_passes > g.fwd_passes) return false;
   if (g.fwd_passes == 2 && (g.bwd_passes != 1 || (g.train && !g.z_bf16))) return false;   // f16x2 forward: single-pass bf16 backward
-  if (g.f16_single < 0 || g.f16_single > 7 || (g.f16_single && g.fwd_passes != 2)) return false;
+  if (g.f16_single < 0 || g.f16_single > 15 || (g.f16_single && g.fwd_passes != 2)) return false;
   return true;
 }
 
@@ -208,6 +208,8 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   for (int i = 0; i < 6; ++i)
     if (!p.w_hi[i] || (P != 1 && !p.w_lo[i])) return EGV_ERR_ARG;
   const int P_fc1 = (g.f16_single & 1) ? 4 : P, P_fc2 = (g.f16_single & 2) ? 4 : P, P_qkv = (g.f16_single & 4) ? 4 : P;   // 4: ONE fp16 product
+  const bool proj1 = (g.f16_single & 8) != 0;      // proj Linears: ONE fp16 product on the attention's fp16(value) plane (its second output plane)
+  const int amode = proj1 ? 2 : 0;
   char* A = (char*)arena;
   // LayerNorm -> operand planes of the qkv / fc1 Linears: split-bf16, or f16x2 (first-operand role, + the bf16 copy the backward reads)
   auto ln = [&](const float* in, const float* gw, const float* gb, egv_bf16* y_hi, egv_bf16* y_lo, int64_t bf_off, float* mean, float* rstd) -> int {
@@ -232,9 +234,10 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
     d.bias = p.bias[0]; d.out_hi = qt_hi; d.out_lo = qt_lo; d.ldoh = 3 * D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
-  EGV_TRY(egv_divided_attn_fwd(qt_hi, qt_lo, g.B, g.T, g.n, g.H, 1, Pa, at_hi, at_lo, at<float>(A, L.lse_t), at<float>(A, L.work_t), stream));
+  EGV_TRY(egv_divided_attn_fwd(qt_hi, qt_lo, g.B, g.T, g.n, g.H, 1 | amode, Pa, at_hi, at_lo, at<float>(A, L.lse_t), at<float>(A, L.work_t), stream));
   {
-    egv_gemm_desc d = nt_desc(at_hi, at_lo, D, p.w_hi[1], p.w_lo[1], p.ldw[1], M, D, D, Pa, g.grid_cap);
+    egv_gemm_desc d = proj1 ? nt_desc(at_lo, nullptr, D, p.w_hi[1], p.w_lo[1], p.ldw[1], M, D, D, 4, g.grid_cap)
+                            : nt_desc(at_hi, at_lo, D, p.w_hi[1], p.w_lo[1], p.ldw[1], M, D, D, Pa, g.grid_cap);
     d.bias = p.bias[1]; d.residual = x; d.ldr = D; d.out_f32 = tr; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
@@ -245,9 +248,10 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
     d.bias = p.bias[2]; d.out_hi = qs_hi; d.out_lo = qs_lo; d.ldoh = 3 * D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
-  EGV_TRY(egv_divided_attn_fwd(qs_hi, qs_lo, g.B, g.T, g.n, g.H, 0, Pa, as_hi, as_lo, at<float>(A, L.lse_s), at<float>(A, L.work_s), stream));
+  EGV_TRY(egv_divided_attn_fwd(qs_hi, qs_lo, g.B, g.T, g.n, g.H, 0 | amode, Pa, as_hi, as_lo, at<float>(A, L.lse_s), at<float>(A, L.work_s), stream));
   {
-    egv_gemm_desc d = nt_desc(as_hi, as_lo, D, p.w_hi[3], p.w_lo[3], p.ldw[3], M, D, D, Pa, g.grid_cap);
+    egv_gemm_desc d = proj1 ? nt_desc(as_lo, nullptr, D, p.w_hi[3], p.w_lo[3], p.ldw[3], M, D, D, 4, g.grid_cap)
+                            : nt_desc(as_hi, as_lo, D, p.w_hi[3], p.w_lo[3], p.ldw[3], M, D, D, Pa, g.grid_cap);
     d.bias = p.bias[3]; d.residual = x; d.ldr = D; d.out_f32 = sr; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
@@ -302,7 +306,9 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   fpl(F.qkvt_hi, F.qkvt_lo, qt_hi, qt_lo); fpl(F.qkvs_hi, F.qkvs_lo, qs_hi, qs_lo);
   // the attention backward takes the forward output's lo plane whenever the forward wrote one, also in a single-pass backward
   // (delta = rowsum(dO o O) exact in O: egv_divided_attn_bwd)
-  const egv_bf16 *as_lo_f = at<egv_bf16>(FA, F.as_lo), *at_lo_f = at<egv_bf16>(FA, F.at_lo);
+  // (not when that plane holds fp16(value) for a single-product proj, egv_block_geom.f16_single bit 3: delta then comes from the bf16 plane)
+  const bool proj1 = (g.f16_single & 8) != 0;
+  const egv_bf16 *as_lo_f = proj1 ? nullptr : at<egv_bf16>(FA, F.as_lo), *at_lo_f = proj1 ? nullptr : at<egv_bf16>(FA, F.at_lo);
   const float *tr = at<float>(FA, F.tr), *sr = at<float>(FA, F.sr);
   float* grads = io.grads;
 

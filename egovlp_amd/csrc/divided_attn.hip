@@ -6,17 +6,17 @@
 #include "egovlp_hip.h"
 
 int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, int T, int n, int H, int passes,
-                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, hipStream_t s);
+                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, int out_fmt, hipStream_t s);
 int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* out_hi, const bf16_t* out_lo,
                             const bf16_t* do_hi, const bf16_t* do_lo,
                             const float* lse, float* delta, float* dcls, int B, int T, int n, int H, int passes,
                             bf16_t* dqkv_hi, bf16_t* dqkv_lo, hipStream_t s);
 int egv_attn_time_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol,
-                           float* lse, float* ws, hipStream_t s);
+                           float* lse, float* ws, int out_fmt, hipStream_t s);
 int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
                            const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls,
                            hipStream_t s);
-int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse,
+int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse, int out_fmt,
                               hipStream_t s);
 int egv_attn_cls_delta_impl(const bf16_t* oh, const bf16_t* ol, const bf16_t* doh, const bf16_t* dol, int B, int S, int H,
                             float* delta, float* dcls, hipStream_t s);
@@ -36,17 +36,19 @@ extern "C" int egv_divided_attn_fwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_
   if (!qkv_hi || !out_hi || !lse || !work || B <= 0 || T <= 0 || n <= 0 || H <= 0) return EGV_ERR_ARG;
   if (passes != 1 && passes != 3) return EGV_ERR_ARG;
   if (passes == 3 && (!out_lo || !qkv_lo)) return EGV_ERR_ARG;
+  if (mode < 0 || mode > 3) return EGV_ERR_ARG;
+  const int out_fmt = (mode >> 1) & 1;           // mode bit 1: the second output plane holds fp16(value) instead of the bf16 residual
+  mode &= 1;
+  if (out_fmt && passes != 3) return EGV_ERR_ARG;
   if (passes == 1) { qkv_lo = nullptr; out_lo = nullptr; }
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (mode == 0)
-    rc = egv_attn_space_fwd_impl(qkv_hi, qkv_lo, B, T, n, H, passes, out_hi, out_lo, lse, work, s);
-  else if (mode == 1)
-    rc = egv_attn_time_fwd_impl(qkv_hi, qkv_lo, B, T, n, H, out_hi, out_lo, lse, work, s);
+    rc = egv_attn_space_fwd_impl(qkv_hi, qkv_lo, B, T, n, H, passes, out_hi, out_lo, lse, work, out_fmt, s);
   else
-    return EGV_ERR_ARG;
+    rc = egv_attn_time_fwd_impl(qkv_hi, qkv_lo, B, T, n, H, out_hi, out_lo, lse, work, out_fmt, s);
   if (rc) return rc;
-  return egv_attn_cls_combine_impl(work, B, mode == 0 ? T : n, 1 + T * n, H, out_hi, out_lo, lse, s);
+  return egv_attn_cls_combine_impl(work, B, mode == 0 ? T : n, 1 + T * n, H, out_hi, out_lo, lse, out_fmt, s);
 }
 
 extern "C" int egv_divided_attn_bwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, const egv_bf16* out_hi,

@@ -136,8 +136,9 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         wf = "f16x2" if fx2 else "bf16"
         if not fx2:
             single = 0
-        s_fc1, s_fc2, s_qkv = bool(single & 1), bool(single & 2), bool(single & 4)
-        P_qkv, P_fc1, P_fc2 = (4 if s_qkv else P), (4 if s_fc1 else P), (4 if s_fc2 else P)
+        s_fc1, s_fc2, s_qkv, s_proj = bool(single & 1), bool(single & 2), bool(single & 4), bool(single & 8)
+        P_qkv, P_fc1, P_fc2, P_proj = (4 if s_qkv else P), (4 if s_fc1 else P), (4 if s_fc2 else P), (4 if s_proj else Pa)
+        wp = "f16x2" if s_proj else "bf16"       # a single-product proj multiplies fp16(W) (plane 1 of the f16x2 encoding)
 
         def W(p, fmt="bf16"):
             return wc.get(p, need_t=False, fmt=fmt)[0]
@@ -146,16 +147,16 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P, want_bf=train, single=s_qkv)
         qkv_t = ops.empty_planes(M, 3 * D, Pa, dev)      # qkv never exists in fp32: the attention kernels read planes
         ops.gemm_nt(n3, W(tqkv_w, wf), passes=P_qkv, bias=tqkv_b, out_planes=qkv_t, ec=ec)
-        a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, Pa)
+        a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, Pa, out_f16=s_proj)
         tr = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(a_t, W(tproj_w), passes=Pa, bias=tproj_b, residual=x2, out_f32=tr, ec=ec)
+        ops.gemm_nt(a_t, W(tproj_w, wp), passes=P_proj, bias=tproj_b, residual=x2, out_f32=tr, ec=ec)
         # ---- spatial attention branch (:168-171)
         n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P, want_bf=train, single=s_qkv)
         qkv_s = ops.empty_planes(M, 3 * D, Pa, dev)
         ops.gemm_nt(n1, W(sqkv_w, wf), passes=P_qkv, bias=sqkv_b, out_planes=qkv_s, ec=ec)
-        a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, Pa)
+        a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, Pa, out_f16=s_proj)
         sr = torch.empty((M, D), dtype=torch.float32, device=dev)
-        ops.gemm_nt(a_s, W(sproj_w), passes=Pa, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
+        ops.gemm_nt(a_s, W(sproj_w, wp), passes=P_proj, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
         # ---- MLP (:175, Mlp.forward :46-52), exact-erf GELU fused into the fc1 epilogue
         n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P, want_bf=train, single=s_fc1)
         h = ops.empty_planes_f16x2(M, Hd, dev, want_bf=train, single=s_fc2) if fx2 else ops.empty_planes(M, Hd, P, dev)
@@ -252,7 +253,7 @@ def _block_geom(B, T, n, H, D, Hd, P, Pb, train, z_bf16, single, eps, grid):
 _X2_FMTS = ("f16x2", "bf16", "f16x2", "bf16", "f16x2", "f16x2")     # f16x2 mode: qkv / fc1 / fc2 weights in the f16x2 format, proj split-bf16
 
 
-def _block_params(wc, ln, biases, weights, need_t, x2=False):
+def _block_params(wc, ln, biases, weights, need_t, x2=False, proj_x2=False):
     """egv_block_params from the parameter tensors: LayerNorm affine (n3w, n3b, n1w, n1b, n2w, n2b), the six biases and the
     cached operand planes of the six weights (W^T planes too when `need_t`).  The planes are refreshed IN PLACE after an optimizer
     step, so the struct stays the same from step to step: it is kept on the model's weight cache, keyed by the block's first weight
@@ -260,9 +261,11 @@ def _block_params(wc, ln, biases, weights, need_t, x2=False):
     import ctypes as C
     from .._lib import BlockParams
     P6, L6 = C.c_void_p * 6, C.c_int64 * 6
-    pls = [wc.get(w, need_t=need_t, fmt=(_X2_FMTS[i] if x2 else "bf16")) for i, w in enumerate(weights)]
+    # proj_x2: the proj Linears run one fp16 product in this block -- their forward weights are f16x2 encodings too
+    fmts = [("f16x2" if (proj_x2 and i in (1, 3)) else _X2_FMTS[i]) if x2 else "bf16" for i in range(6)]
+    pls = [wc.get(w, need_t=need_t, fmt=fmts[i]) for i, w in enumerate(weights)]
     small = tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in biases)
-    key = (id(weights[0]), need_t, x2)
+    key = (id(weights[0]), need_t, x2, proj_x2)
     hit = wc.param_structs.get(key)
     if hit is not None and hit[1] == small and all(a[0] is b[0] and a[1] is b[1] for a, b in zip(hit[0], pls)):
         return hit[2]
@@ -312,7 +315,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         ln = (n3w, n3b, n1w, n1b, n2w, n2b)
         biases = (tqkv_b, tproj_b, sqkv_b, sproj_b, fc1_b, fc2_b)
         weights = (tqkv_w, tproj_w, sqkv_w, sproj_w, fc1_w, fc2_w)
-        prm = _block_params(ec.wc, ln, biases, weights, need_t=False, x2=P == 2)
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=False, x2=P == 2, proj_x2=bool(single & 8))
         _lib.check(_lib.lib().egv_block_fwd(C.byref(g), C.byref(prm), x2.data_ptr(), out.data_ptr(), arena.data_ptr(), ops._stream(x2)),
                    "egv_block_fwd")
         if train:
@@ -383,7 +386,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
                     t.record_stream(st)
         if used:
             ec.hold_until_join(ctx.arena, barena)               # the multi-GB arenas: held until the join instead (see there)
-        prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2)
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2, proj_x2=bool(single & 8))
         P6 = C.c_void_p * 6
         io = BlockBwdIO(G.data_ptr(), g_hi, g_lo, x2.data_ptr(), ctx.arena.data_ptr(), barena.data_ptr(),
                         d_x.data_ptr(), dx_pl.hi.data_ptr(), dx_pl.lo.data_ptr() if dx_pl.lo is not None else None, grads.data_ptr(),

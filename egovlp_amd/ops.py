@@ -44,7 +44,7 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # injected in the first blocks is amplified by everything behind it, so the policy is "op X runs single-product from block k_X on"
 # (setting `f16_single`, see single_product_policy and profiles/r05_precision_table.txt).
 _PASSES = {"bf16x3": 3, "bf16": 1, "f16x2": 2}
-F16_SINGLE_BITS = {"fc1": 1, "fc2": 2, "qkv": 4}
+F16_SINGLE_BITS = {"fc1": 1, "fc2": 2, "qkv": 4, "proj": 8}
 _PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16x2"}
 _HARD_DEFAULTS = {
     "fwd_passes": 3, "bwd_passes": 3,
@@ -79,13 +79,13 @@ _HARD_DEFAULTS = {
 
 
 def single_product_policy(depth):
-    """-> {"fc2": k, "fc1": k, "qkv": k}: the op runs ONE fp16 product in blocks [k, depth), two before.  k = depth / 4: the first
-    quarter of the tower keeps two products.  profiles/r05_precision_table.txt (CPU oracle, operands rounded as the hardware rounds
-    them; video-embedding error of the whole model against fp32): a single-product Linear costs (0.65 .. 0.9)e-4 in the later blocks
-    but 2.4e-4 (fc1 / fc2) .. 9.4e-4 (qkv) in block 0, and the contributions add in quadrature -- with k = depth / 4: ViT-B/16 T = 4
-    4.4e-4, T = 16 4.0e-4, ViT-L/14 3.6e-4 (north_star's bar: 1e-3; text tower untouched, 2.7e-5)."""
-    k = -(-depth // 4)
-    return {"fc2": k, "fc1": k, "qkv": k}
+    """-> {"fc2": k, "fc1": k, "qkv": k, "proj": k2}: the op runs ONE fp16 product in blocks [k, depth); before that qkv / fc1 / fc2
+    run two fp16 products (f16x2) and proj three bf16 products.  k = depth / 4, k2 = depth / 2.  profiles/r05_precision_table.txt
+    (CPU oracle, operands rounded as the hardware rounds them; video-embedding error of the whole model against fp32): a
+    single-product Linear costs (0.65 .. 0.9)e-4 in the later blocks but 2.4e-4 (fc1 / fc2) .. 9.4e-4 (qkv) in block 0, and the
+    contributions add in quadrature -- with this policy: ViT-B/16 T = 4 4.7e-4, T = 16 4.5e-4, ViT-L/14 4.0e-4 (north_star's bar:
+    1e-3; text tower untouched, 2.7e-5)."""
+    return {"fc2": -(-depth // 4), "fc1": -(-depth // 4), "qkv": -(-depth // 4), "proj": -(-depth // 2)}
 
 
 def parse_f16_single(spec, depth):
@@ -495,6 +495,8 @@ class Planes:
     cols: int                        # logical columns (<= ld)
     fmt: str = "bf16"                # 'bf16' (split planes), 'f16x2' (include/egovlp_hip.h: egv_f16x2_encode; role: first / second operand)
                                      # or 'f16' (ONE plane of plain fp16 in `hi`, lo = None: the first operand of a single-fp16-product GEMM)
+                                     # or 'bf16+f16' (attention output ahead of a single-product proj: hi = bf16(value) for the backward,
+                                     # lo = fp16(value), the GEMM's operand)
     bf: Optional[torch.Tensor] = None  # fmt 'f16x2' / 'f16' only: bf16(value) [rows, ld], what the single-pass backward GEMMs read
 
     @property
@@ -502,15 +504,23 @@ class Planes:
         return self.hi.stride(0)
 
     def float(self):
+        if self.fmt == "bf16+f16":
+            return self.lo[:, : self.cols].float()
         v = self.hi[:, : self.cols].float()
         if self.lo is not None and self.fmt == "bf16":
             v = v + self.lo[:, : self.cols].float()
         return v
 
+    def f16_plane(self):
+        """The plain-fp16 plane a single-product GEMM (passes == 4) reads."""
+        return self.hi if self.fmt == "f16" else self.lo
+
     def bwd(self):
         """The operand view the backward GEMMs take: the planes themselves, or the bf16 copy of an f16x2 operand."""
         if self.fmt == "bf16":
             return self
+        if self.fmt == "bf16+f16":
+            return Planes(self.hi, None, self.rows, self.cols)
         if self.bf is None:
             raise ValueError("this fp16 operand was produced without its bf16 plane (forward outside a training step)")
         return Planes(self.bf, None, self.rows, self.cols)
@@ -619,8 +629,9 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
     # passes 4: ONE fp16 product -- A a plain fp16 plane ('f16'), B the weight's f16x2 encoding (its plane 1 IS fp16(W))
-    if (a.fmt == "f16x2") != (passes == 2) or (a.fmt == "f16") != (passes == 4) or b.fmt != ("f16x2" if passes in (2, 4) else "bf16"):
+    if (a.fmt == "f16x2") != (passes == 2) or (a.fmt in ("f16", "bf16+f16")) != (passes == 4) or b.fmt != ("f16x2" if passes in (2, 4) else "bf16"):
         raise ValueError(f"gemm_nt: operand formats {a.fmt} / {b.fmt} do not go with passes = {passes}")
+    a_hi = a.f16_plane() if passes == 4 else a.hi
     out_fmt = 0
     if out_planes is not None and out_planes.fmt != "bf16":
         out_fmt = 2 if out_planes.fmt == "f16" else 1
@@ -637,7 +648,7 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device) if ksplit > 1 else None
     # one positional construction (the field order of egv_gemm_desc): 30 attribute stores cost ~6 us of host time per GEMM,
     # and the step issues 296 of them
-    d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, K, passes, alpha, act, _p(bias),
+    d = GemmDesc(_p(a_hi), (None if passes == 4 else _p(a.lo)), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, K, passes, alpha, act, _p(bias),
                  _p(residual), (residual.stride(0) if residual is not None else 0),
                  _p(aux_in), _p(aux_out), (aux.stride(0) if aux is not None else 0),
                  _p(out_f32), (out_f32.stride(0) if out_f32 is not None else 0),
@@ -921,13 +932,20 @@ def assemble_tokens_bwd(dx, B, T, n, D, T_model):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes):
-    """qkv planes [B*S, 3*H*64] (the qkv GEMM's out_planes) -> (Planes [B*S, H*64], lse [B,H,S])."""
+def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes, out_f16=False):
+    """qkv planes [B*S, 3*H*64] (the qkv GEMM's out_planes) -> (Planes [B*S, H*64], lse [B,H,S]).
+    out_f16 (passes == 3): the second output plane holds fp16(value) instead of the bf16 residual (Planes fmt 'bf16+f16'): the
+    operand of a single-fp16-product proj Linear."""
     S = 1 + T * n
     dev = qkv.hi.device
     out = empty_planes(B * S, H * 64, passes, dev)
+    if out_f16:
+        if passes != 3:
+            raise ValueError("divided_attn_fwd: the fp16 output plane takes the place of the lo plane of a three-pass forward")
+        out = Planes(out.hi, out.lo.view(torch.float16), out.rows, out.cols, "bf16+f16")
+        mode = mode | 2
     lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
-    work = torch.empty(_cached_size("attn_fwd", B, T, n, H, mode), dtype=torch.float32, device=dev)
+    work = torch.empty(_cached_size("attn_fwd", B, T, n, H, mode & 1), dtype=torch.float32, device=dev)
     check(_lib.lib().egv_divided_attn_fwd(_p(qkv.hi), _p(qkv.lo), B, T, n, H, mode, passes, _p(out.hi), _p(out.lo),
                                           _p(lse), _p(work), _stream(qkv.hi)), "egv_divided_attn_fwd")
     return out, lse
@@ -939,7 +957,8 @@ def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, m
     dev = qkv.hi.device
     dqkv = empty_planes(B * S, 3 * H * 64, passes, dev)
     work = torch.empty(_cached_size("attn_bwd", B, T, n, H), dtype=torch.float32, device=dev)
-    check(_lib.lib().egv_divided_attn_bwd(_p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out.lo), _p(d_out.hi), _p(d_out.lo),
+    out_lo = out.lo if out.fmt == "bf16" else None      # an fp16(value) plane is not a residual: delta comes from the bf16 plane alone
+    check(_lib.lib().egv_divided_attn_bwd(_p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out_lo), _p(d_out.hi), _p(d_out.lo),
                                           _p(lse), B, T, n, H, mode, passes, _p(dqkv.hi), _p(dqkv.lo), _p(work),
                                           _stream(qkv.hi)), "egv_divided_attn_bwd")
     return dqkv

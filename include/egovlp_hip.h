@@ -141,7 +141,9 @@ typedef struct egv_block_geom {
   int32_t f16_single;   /* fwd_passes == 2 only: which Linears of THIS block run ONE fp16 product (egv_gemm_nt passes == 4) instead of
                            the two of the f16x2 format -- bit 0: fc1 (norm2 then writes one plain fp16 plane), bit 1: fc2 (the GELU
                            epilogue of fc1 then writes h as one plain fp16 plane), bit 2: both qkv Linears (norm3 / norm1 write one
-                           plain fp16 plane).  0 elsewhere.  Which blocks may is the caller's precision policy.        */
+                           plain fp16 plane), bit 3: both proj Linears (the attention kernels write fp16(value) as their second
+                           output plane; w_hi[1] / w_hi[3] are then the weights' f16x2 encodings like those of the other single-
+                           product Linears).  0 elsewhere.  Which blocks may is the caller's precision policy.        */
 } egv_block_geom;
 typedef struct egv_block_params {                 /* weight index: 0 timeattn.qkv, 1 timeattn.proj, 2 attn.qkv, 3 attn.proj, 4 fc1, 5 fc2 */
   const float *n3w, *n3b, *n1w, *n1b, *n2w, *n2b; /* LayerNorm affine (norm3 = temporal, norm1 = spatial, norm2 = MLP)              */
@@ -253,9 +255,12 @@ int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, int32_t n, in
  * planes (exactly what the qkv GEMM epilogue writes; qkv_lo is ignored / may be NULL when passes == 1).
  * S = 1 + T*n, token order 1 + f*n + i.  q is scaled by 64^-0.5 inside.  mode 0 = space (group = (b,f,h): n queries x
  * (CLS + n) keys, bf16 MFMA, scores never leave LDS / registers), mode 1 = time (group = (b,i,h): T queries x (CLS + T)
- * keys, VALU fp32).  The CLS query row (attends to all S keys, :112) rides in every group as an extra query; its
+ * keys, bf16 MFMA as well).  The CLS query row (attends to all S keys, :112) rides in every group as an extra query; its
  * partials are merged by a small combine kernel.  Output: split planes [B, S, H*64]; lse [B, H, S] (log-sum-exp of each
- * query row, saved for backward).  `work`: egv_divided_attn_fwd_work_floats(...) floats.                            */
+ * query row, saved for backward).  `work`: egv_divided_attn_fwd_work_floats(...) floats.
+ * mode bit 1 (mode = 2 space, 3 time; passes == 3 only): out_lo receives fp16(value) instead of the bf16 residual -- the first
+ * operand of a proj Linear that runs ONE fp16 product (egv_gemm_nt passes == 4 with a_hi = this plane); out_hi stays bf16(value),
+ * which is what the backward reads (egv_divided_attn_bwd then takes out_lo = NULL).                                     */
 int egv_divided_attn_fwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, int32_t B, int32_t T, int32_t n, int32_t H,
                          int32_t mode, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, float* work,
                          void* stream);

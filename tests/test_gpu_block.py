@@ -74,12 +74,13 @@ def test_block_calls_equal_the_per_kernel_path(mode, side, geom):
     assert exact["mlp.fc2.weight"] and exact["mlp.fc2.bias"] and exact["mlp.fc1.weight"], exact     # upstream of any atomics
 
 
-@pytest.mark.parametrize("policy", ["none", "fc2:0", "fc1:0,fc2:0", "qkv:0", "fc2:0,fc1:0,qkv:0"])
+@pytest.mark.parametrize("policy", ["none", "fc2:0", "fc1:0,fc2:0", "qkv:0", "proj:0", "fc2:0,fc1:0,qkv:0,proj:0"])
 @pytest.mark.parametrize("geom", [(8, 4, 196), (2, 16, 196)])
 def test_block_calls_equal_the_per_kernel_path_in_the_fp16_modes(policy, geom):
     """The same comparison for the fp16-product forwards: 'f16x2' (policy "none": two fp16 products in qkv / fc1 / fc2) and the
-    per-block single-product choices of 'f16mix' (egv_block_geom.f16_single: ONE fp16 product in fc2 / fc1 / both qkv Linears, their
-    first operand one plain fp16 plane).  Backward: single-pass bf16 on the bf16 copies."""
+    per-block single-product choices of 'f16mix' (egv_block_geom.f16_single: ONE fp16 product in fc2 / fc1 / both qkv / both proj
+    Linears, their first operand one plain fp16 plane -- for proj the attention kernels' second output plane).  Backward: single-pass
+    bf16 on the bf16 copies."""
     from egovlp_amd import ops
     B, T, n = geom
     D = 768
@@ -101,7 +102,11 @@ def test_block_calls_equal_the_per_kernel_path_in_the_fp16_modes(policy, geom):
     def rel(a, b):
         return float((a.double() - b.double()).norm() / b.double().norm())
     diffs = {"dx": rel(dx_c, dx_k), **{k: rel(gr_c[k], gr_k[k]) for k in gr_k}}
-    assert all(v < 1e-4 for v in diffs.values()), diffs
+    print("fp16 block, policy %s: block calls vs per-kernel path:" % policy, {k: "%.1e" % v for k, v in diffs.items() if v})
+    # downstream of the time attention's CLS-row atomics (norm3, timeattn.qkv) ONE bf16 flip of the single-pass backward is worth
+    # 1.05e-4 / 1.19e-4 on this input (two discrete outcomes, seen on ~40 % of the runs of either path against itself); a wrong
+    # operand shows up at >= 5e-4 (see above)
+    assert all(v < 3e-4 for v in diffs.values()), {k: v for k, v in diffs.items() if v >= 3e-4}
     assert diffs["mlp.fc2.weight"] == 0.0 and diffs["mlp.fc1.weight"] == 0.0, diffs
     # and against the all-bf16x3 forward of the same block: a single-product Linear is 2^-11-grade, the two-product form 2^-17-grade
     ec3 = ops.new_context()

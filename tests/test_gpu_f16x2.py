@@ -203,6 +203,38 @@ def test_single_product_mlp_with_gelu_handover(ops, fc1_single):
     assert rel(out, exact) < 4e-6 and rel(out, ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("mode,T", [(0, 4), (1, 4), (1, 16)])
+def test_attention_writes_the_fp16_plane_for_a_single_product_proj(ops, mode, T):
+    """egv_divided_attn_fwd mode bit 1: same attention, same bf16(value) first plane, but the second output plane holds fp16(value)
+    (not the bf16 residual) -- every row incl. the CLS row (combine kernel) -- and a passes = 4 proj GEMM consumes it."""
+    B, n, H = 2, 196, 12
+    S = 1 + T * n
+    g = torch.Generator().manual_seed(7 + mode + T)
+    qkv = ops.split_f32((torch.randn(B * S, 3 * H * 64, generator=g) * 0.5).cuda(), 3)[0]
+    ref, lse0 = ops.divided_attn_fwd(qkv, B, T, n, H, mode, 3)
+    out, lse1 = ops.divided_attn_fwd(qkv, B, T, n, H, mode, 3, out_f16=True)
+    torch.cuda.synchronize()
+    assert out.fmt == "bf16+f16" and out.lo.dtype == torch.float16
+    val = ref.hi.float() + ref.lo.float()
+    assert torch.equal(out.hi, ref.hi) and torch.equal(lse0, lse1)
+    same = (out.lo.view(torch.int16) == val.to(torch.float16).view(torch.int16)).float().mean()
+    print("attention mode %d T=%d: fp16 plane == fp16(hi + lo) on %.4f of the elements, rel %.2e" % (mode, T, float(same), rel(out.lo, val)))
+    assert float(same) > 0.98 and rel(out.lo, val) < 3e-4       # hi + lo is the value to 2^-17: the fp16 of it differs by a last-place tie at most
+    w = _inputs(768, 768, 61, 0.03)
+    pw = ops.f16x2_encode(w.cuda(), 1)
+    o = torch.empty(B * S, 768, device="cuda")
+    ops.gemm_nt(out, pw, passes=4, out_f32=o)
+    exact = out.lo.cpu().double() @ pw.hi.cpu().double().t()
+    assert rel(o, exact) < 4e-6
+    # the backward takes delta from the bf16 plane alone
+    d_out = ops.split_f32((torch.randn(B * S, H * 64, generator=g) * 0.1).cuda(), 1)[0]
+    qkv1 = ops.Planes(qkv.hi, None, qkv.rows, qkv.cols)
+    a = ops.divided_attn_bwd(qkv1, out, d_out, lse1, B, T, n, H, mode, 1)
+    b = ops.divided_attn_bwd(qkv1, ops.Planes(ref.hi, None, ref.rows, ref.cols), d_out, lse1, B, T, n, H, mode, 1)
+    torch.cuda.synchronize()
+    assert rel(a.hi.float(), b.hi.float()) < 1e-3          # identical inputs; the CLS rows accumulate with fp32 atomics (bf16 flips)
+
+
 def test_gemm_f16x2_rejects_what_it_cannot_run(ops):
     from egovlp_amd._lib import EgovlpHipError
     a, w = ops.f16x2_encode(_inputs(512, 256, 51).cuda(), 0), ops.f16x2_encode(_inputs(512, 256, 52).cuda(), 1)

@@ -580,7 +580,10 @@ def test_padded_patch_embedding_gradient_with_the_wgrad_side_stream():
     assert float(ref.abs().max()) > 0
     for _ in range(3):
         r = rel(grad(True), ref)
-        assert r < 1e-4, r
+        # same kernels, same inputs: what differs is the order of the fp32 atomics of the CLS rows -- one bf16 flip of the single-pass
+        # backward behind them is worth up to 4e-4 on this one-block model (seen once in ~10 runs); the race this test guards against
+        # made the gradient 100 % wrong
+        assert r < 2e-3, r
 
 
 def test_retrieval_heads_match_the_reference_golden(full, golden_dir):

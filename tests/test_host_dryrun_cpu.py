@@ -292,7 +292,7 @@ def test_f16x2_mode_wiring(model):
 
 def test_f16mix_mode_wiring(model):
     """Precision 'f16mix' (the benchmarked mode): the per-block single-product policy reaches the C block calls -- the first quarter of
-    the video blocks keeps two fp16 products (f16_single 0), the rest run fc1 / fc2 / both qkv Linears as ONE (bits 1 | 2 | 4) --, a
+    the video blocks keeps two fp16 products (f16_single 0), the rest run fc1 / fc2 / both qkv Linears as ONE (bits 1 | 2 | 4), the second half both proj Linears as well (bit 8) --, a
     policy string overrides it, 'f16x2' switches it off again; the weights are the same f16x2 planes either way."""
     from egovlp_amd import ops
     from egovlp_amd.model.loss import EgoNCE
@@ -300,7 +300,7 @@ def test_f16mix_mode_wiring(model):
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
     opt = AdamW(model.parameters(), lr=3e-5)
     ec = model.exec_ctx
-    assert ops.single_product_policy(12) == {"fc2": 3, "fc1": 3, "qkv": 3} and ops.single_product_policy(24)["qkv"] == 6
+    assert ops.single_product_policy(12) == {"fc2": 3, "fc1": 3, "qkv": 3, "proj": 6} and ops.single_product_policy(24)["qkv"] == 6
     seen = {}
     with mock_hip() as calls:
         try:
@@ -315,6 +315,6 @@ def test_f16mix_mode_wiring(model):
                 seen[name] = (list(calls.block_single), ec.precision_name())
         finally:
             ec.unset("fwd_passes", "bwd_passes", "f16_single")
-    assert seen["f16mix"] == ([0, 0, 0] + [7] * 9, ("f16mix", "bf16")), seen["f16mix"]
+    assert seen["f16mix"] == ([0, 0, 0] + [7] * 3 + [15] * 6, ("f16mix", "bf16")), seen["f16mix"]
     assert seen["policy"] == ([2] * 6 + [3] * 6, ("f16mix", "bf16")), seen["policy"]
     assert seen["f16x2"] == ([0] * 12, ("f16x2", "bf16")), seen["f16x2"]
