@@ -427,8 +427,25 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       oke = nkt_total;
       return;
     }
-    oz = v / nwg;
-    const int wg = xcd_remap(v - oz * nwg, nwg);
+    int wg;
+#ifndef EGV_TN_OLD_MAP
+    if constexpr (TN) {
+      // k-slices are the outer index of the work ids (id = z nwg + tile): remap the WHOLE id space of a round, so that an XCD (blocks
+      // b % 8 == x) owns a contiguous id range = all tiles of ~one k-slice -- the 9 x 3 tiles of a slice read the same dY / X rows and
+      // share them in that XCD's L2.  (Remapping inside each slice, as for NT, dealt every slice's tiles to all eight XCDs: PMC
+      // FETCH_SIZE 464 MB per qkv wgrad for 154 MB of operands, profiles/r05_gemm_pmc_per_instance.txt.)
+      const int G = (int)gridDim.x;
+      const int r = v / G;
+      const int left = total - r * G;
+      const int w = r * G + xcd_remap(v - r * G, left < G ? left : G);
+      oz = w / nwg;
+      wg = w - oz * nwg;
+    } else
+#endif
+    {
+      oz = v / nwg;
+      wg = xcd_remap(v - oz * nwg, nwg);
+    }
     const int tm = wg / tiles_n;
     otn = wg - tm * tiles_n;
     om0 = min(tm * BM, p.M - BM);      // shifted, never predicated (host guarantees M >= BM, N >= 256)

@@ -71,28 +71,39 @@ def parse(order_path, out_path, csvs):
             for c in grp[0]:
                 if c != "name":
                     ent[c] = sum(g[c] for g in grp) / len(grp)
+    write_table(table, out_path)
+
+
+def write_table(table, out_path):
     with open(out_path, "w") as f:
         def w(s=""):
             f.write(s + "\n")
             print(s)
-        w("# tools/gemm_pmc.py: PMC counters per launch of the gemm_big instances the benchmarked step runs, real epilogues (M = 25 120 tokens)")
-        w("# MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (both summed over SEs); fabric bytes = FETCH_SIZE x 2048 B + WRITE_SIZE x 1024 B")
-        w("# (calibration: profiles/r03_traffic_calibration.json); algo = bf16-algorithmic bytes of the shape (SURVEY 8d: A + B + C as bf16; wgrad: fp32 C)")
-        w(f"{'case':34s} {'instance <MF,TN,EPI,PROD,MIXED>':34s} {'MFMA busy':>9s} {'LDS bank confl / active':>23s} {'fetch MB':>9s} {'write MB':>9s} {'algo MB':>8s} {'ratio':>6s}")
+        w("# tools/gemm_pmc.py: PMC counters per launch of the gemm_big instances the benchmarked step runs, real epilogues (M = 25 120 tokens);")
+        w("# isolated launches on an idle GPU (the wgrads with the full k-slice count of a main-stream launch), mean of the last 2 of 4 launches per case.")
+        w("# MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs (the counter adds up")
+        w("#   the SIMDs' busy cycles: a 16x16x32 MFMA keeps one SIMD busy for 16 cycles, which reproduces 2 M N K x products / 1024 flop per cycle);")
+        w("# MFMA instr = SQ_INSTS_VALU_MFMA_MOPS_{F16,BF16} / 512 (the counter counts 512-flop units; 16x16x32 = 16 384 flop = 32 units... per lane group)")
+        w("# fabric bytes = FETCH_SIZE x 2048 B + WRITE_SIZE x 1024 B (calibration: profiles/r03_traffic_calibration.json; Infinity-Cache hits are counted);")
+        w("# algo = bf16-algorithmic bytes of the shape (SURVEY 8d: A + B + C as bf16; wgrad: bf16 operands + fp32 C); us = kernel cycles / 2.4 GHz (profiler clock, ~5 % above the un-profiled launch)")
+        w(f"{'case':30s} {'instance <MF,TN,EPI,PROD,MIXED>':30s} {'us':>6s} {'MFMA busy':>9s} {'LDS conflict/active':>20s} {'fetch MB':>9s} {'write MB':>9s} {'algo MB':>8s} {'ratio':>6s}")
         for case, e in table.items():
-            busy = e.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")) / max(e.get("SQ_BUSY_CYCLES", float("nan")), 1e-9) if "SQ_BUSY_CYCLES" in e else float("nan")
+            cyc = e.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0
+            busy = e.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")) / (1024.0 * cyc)
             lds = "%.3g / %.3g" % (e.get("SQ_LDS_BANK_CONFLICT", float("nan")), e.get("SQ_LDS_IDX_ACTIVE", float("nan")))
             fe = e.get("FETCH_SIZE", float("nan")) * 2048 / 1e6
             wr = e.get("WRITE_SIZE", float("nan")) * 1024 / 1e6
             m, n, k = e["M"], e["N"], e["K"]
             tn = "wgrad" in case
             algo = (2 * (k * m + k * n) + 4 * m * n if tn else 2 * (m * k + n * k + m * n)) / 1e6
-            w(f"{case:34s} {e.get('instance', '?'):34s} {busy:9.3f} {lds:>23s} {fe:9.1f} {wr:9.1f} {algo:8.1f} {(fe + wr) / algo:6.2f}")
-        json.dump(table, open(out_path.replace(".txt", ".json"), "w"), indent=1)
+            w(f"{case:30s} {e.get('instance', '?'):30s} {cyc / 2400.0:6.1f} {busy:9.3f} {lds:>20s} {fe:9.1f} {wr:9.1f} {algo:8.1f} {(fe + wr) / algo:6.2f}")
+    json.dump(table, open(out_path.replace(".txt", ".json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2])
+    elif sys.argv[1] == "table":          # re-print a saved summary: python tools/gemm_pmc.py table <summary.json> <out.txt>
+        write_table(json.load(open(sys.argv[2])), sys.argv[3])
     else:
         parse(sys.argv[2], sys.argv[3], sys.argv[4:])
