@@ -392,6 +392,7 @@ def main():
         # Cross-checks: the cheapest three consecutive steps of the loop (wall clock, waits included when they happen) and how far
         # ahead of the GPU the host was when it had enqueued the last step.
         per = [(b_ - a_) * 1e3 for a_, b_ in zip(marks, marks[1:])]
+        HOST["per_step_wall_ms"] = [round(x, 1) for x in per]          # host wall time between consecutive enqueues (waits included)
         w = min(3, len(per))
         HOST["enqueue_ms_unthrottled"] = min(sum(per[i:i + w]) / w for i in range(len(per) - w + 1))
         HOST["lead_ms"] = (dt - (marks[-1] - t0)) * 1e3
@@ -512,6 +513,7 @@ def main():
         "host_flow_control_wait_ms_per_step": round(HOST.get("flow_wait_ms_per_step", 0.0), 3),
         "host_enqueue_ms_per_step_unthrottled": round(HOST.get("enqueue_ms_unthrottled", 0.0), 3),
         "host_lead_ms_at_last_enqueue": round(HOST.get("lead_ms", 0.0), 1),
+        "host_wall_ms_between_enqueues": HOST.get("per_step_wall_ms"),
         "step_mfma_frac": None if step_frac is None else round(step_frac, 4),
     }
     if roof is not None:

@@ -291,8 +291,8 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NKF * 16 * ATT_ROW_BYTES + NKF * 16 * sizeof(float);
 #ifndef EGV_STREAM18
-#define EGV_STREAM18 0      // A/B builds: the streaming kernel for ViT-L/14's 257-key groups as well (17 query tiles on 16 waves: two rounds)
-#endif
+#define EGV_STREAM18 1      // the streaming kernel for ViT-L/14's 257-key groups as well (17 query tiles on 16 waves: two rounds, and still
+#endif                      // +0.25 % on config 5 against attn_fwd_kernel<0,18,3>: 234.6 vs 234.0 pairs/s, profiles/r05e_ab_config5_stream18.txt; 0: A/B builds
   if constexpr (MODE == MODE_SPACE && (NKF == 14 || (NKF == 18 && EGV_STREAM18))) {   // measured on ViT-B/16 (13 query tiles on 16 waves): 137 -> 130 us
     if (passes == 3 && ol != nullptr) {
       auto kern = attn_fwd_stream3_kernel<NKF>;

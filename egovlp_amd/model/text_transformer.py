@@ -260,6 +260,9 @@ class _TextLayerCFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         mask, qkv_w, qkv_b, others_w, others_b, ln = saved[0], saved[1:4], saved[4:7], saved[7:10], saved[10:13], saved[13:17]
         g, ec = ctx.g, ctx.ec
+        if ctx.arena is None:
+            raise RuntimeError("the C layer calls release their forward workspace after the first backward: a second backward through "
+                               "the same graph (retain_graph=True) needs the per-kernel path (exec_ctx.set(block_calls=False))")
         if ec.bwd_passes != g.bwd_passes:
             raise RuntimeError("the backward precision changed between this layer's forward and its backward")
         B, L, D = g.B, g.L, g.D

@@ -330,6 +330,9 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         from .._lib import BlockBwdIO
         saved = ctx.saved_tensors
         x2, ln, biases, weights = saved[0], saved[1:7], saved[7:13], saved[13:19]
+        if ctx.arena is None:
+            raise RuntimeError("the C block calls release their forward workspace after the first backward: a second backward through "
+                               "the same graph (retain_graph=True) needs the per-kernel path (exec_ctx.set(block_calls=False))")
         B, T, n, H, D, Hd, P, Pb, train, z_bf16, single = ctx.key
         ec = ctx.ec
         ec.poll_backward()              # gradients of the blocks behind this one are final: the data-parallel exchange may start
@@ -378,14 +381,13 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         d_x = torch.empty((M, D), dtype=torch.float32, device=dev)
         dx_pl = ops.empty_planes(M, D, Pb, dev)
         used = {s_ for s_ in streams if s_ is not None}          # the side streams read / write these allocations of the main stream
-        for st in used:
-            # the handed-over gradient planes are allocations of the block behind this one: BOTH planes (a bf16x3 backward reads the lo
-            # plane in the fc2 weight gradient on a side stream as well)
-            for t in (grads,) + ((g_pl.hi, g_pl.lo) if g_hi is not None else ()):
-                if t is not None:
-                    t.record_stream(st)
         if used:
-            ec.hold_until_join(ctx.arena, barena)               # the multi-GB arenas: held until the join instead (see there)
+            # held until the side streams are joined (end of backward) instead of record_stream-ed: the multi-GB arenas (see
+            # hold_until_join), the gradient buffer, and the gradient planes handed over by the block behind this one -- BOTH planes (a
+            # bf16x3 backward reads the lo plane in the fc2 weight gradient as well).  record_stream leaves an event per block and
+            # stream with the caching allocator, which polls every outstanding event on every allocation: with 24 blocks and a host
+            # that runs two steps ahead that was ~10 ms of host time per ViT-L/14 step (host_enqueue 26 ms against 16 from idle).
+            ec.hold_until_join(ctx.arena, barena, grads, *((g_pl.hi, g_pl.lo) if g_hi is not None else ()))
         prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2, proj_x2=bool(single & 8))
         P6 = C.c_void_p * 6
         io = BlockBwdIO(G.data_ptr(), g_hi, g_lo, x2.data_ptr(), ctx.arena.data_ptr(), barena.data_ptr(),

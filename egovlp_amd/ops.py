@@ -278,9 +278,10 @@ class ExecContext:
         'queued' set and later passes would not queue theirs), and validate / refresh the weight-plane cache once for the step."""
         self._side["queued"] = False
         self._side["load"] = None
-        if not self._side["dirty"]:
-            self._side["held"].clear()        # a backward that raised before its join
-        self._throttle()
+        # a backward that raised before its join leaves the side streams dirty and their workspaces held: wait for them and let go
+        self.join_side_stream()
+        if torch.is_grad_enabled():
+            self._throttle()                  # flow control of the TRAINING loop; evaluation forwards are not throttled
         if self._wc is not None:
             self._wc.begin_step()
 

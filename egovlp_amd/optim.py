@@ -47,8 +47,10 @@ class AdamW(torch.optim.Optimizer):
             _, states, ms, vs, tables, ptrs = plan
             step = states[0]["step"] + 1
             ok = all(p.data_ptr() == q for p, q in zip(params, ptrs))       # `p.data = ...` / `.to()` since the plan was made
-            for st, m in zip(states, ms):
-                ok = ok and st["step"] + 1 == step and st["exp_avg"] is m
+            for p_, st, m, v in zip(params, states, ms, vs):
+                # the cached state dicts must still BE the optimizer's state (a caller may have replaced optimizer.state[p] or one of
+                # the moment tensors without load_state_dict): otherwise the fast path would keep updating orphaned buffers
+                ok = ok and st["step"] + 1 == step and st["exp_avg"] is m and st.get("exp_avg_sq") is v and self.state.get(p_) is st
                 st["step"] += 1
             grads = [p.grad for p in params]
             if ok and not any(g.is_sparse or not g.is_contiguous() for g in grads):

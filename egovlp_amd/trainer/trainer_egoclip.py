@@ -204,6 +204,8 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
                     data['video'] = torch.cat((data['video'], data['video_neg']), axis=0)
                     data['noun_vec'] = torch.cat((data['noun_vec'], data['noun_vec_neg']), axis=0)
                     data['verb_vec'] = torch.cat((data['verb_vec'], data['verb_vec_neg']), axis=0)
+                    for k in ('text_neg', 'video_neg', 'noun_vec_neg', 'verb_vec_neg'):
+                        data.pop(k, None)        # concatenated above: not staged / copied to the device a second time
                 if self.tokenizer is not None:
                     data['text'] = self.tokenizer(data['text'], return_tensors='pt', padding=True, truncation=True)
                 yield batch_idx, dl_idx, data
