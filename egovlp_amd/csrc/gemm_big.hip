@@ -304,7 +304,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   // k-tile barrier the OTHER wave of every SIMD goes straight back to its MFMAs instead of all eight queueing ~9 DMA
   // issues (~60 cycles each) with the matrix pipes idle: main loop 91 -> 81.5 us on fc2-forward (tools/gemm_trace.py).
   // EGV_GEMM_DBG bit 16 restores "every wave stages its own share" (A/B diagnostics).
-  constexpr int DMA_PH = TN ? 0 : 4;     // NT: the DMA of k-tile t+1 is issued over the first 4 phases of k-tile t (see main loop)
+#ifndef EGV_TN_DMA_PH
+#define EGV_TN_DMA_PH 0
+#endif
+  constexpr int DMA_PH = TN ? EGV_TN_DMA_PH : 4;     // NT: the DMA of k-tile t+1 is issued over the first 4 phases of k-tile t (see main loop)
   constexpr bool SPREAD_A = !TN;         // NT: the A fragments of k-step 1 are fetched over phases 0-2 of k-step 0
   const bool loader = wave < 4;
   const int vw0 = 2 * (wave & 3);
