@@ -456,8 +456,12 @@ template <int MODE, int NF>
 int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hipStream_t s) {
   const int planes = passes == 3 ? 4 : 2;
   const size_t lds = (size_t)planes * NF * 16 * ATT_ROW_BYTES + 2 * NF * 16 * sizeof(float);
-  if constexpr (MODE == MODE_SPACE && NF == 14) {     // ViT-B/16: streaming dQ kernel (measured), then the dK/dV kernel
-    if (gr.oh != nullptr) {
+#ifndef EGV_BWD_STREAM18
+#define EGV_BWD_STREAM18 1      // ViT-L/14's 257-key groups on the streaming dQ kernel as well: the register-resident attn_bwd_dq_kernel<0,18,3>
+#endif                          // spills 51 VGPRs (the all-bf16x3 parity mode of config 5 dispatched it); 0: A/B builds
+  if constexpr (MODE == MODE_SPACE && (NF == 14 || (NF == 18 && EGV_BWD_STREAM18))) {     // streaming dQ kernel (measured on ViT-B/16), then the dK/dV kernel
+    if (gr.oh == nullptr) return EGV_ERR_ARG;          // delta = rowsum(dO o O) is taken from the forward's output planes
+    {
       const size_t lds1 = (size_t)planes * NF * 16 * ATT_ROW_BYTES + NF * 16 * sizeof(float);
       if (passes == 3) {
         auto k1 = attn_bwd_dq_stream_kernel<NF, 3>;
@@ -479,7 +483,7 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
       EGV_CHECK_LAUNCH();
       return EGV_OK;
     }
-  }
+  } else {        // (else-branch of the if constexpr: the register-resident dQ kernel is not even instantiated for the streamed sizes)
   if (passes == 3) {
     auto k1 = attn_bwd_dq_kernel<MODE, NF, 3>;
     auto k2 = attn_bwd_dkv_kernel<MODE, NF, 3>;
@@ -500,6 +504,7 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;
+  }
 }
 
 template <int MODE>

@@ -314,11 +314,14 @@ def test_divided_attention_fwd_bwd(ops, passes, mode, B, T, n, H):
 
 
 @pytest.mark.parametrize("passes", [3, 1])
-def test_text_attention_fwd_bwd(ops, passes):
+@pytest.mark.parametrize("L", [32, 50, 100, 257])
+def test_text_attention_fwd_bwd(ops, passes, L):
+    """DistilBERT's masked attention at the benchmarked length (32 tokens) and at the longer padded lengths the tokenizer can produce
+    (<= 64, <= 224, <= 288 keys: the other three kernel sizes)."""
     g = torch.Generator().manual_seed(11)
-    B, L, H = 3, 32, 2
+    B, H = 3, 2
     q, k, v = [torch.randn(B * L, H * 64, generator=g) for _ in range(3)]
-    lens = torch.tensor([32, 9, 20])
+    lens = torch.tensor([L, 9, (2 * L) // 3])
     mask = (torch.arange(L)[None] < lens[:, None]).long()
     out, lse = ops.text_attn_fwd(q.cuda(), k.cuda(), v.cuda(), mask.cuda(), B, L, H, passes)
     qd, kd, vd = [t.double().view(B, L, -1).requires_grad_(True) for t in (q, k, v)]
