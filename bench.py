@@ -620,7 +620,7 @@ def main():
         grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
                                  exchange=args.grad_exchange)
         ec.set(backward_poll=grad_sync.poll, gemm_grid=248)
-        ec.reset_side_streams()                 # one wgrad stream under a process group (ops._wgrad_stream_count)
+        ec.reset_side_streams()
         dt3, loss3 = measure(args.steps, max(args.warmup, 3))
         out["dp_policy_at_world_size_1"] = {
             "value": round(B * args.steps / dt3, 2), "unit": "clip-pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),

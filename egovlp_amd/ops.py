@@ -315,7 +315,7 @@ class ExecContext:
 
     def reset_side_streams(self):
         """Forget the wgrad side streams (after joining them): the next weight gradient re-creates them under the CURRENT policy
-        (ops._wgrad_stream_count: two streams in a single-process run, one as soon as a process group exists)."""
+        (ops._wgrad_stream_count)."""
         self.join_side_stream()
         sd = self._side
         sd["stream"], sd["extra"], sd["load"], sd["events"], sd["rr"] = None, [], None, None, 0
@@ -589,15 +589,16 @@ _WGRAD_KSPLIT_DIV = int(os.environ.get("EGV_WGRAD_KSPLIT_DIV", "0"))   # A/B ove
 
 
 def _wgrad_stream_count():
-    """How many side streams the weight-gradient GEMMs are dealt to (round robin).  TWO in a single-process run: with a third of the
-    k-slices each, two wgrads fit next to each other on the CUs the main stream's kernels leave free (+0.7 .. 0.9 % step rate on
-    three boxes).  ONE as soon as a process group exists: RCCL's and the gradient exchange's streams are in play then, and with a
-    second wgrad stream on top the step collapses from 39 to 48.5 ms (world size 1 under RCCL; three wgrad streams do the same
-    without RCCL; more hardware queues do not help) -- profiles/r03_stream_ab.txt."""
+    """How many side streams the weight-gradient GEMMs are dealt to.  ONE, with half the k-slices of a main-stream launch (wgrad_ksplit).
+    Rounds 3 - 4 used TWO streams with a third of the slices each in single-process runs (+0.7 % then); with the round-5 forward (a
+    shorter main stream) and the XCD-contiguous wgrad mapping that order has turned: one stream / half the slices 997, two streams /
+    half 995, two streams / a third (the old policy) 990 pairs/s, one stream / all slices 980 (same box, interleaved,
+    profiles/r05w_wgrad_stream_policy_ab.txt).  One stream is also what a process group needs (RCCL's and the exchange's streams are
+    in play then: a second wgrad stream next to them collapsed the step from 39 to 48.5 ms, profiles/r03_stream_ab.txt) -- so the
+    N = 1 and the N > 1 step now run the same stream policy.  EGV_WGRAD_STREAMS overrides (A/B runs)."""
     if _WGRAD_STREAMS > 0:
         return _WGRAD_STREAMS
-    import torch.distributed as dist
-    return 1 if (dist.is_available() and dist.is_initialized()) else 2
+    return 1
 
 
 _SIZE_CACHE = {}
