@@ -620,7 +620,8 @@ def main():
         grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
                                  exchange=args.grad_exchange)
         ec.set(backward_poll=grad_sync.poll, gemm_grid=248)
-        ec.reset_side_streams()
+        if args.wgrad_side and len(ec._side["extra"]) + 1 != ops._wgrad_stream_count():
+            ec.reset_side_streams()             # (only when an EGV_WGRAD_STREAMS override made the N = 1 stream count differ)
         dt3, loss3 = measure(args.steps, max(args.warmup, 3))
         out["dp_policy_at_world_size_1"] = {
             "value": round(B * args.steps / dt3, 2), "unit": "clip-pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
@@ -635,7 +636,6 @@ def main():
         torch.cuda.synchronize()
         dist.destroy_process_group()
         use_dist = False
-        ec.reset_side_streams()
         sys.stdout.flush()
         _libc.fflush(None)
         os.dup2(saved_fd1, 1)
