@@ -606,7 +606,6 @@ def main():
         # a link.  No scaling claim: gpurun boxes have one GPU.
         from egovlp_amd.dist import Bf16GradSync
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
         # RCCL prints a version banner through C stdio on stdout when its first communicator comes up: this leg's stdout goes to
         # stderr, so that the ONE JSON line stays the only thing on stdout
@@ -614,32 +613,48 @@ def main():
         _libc.fflush(None)
         saved_fd1 = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        os.environ["EGV_FORCE_GATHER"] = "1"
-        use_dist = True
-        grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
-                                 exchange=args.grad_exchange)
-        ec.set(backward_poll=grad_sync.poll, gemm_grid=248)
-        if args.wgrad_side and len(ec._side["extra"]) + 1 != ops._wgrad_stream_count():
-            ec.reset_side_streams()             # (only when an EGV_WGRAD_STREAMS override made the N = 1 stream count differ)
-        dt3, loss3 = measure(args.steps, max(args.warmup, 3))
-        out["dp_policy_at_world_size_1"] = {
-            "value": round(B * args.steps / dt3, 2), "unit": "clip-pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
-            "loss": round(loss3, 5), "gemm_grid": 248, "wgrad_streams": ops._wgrad_stream_count() if args.wgrad_side else 0,
-            "gradient_exchange": args.grad_exchange, "buckets": int(grad_sync.stats.get("buckets", 0)),
-            "launched_during_backward": int(grad_sync.stats.get("launched_during_backward", 0)),
-            "what": "the N > 1 step policy (RCCL process group, fused all-gather, hook-free bf16 gradient exchange, one wgrad stream, "
-                    "248-workgroup GEMM grid) at world size 1 on this GPU; `value` above is the N = 1 policy"}
-        ec.set(backward_poll=None, gemm_grid=grid)
-        grad_sync = None
-        os.environ.pop("EGV_FORCE_GATHER", None)
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
-        use_dist = False
-        sys.stdout.flush()
-        _libc.fflush(None)
-        os.dup2(saved_fd1, 1)
-        os.close(saved_fd1)
+        pg_up = False
+        try:
+            # a free rendezvous port: a fixed one may still be held by a previous run on this node
+            if "MASTER_PORT" not in os.environ or os.environ["MASTER_PORT"] == "29533":
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            pg_up = True
+            os.environ["EGV_FORCE_GATHER"] = "1"
+            use_dist = True
+            grad_sync = Bf16GradSync(model.parameters(), use_hooks=False, order_hint=model.gradient_ready_order(), exec_ctx=ec,
+                                     exchange=args.grad_exchange)
+            ec.set(backward_poll=grad_sync.poll, gemm_grid=248)
+            if args.wgrad_side and len(ec._side["extra"]) + 1 != ops._wgrad_stream_count():
+                ec.reset_side_streams()         # (only when an EGV_WGRAD_STREAMS override made the N = 1 stream count differ)
+            dt3, loss3 = measure(args.steps, max(args.warmup, 3))
+            out["dp_policy_at_world_size_1"] = {
+                "value": round(B * args.steps / dt3, 2), "unit": "clip-pairs/s", "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+                "loss": round(loss3, 5), "gemm_grid": 248, "wgrad_streams": ops._wgrad_stream_count() if args.wgrad_side else 0,
+                "gradient_exchange": args.grad_exchange, "buckets": int(grad_sync.stats.get("buckets", 0)),
+                "launched_during_backward": int(grad_sync.stats.get("launched_during_backward", 0)),
+                "what": "the N > 1 step policy (RCCL process group, fused all-gather, hook-free bf16 gradient exchange, one wgrad stream, "
+                        "248-workgroup GEMM grid) at world size 1 on this GPU; `value` above is the N = 1 policy"}
+        except Exception as e:          # a secondary leg must never cost the line: report why it is missing
+            out["dp_policy_at_world_size_1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            ec.set(backward_poll=None, gemm_grid=grid)
+            grad_sync = None
+            os.environ.pop("EGV_FORCE_GATHER", None)
+            use_dist = False
+            try:
+                torch.cuda.synchronize()
+                if pg_up:
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            sys.stdout.flush()
+            _libc.fflush(None)
+            os.dup2(saved_fd1, 1)
+            os.close(saved_fd1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     _libc.fflush(None)        # anything native code buffered on stdout (RCCL's banner at N > 1) goes out BEFORE the line
