@@ -162,11 +162,11 @@ def test_eight_rank_step_on_a_toy_model(tmp_path):
 
 @pytest.mark.timeout(900)
 def test_two_rank_step_in_the_benchmarked_mode(tmp_path):
-    """The data-parallel step as bench.py --gpus 2 runs it: precision f16x2 (two-fp16-product forward of the video blocks' Linears,
-    single-pass backward) at a token count where the 12 SpaceTimeBlocks and the 6 DistilBERT layers go through their one-call-per-
+    """The data-parallel step as bench.py --gpus 2 runs it: precision f16mix (fp16-product forward of the video blocks' Linears -- two
+    products in the first quarter of the tower, one behind it --, single-pass backward) at a token count where the 12 SpaceTimeBlocks and the 6 DistilBERT layers go through their one-call-per-
     direction C entry points (B = 8, T = 4 per rank: M = 6 280), buckets leaving from the polls inside the block backward calls."""
     world = 2
-    mp.spawn(_worker, args=(world, 29711, str(tmp_path), "direct", False, 8, ("f16x2",), 4), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29711, str(tmp_path), "direct", False, 8, ("f16mix",), 4), nprocs=world, join=True)
     r = [torch.load(os.path.join(str(tmp_path), f"rank{i}.pt"), weights_only=False) for i in range(world)]
     assert r[0]["w0"] == r[1]["w0"]
     for step in range(2):
