@@ -621,7 +621,8 @@ def main():
                 with socket.socket() as sk:
                     sk.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            import datetime
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=120))
             pg_up = True
             os.environ["EGV_FORCE_GATHER"] = "1"
             use_dist = True
