@@ -156,6 +156,13 @@ __device__ __forceinline__ void stage4(char* sh, char* sl, int p, int col, const
 template <int TP, int SITE>
 __device__ __forceinline__ void flush_rows(const char* sh, const char* sl, bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long tok0, long ts,
                                            long col0, int T, int n, int i0, int lane) {
+  // the tile was written by OTHER lanes of this wave (stage4) with plain C++ stores: LDS operations of a wave execute in order, but
+  // nothing would stop the compiler from moving this lane's reads above another lane's writes -- or the next stage4 (the rows are
+  // reused three times in the backward) above these reads -- if its alias analysis proves per-thread disjointness.  A wave barrier
+  // is a scheduling fence only (no instruction): it pins the order the hardware already keeps.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int row = 8 * it + (lane >> 3), chunk = lane & 7;
@@ -165,6 +172,9 @@ __device__ __forceinline__ void flush_rows(const char* sh, const char* sl, bf16_
     egv_store<SITE>(ph + o, *(const u32x4_t*)(sh + lo));
     if (pl) egv_store<SITE>(pl + o, *(const u32x4_t*)(sl + lo));
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();           // ... and the staging rows may be overwritten only behind these reads
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward

@@ -43,6 +43,7 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # its share of the 1e-3 parity budget allows it: an error injected late in the tower reaches the embedding almost unamplified, one
 # injected in the first blocks is amplified by everything behind it, so the policy is "op X runs single-product from block k_X on"
 # (setting `f16_single`, see single_product_policy and profiles/r05_precision_table.txt).
+_ENV_F16_SINGLE = os.environ.get("EGV_F16_SINGLE", "auto")     # read once: later Precision.set calls of the process agree
 _PASSES = {"bf16x3": 3, "bf16": 1, "f16x2": 2}
 F16_SINGLE_BITS = {"fc1": 1, "fc2": 2, "qkv": 4, "proj": 8}
 _PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16x2"}
@@ -145,15 +146,22 @@ class ExecContext:
             self._s.pop(k, None)
         return self
 
-    def set_precision(self, fwd: str = "bf16x3", bwd: Optional[str] = None):
+    def set_precision(self, fwd: str = "bf16x3", bwd: Optional[str] = None, f16_single=None):
         """'bf16x3' = split-bf16, three MFMA products, fp32-grade (meets the 1e-3 parity bar); 'bf16' = single pass;
         'f16x2' (forward only, with a single-pass 'bf16' backward) = two fp16 products, fp32-grade like 'bf16x3' (3e-5 on the embeddings);
-        'f16mix' = 'f16x2' in the first quarter of the video blocks, ONE fp16 product in their qkv / fc1 / fc2 Linears behind it (4e-4)."""
+        'f16mix' = 'f16x2' in the first quarter of the video blocks, ONE fp16 product in their qkv / fc1 / fc2 Linears behind it and in
+        the proj Linears from the middle of the tower on (4e-4).  `f16_single` ('f16mix' only): an explicit single-product policy
+        ("fc2:3,fc1:3", a dict, "auto"); default: the policy this context already carries if it is a custom one (so that
+        `set_precision(*precision_name())` restores a mode instead of resetting it), else EGV_F16_SINGLE (read ONCE, at import), else "auto"."""
         single = "none"
         if fwd == "f16mix":
             # 'f16mix' (the benchmarked mode of round 5) = 'f16x2' with ONE fp16 product where the parity budget allows it
             # (single_product_policy); EGV_F16_SINGLE overrides the policy (A/B runs: "none", "fc2:0", "fc2:3,fc1:3,qkv:3")
-            fwd, single = "f16x2", os.environ.get("EGV_F16_SINGLE", "auto")
+            cur = self._s.get("f16_single")
+            fwd = "f16x2"
+            single = f16_single if f16_single is not None else (cur if cur not in (None, "none", "", "auto") else _ENV_F16_SINGLE)
+        elif f16_single not in (None, "none", ""):
+            raise ValueError("f16_single is the per-block policy of the 'f16mix' forward")
         bwd = bwd if bwd is not None else ("bf16" if fwd == "f16x2" else fwd)
         if bwd in ("f16x2", "f16mix") or (fwd == "f16x2" and bwd != "bf16"):
             raise ValueError("'f16x2' / 'f16mix' are forward formats; they pair with the single-pass 'bf16' backward")
@@ -183,10 +191,12 @@ class ExecContext:
         """Bit mask (F16_SINGLE_BITS) of the Linears of video block `layer` (of `depth`) that run ONE fp16 product in the f16x2 mode."""
         if layer is None or depth is None:
             return 0
-        key = (self.get("f16_single") if not isinstance(self.get("f16_single"), dict) else id(self.get("f16_single")), depth)
+        spec = self.get("f16_single")
+        # keyed on the CONTENT of the policy (a dict that is mutated or whose id is recycled must not hit a stale entry)
+        key = (tuple(sorted(spec.items())) if isinstance(spec, dict) else spec, depth)
         pol = self._pol_cache.get(key)
         if pol is None:
-            pol = self._pol_cache[key] = parse_f16_single(self.get("f16_single"), depth)
+            pol = self._pol_cache[key] = parse_f16_single(spec, depth)
         m = 0
         for op, k in pol.items():
             if layer >= k:
