@@ -99,8 +99,15 @@ def grad_rel_err(model, loss_fn, data, world, rank, set_precision, mode):
             p_.grad = None
         te, ve = model(data)
         ve, te, n_, v_ = AllGatherFused.apply(ve, te, data["noun_vec"], data["verb_vec"], world, rank)
-        loss_fn.fused(te, ve, n_, v_).backward()
-        return {n: params[n].grad.detach().double().clone() for n in names}
+        loss = loss_fn.fused(te, ve, n_, v_)
+        k = 1.0
+        if model.exec_ctx.bwd_passes == 4:       # the fp16 backward: scaled loss, gradients un-scaled here (AdamW does it in a step)
+            sc = model.exec_ctx.loss_scaler()
+            k = 1.0 / sc.get_scale()
+            loss = sc.scale(loss)
+        loss.backward()
+        model.exec_ctx.join_side_stream()
+        return {n: params[n].grad.detach().double().clone() * k for n in names}
 
     pd, pa = model.text_model.config.dropout, model.text_model.config.attention_dropout
     model.text_model.set_dropout(0.0, 0.0)          # two calls draw different masks: compare the deterministic function
@@ -495,7 +502,10 @@ def main():
                                                    "f16x2": "qkv / fc1 / fc2 of the video blocks 2 x fp16 MFMA (f16x2 operands), proj / attention / "
                                                             "text tower / heads 3 x bf16 MFMA",
                                                    "bf16x3": "3 x bf16 MFMA per product", "bf16": "1 x bf16 MFMA per product"}[ec.precision_name()[0]]
-                                    + "; backward: " + {"bf16x3": "3 x", "bf16": "1 x"}[ec.precision_name()[1]] + " bf16 MFMA per product; fp32 accumulation",
+                                    + "; backward: " + {"bf16x3": "3 x bf16 MFMA per product", "bf16": "1 x bf16 MFMA per product",
+                                                        "f16": "1 x fp16 MFMA per product of the video blocks' Linears on loss-scaled gradients (dynamic scale on the "
+                                                               "device, egovlp_amd.optim.LossScaler), 3 x bf16 in the text tower / patch embedding / heads"
+                                                        }[ec.precision_name()[1]] + "; fp32 accumulation",
                    "text_dropout": args.text_dropout,
                    "streams": {"text_tower_side_stream": bool(args.text_side), "wgrad_side_stream": bool(args.wgrad_side),
                                # what differs between the N = 1 and the N > 1 step: one wgrad stream and a 248-workgroup

@@ -123,6 +123,11 @@ PROTOTYPES = {
     "egv_slice_sum_bf16": (i32, [c_p, i32, i64, c_p, c_p]),
     "egv_relu_split": (i32, [c_p, i64, i32, i32, c_p, c_p, i64, c_p]),
     "egv_version": (i32, []),
+    "egv_abi_check": (i32, [i32, i64, i64, i64, i64]),
+    "egv_split_f32_multi_t16": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "egv_layernorm_bwd_fmt": (i32, [c_p, c_p, c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, i32, c_p, c_p, c_p, c_p]),
+    "egv_grad_nonfinite_multi": (i32, [i32, c_p, c_p, c_p, c_p]),
+    "egv_loss_scale_update": (i32, [c_p, c_p, f32, f32, f32, i32, i32, f32, f32, i32, f32, i32, c_p]),
     "egv_split_f32_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_f16x2_encode": (i32, [c_p, i64, i32, i32, c_p, c_p, c_p, i64, i32, c_p]),
     "egv_f16x2_encode_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i32, c_p]),
@@ -142,6 +147,7 @@ PROTOTYPES = {
     "egv_diag_traffic_calib": (i32, [i32, c_p, c_p, i64, c_p]),
 }
 
+ABI_VERSION = 6      # EGV_ABI_VERSION of the header this binding was written against (include/egovlp_hip.h)
 _lib = None
 
 
@@ -165,6 +171,10 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
+        # a library built from another header (struct layouts, mode / format codes) must fail here, not pass garbage in trailing fields
+        if h.egv_abi_check(ABI_VERSION, C.sizeof(GemmDesc), C.sizeof(BlockGeom), C.sizeof(BlockParams), C.sizeof(BlockBwdIO)) != 0:
+            raise EgovlpHipError(f"{LIB_PATH}: ABI mismatch (library version {h.egv_version()}, binding {ABI_VERSION}, or struct sizes "
+                                 "differ): rebuild with `make -C egovlp_amd/csrc`")
         _lib = h
     return _lib
 

@@ -86,9 +86,22 @@ __device__ __forceinline__ bf16x8_t att_frag_rows(const char* plane, int r0, int
 #endif
 }
 
-// 8 fp32 -> split bf16x8 pair (four v_cvt_pk_bf16_f32 per plane)
+// 8 fp32 -> split bf16x8 pair (four v_cvt_pk_bf16_f32 per plane); F16: the same split in fp16 (hi = fp16(v), lo = fp16(v - hi), NOT
+// saturating: the values are probabilities in [0, 1] or scaled gradients, whose overflow must surface as inf) in the same registers
+template <bool F16 = false>
 __device__ __forceinline__ void att_split8(const float* v, bf16x8_t& hi, bf16x8_t& lo) {
   u32x4_t h, l;
+  if constexpr (F16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const _Float16 h0 = (_Float16)v[2 * e], h1 = (_Float16)v[2 * e + 1];
+      h[e] = f16x2_pack(h0, h1);
+      l[e] = f16x2_pack((_Float16)(v[2 * e] - (float)h0), (_Float16)(v[2 * e + 1] - (float)h1));
+    }
+    hi = __builtin_bit_cast(bf16x8_t, h);
+    lo = __builtin_bit_cast(bf16x8_t, l);
+    return;
+  }
   uint32_t a, b;
   split_bf16x2(v[0], v[1], a, b); h[0] = a; l[0] = b;
   split_bf16x2(v[2], v[3], a, b); h[1] = a; l[1] = b;
@@ -139,13 +152,25 @@ __device__ __forceinline__ void att_gfrag_planes(const bf16_t* ph, const bf16_t*
   if (pl) lo = *(const bf16x8_t*)(pl + o);
 }
 
-template <int PASSES>
+// F16: the operand registers hold fp16 (the fp16 attention of the fp16 backward mode: q / k / v / dO planes, P and dS are fp16 -- 2^-11
+// per operand where bf16 has 2^-8; the three-product form multiplies (hi, lo) fp16 splits, fp32-grade like the bf16 one)
+template <int PASSES, bool F16 = false>
 __device__ __forceinline__ f32x4_t att_mma(bf16x8_t ah, bf16x8_t al, bf16x8_t bh, bf16x8_t bl, f32x4_t c) {
-  if (PASSES == 3) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  if constexpr (F16) {
+    const f16x8_t a0 = __builtin_bit_cast(f16x8_t, ah), a1 = __builtin_bit_cast(f16x8_t, al);
+    const f16x8_t b0 = __builtin_bit_cast(f16x8_t, bh), b1 = __builtin_bit_cast(f16x8_t, bl);
+    if (PASSES == 3) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
+  } else {
+    if (PASSES == 3) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
   }
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
 
 // Geometry of one attention "group" (the rows that attend to each other).
@@ -154,11 +179,44 @@ __device__ __forceinline__ f32x4_t att_mma(bf16x8_t ah, bf16x8_t al, bf16x8_t bh
 //  MODE_TEXT : separate q,k,v [B,L,H*64]; group = (b, h); nq = nk = L; key j masked if mask[b,j] == 0
 enum { MODE_SPACE = 0, MODE_TEXT = 2 };
 
-// one output pair in the two plane formats of the attention forward: hi = bf16 pair; lo = the bf16 residual pair (fmt 0) or the fp16
-// pair of the VALUES (fmt 1: the proj Linear behind this attention runs ONE fp16 product, egv_divided_attn_fwd mode bit 1)
+// one output pair in the plane formats of the attention forward (egv_divided_attn_fwd, mode >> 1):
+//   0  hi = bf16 pair, lo = the bf16 residual pair (split planes: a three-product proj)
+//   1  hi = bf16 pair (what a bf16 backward reads), lo = the fp16 pair of the VALUES (the proj Linear runs ONE fp16 product)
+//   2  the f16x2 operand format, first-operand role (csrc/f16x2.h): hi = a1 = fp16((1 - e) v), lo = a2 = fp16(v - a1) -- a two-product proj
+//      whose backward is fp16 as well (the weight gradient reads a1, the attention backward takes O = a1 / (1 - e))
+//   3  hi = fp16(value), nothing else (the second plane does not exist): one-product proj, fp16 backward
+enum { ATT_OUT_SPLIT = 0, ATT_OUT_BF16_F16 = 1, ATT_OUT_F16X2 = 2, ATT_OUT_F16 = 3, ATT_GRAD_F16 = 4 };
 __device__ __forceinline__ void att_out2(float a, float b, int fmt, uint32_t& hi, uint32_t& lo) {
+  if (fmt == ATT_OUT_F16X2) {
+    _Float16 a1, a2, b1, b2;
+    f16x2_a(a, a1, a2);
+    f16x2_a(b, b1, b2);
+    hi = f16x2_pack(a1, b1);
+    lo = f16x2_pack(a2, b2);
+    return;
+  }
+  if (fmt == ATT_OUT_F16) {
+    hi = lo = f16x2_pack((_Float16)f16x2_clamp(a), (_Float16)f16x2_clamp(b));
+    return;
+  }
+  if (fmt == ATT_GRAD_F16) {       // a scaled gradient of the fp16 backward: ONE plane, NOT saturating (overflow -> inf -> skipped step)
+    hi = lo = f16_grad_pack2(a, b);
+    return;
+  }
   split_bf16x2(a, b, hi, lo);
   if (fmt) lo = f16x2_pack((_Float16)f16x2_clamp(a), (_Float16)f16x2_clamp(b));
+}
+// the forward output O as the backward reads it back (delta = rowsum(dO o O)): one 32-bit word of the first plane (and of the second,
+// fmt 0 only) -> two fp32 values
+__device__ __forceinline__ void att_o_unpack(uint32_t w_hi, uint32_t w_lo, bool has_lo, int fmt, float& x, float& y) {
+  if (fmt == ATT_OUT_F16X2 || fmt == ATT_OUT_F16) {
+    f16x2_unpack(w_hi, x, y);
+    if (fmt == ATT_OUT_F16X2) { x *= (1.0f / (1.0f - F16X2_E)); y *= (1.0f / (1.0f - F16X2_E)); }
+    return;
+  }
+  x = __uint_as_float(w_hi << 16);
+  y = __uint_as_float(w_hi & 0xffff0000u);
+  if (has_lo && fmt == ATT_OUT_SPLIT) { x += __uint_as_float(w_lo << 16); y += __uint_as_float(w_lo & 0xffff0000u); }
 }
 
 struct AttGeom {
@@ -173,8 +231,9 @@ struct AttGeom {
   const long long* mask;  // MODE_TEXT only
   EgvDrop drop;           // MODE_TEXT only: attention-probability dropout (thresh == 0: none); element index
                           // ((b * H + h) * S + query) * S + key
-  int out_fmt;            // format of the output's second plane: 0 = the bf16 residual (split planes); 1 = fp16(value) -- the
-                          // operand of a single-fp16-product proj GEMM (the hi plane stays bf16(value) for the backward)
+  int out_fmt;            // format of the output planes (ATT_OUT_*, see att_out2)
+  int f16;                // MODE_SPACE: the qkv planes (and, backward, the dO planes) hold fp16 -- (hi, lo) = (fp16(x), fp16(x - hi)) -- and
+                          // every product runs on the fp16 MFMA
 };
 
 template <int MODE>

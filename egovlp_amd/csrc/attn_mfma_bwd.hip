@@ -33,12 +33,14 @@ struct AttGrad {
   float* delta;        // [B, H, S] workspace (written by dQ kernel, read by dKV kernel; slot 0 = the CLS row's delta,
                        //  precomputed by egv_attn_cls_delta in MODE_SPACE)
   float* dcls;         // MODE_SPACE: [B, H, 3, 64] fp32 accumulators of the CLS token's raw dq / dk / dv (zeroed first)
+  int o_fmt;           // MODE_SPACE: format of the forward's output planes (attn_common.h ATT_OUT_*)
+  int g_fmt;           // MODE_SPACE: format of the gradient planes: 0 = split-bf16 (hi[, lo]), ATT_GRAD_F16 = ONE plane of un-clamped fp16
 };
 
-__device__ __forceinline__ void store_planes4(bf16_t* hi, bf16_t* lo, long off, f32x4_t v) {
+__device__ __forceinline__ void store_planes4(bf16_t* hi, bf16_t* lo, long off, f32x4_t v, int fmt = 0) {
   uint32_t h0, h1, l0, l1;
-  split_bf16x2(v[0], v[1], h0, l0);
-  split_bf16x2(v[2], v[3], h1, l1);
+  att_out2(v[0], v[1], fmt, h0, l0);
+  att_out2(v[2], v[3], fmt, h1, l1);
   egv_store<EGV_NT_SPACE_ATTN>(hi + off, (u32x2_t){h0, h1});
   if (lo) egv_store<EGV_NT_SPACE_ATTN>(lo + off, (u32x2_t){l0, l1});
 }
@@ -46,7 +48,7 @@ __device__ __forceinline__ void store_planes4(bf16_t* hi, bf16_t* lo, long off, 
 // ------------------------------------------------------------------------------------------------ dQ
 // MODE_SPACE: operands are planes; the clip's CLS query rides as query row n (see attn_mfma_fwd.hip): its L and delta
 // are the GLOBAL ones (lse[b,h,0], delta[b,h,0]); its dq partial over this frame's keys is accumulated atomically.
-template <int MODE, int NKF, int PASSES>
+template <int MODE, int NKF, int PASSES, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const AttGrad gr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKP = NKF * 16;
@@ -114,11 +116,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const
         const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
         bf16x8_t al = ah;
         if (PASSES == 3) al = att_frag_cols(k_lo, kf * 16, ks, lane);
-        s = att_mma<PASSES>(ah, al, qh[ks], ql[ks], s);
+        s = att_mma<PASSES, F16>(ah, al, qh[ks], ql[ks], s);
         const bf16x8_t bh = att_frag_cols(v_hi, kf * 16, ks, lane);
         bf16x8_t bl = bh;
         if (PASSES == 3) bl = att_frag_cols(v_lo, kf * 16, ks, lane);
-        d = att_mma<PASSES>(bh, bl, gh[ks], gl[ks], d);
+        d = att_mma<PASSES, F16>(bh, bl, gh[ks], gl[ks], d);
       }
       const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
       if (MODE == MODE_TEXT && g.drop.thresh != 0u) {
@@ -153,13 +155,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const
         dsv[4 + r] = p[2 * c + 1][r] * (dp[2 * c + 1][r] - delta);
       }
       bf16x8_t sh, sl;
-      att_split8(dsv, sh, sl);
+      att_split8<F16>(dsv, sh, sl);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const bf16x8_t kh = att_frag_rows(k_hi, 32 * c, df * 16, lane);
         bf16x8_t kl = kh;
         if (PASSES == 3) kl = att_frag_rows(k_lo, 32 * c, df * 16, lane);
-        dq[df] = att_mma<PASSES>(kh, kl, sh, sl, dq[df]);
+        dq[df] = att_mma<PASSES, F16>(kh, kl, sh, sl, dq[df]);
       }
     }
     if (SP && qi == g.nq) {
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const
       if (SP) {
 #pragma unroll
         for (int df = 0; df < 4; ++df)
-          store_planes4(gr.gh, gr.gl, tok * gr.tok_stride + hoff + df * 16 + 4 * gq, dq[df] * 0.125f);
+          store_planes4(gr.gh, gr.gl, tok * gr.tok_stride + hoff + df * 16 + 4 * gq, dq[df] * 0.125f, gr.g_fmt);
       } else {
         float* out = gr.dq + tok * gr.tok_stride + hoff;
 #pragma unroll
@@ -189,22 +191,28 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const AttGeom g, const
 // query's dO row with the forward's output row -- so here it is computed up front from the O planes and the keys are walked
 // in 32-key chunks with nothing but the dQ accumulators live: under 128 VGPRs, i.e. two 8-wave workgroups per CU in
 // single-pass mode (the staging of one hides under the tiles of the other) and 16 waves per workgroup in three-pass mode.
-__device__ __forceinline__ float frag_dot8(bf16x8_t ah, bf16x8_t al, bool a_lo, bf16x8_t bh, bf16x8_t bl, bool b_lo) {
+// a = dO (split-bf16), b = O in the format the forward wrote it (b_fmt: ATT_OUT_*)
+template <bool F16 = false>
+__device__ __forceinline__ float frag_dot8(bf16x8_t ah, bf16x8_t al, bool a_lo, bf16x8_t bh, bf16x8_t bl, bool b_lo, int b_fmt) {
   const u32x4_t a0 = __builtin_bit_cast(u32x4_t, ah), a1 = __builtin_bit_cast(u32x4_t, al);
   const u32x4_t b0 = __builtin_bit_cast(u32x4_t, bh), b1 = __builtin_bit_cast(u32x4_t, bl);
   float acc = 0.f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float ax = __uint_as_float(a0[e] << 16), ay = __uint_as_float(a0[e] & 0xffff0000u);
-    float bx = __uint_as_float(b0[e] << 16), by = __uint_as_float(b0[e] & 0xffff0000u);
-    if (a_lo) { ax += __uint_as_float(a1[e] << 16); ay += __uint_as_float(a1[e] & 0xffff0000u); }
-    if (b_lo) { bx += __uint_as_float(b1[e] << 16); by += __uint_as_float(b1[e] & 0xffff0000u); }
+    float ax, ay, bx, by;
+    if constexpr (F16) {
+      f16x2_unpack(a0[e], ax, ay);           // dO as an fp16 plane (the fp16 attention backward)
+    } else {
+      ax = __uint_as_float(a0[e] << 16), ay = __uint_as_float(a0[e] & 0xffff0000u);
+      if (a_lo) { ax += __uint_as_float(a1[e] << 16); ay += __uint_as_float(a1[e] & 0xffff0000u); }
+    }
+    att_o_unpack(b0[e], b1[e], b_lo, b_fmt, bx, by);
     acc += ax * bx + ay * by;
   }
   return acc;
 }
 
-template <int NKF, int PASSES>
+template <int NKF, int PASSES, bool F16 = false>
 __global__ __launch_bounds__(PASSES == 3 ? 1024 : 512) void attn_bwd_dq_stream_kernel(const AttGeom g, const AttGrad gr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKP = NKF * 16;
@@ -241,8 +249,8 @@ __global__ __launch_bounds__(PASSES == 3 ? 1024 : 512) void attn_bwd_dq_stream_k
     }
     const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (tok - grp.tok0);
     const float L = gr.lse[lrow];
-    float delta = frag_dot8(gh[0], gl[0], gr.dol != nullptr, oh[0], ol[0], gr.ol != nullptr) +
-                  frag_dot8(gh[1], gl[1], gr.dol != nullptr, oh[1], ol[1], gr.ol != nullptr);
+    float delta = frag_dot8<F16>(gh[0], gl[0], gr.dol != nullptr, oh[0], ol[0], gr.ol != nullptr, gr.o_fmt) +
+                  frag_dot8<F16>(gh[1], gl[1], gr.dol != nullptr, oh[1], ol[1], gr.ol != nullptr, gr.o_fmt);
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
     if (is_cls) delta = gr.delta[lrow];             // the CLS row's delta spans all frame groups: precomputed
@@ -263,11 +271,11 @@ __global__ __launch_bounds__(PASSES == 3 ? 1024 : 512) void attn_bwd_dq_stream_k
           const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
           bf16x8_t al = ah;
           if (PASSES == 3) al = att_frag_cols(k_lo, kf * 16, ks, lane);
-          sc = att_mma<PASSES>(ah, al, qh[ks], ql[ks], sc);
+          sc = att_mma<PASSES, F16>(ah, al, qh[ks], ql[ks], sc);
           const bf16x8_t bh = att_frag_cols(v_hi, kf * 16, ks, lane);
           bf16x8_t bl = bh;
           if (PASSES == 3) bl = att_frag_cols(v_lo, kf * 16, ks, lane);
-          d = att_mma<PASSES>(bh, bl, gh[ks], gl[ks], d);
+          d = att_mma<PASSES, F16>(bh, bl, gh[ks], gl[ks], d);
         }
         const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
 #pragma unroll
@@ -278,13 +286,13 @@ __global__ __launch_bounds__(PASSES == 3 ? 1024 : 512) void attn_bwd_dq_stream_k
         }
       }
       bf16x8_t sh, sl;
-      att_split8(dsv, sh, sl);
+      att_split8<F16>(dsv, sh, sl);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const bf16x8_t kh = att_frag_rows(k_hi, 32 * c, df * 16, lane);
         bf16x8_t kl = kh;
         if (PASSES == 3) kl = att_frag_rows(k_lo, 32 * c, df * 16, lane);
-        dq[df] = att_mma<PASSES>(kh, kl, sh, sl, dq[df]);
+        dq[df] = att_mma<PASSES, F16>(kh, kl, sh, sl, dq[df]);
       }
     }
     if (qi == g.nq) {
@@ -296,14 +304,14 @@ __global__ __launch_bounds__(PASSES == 3 ? 1024 : 512) void attn_bwd_dq_stream_k
     } else if (qi < g.nq) {
 #pragma unroll
       for (int df = 0; df < 4; ++df)
-        store_planes4(gr.gh, gr.gl, tok * gr.tok_stride + hoff + df * 16 + 4 * gq, dq[df] * 0.125f);
+        store_planes4(gr.gh, gr.gl, tok * gr.tok_stride + hoff + df * 16 + 4 * gq, dq[df] * 0.125f, gr.g_fmt);
       if (gq == 0) gr.delta[lrow] = delta;
     }
   }
 }
 
 // ----------------------------------------------------------------------------------------------- dKV
-template <int MODE, int NQF, int PASSES>
+template <int MODE, int NQF, int PASSES, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttGeom g, const AttGrad gr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NQP = NQF * 16;
@@ -386,11 +394,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttGeom g, cons
           const bf16x8_t ah = att_frag_cols(q_hi, r0, ks, lane);
           bf16x8_t al = ah;
           if (PASSES == 3) al = att_frag_cols(q_lo, r0, ks, lane);
-          s = att_mma<PASSES>(ah, al, kh[ks], kl[ks], s);
+          s = att_mma<PASSES, F16>(ah, al, kh[ks], kl[ks], s);
           const bf16x8_t bh = att_frag_cols(o_hi, r0, ks, lane);
           bf16x8_t bl = bh;
           if (PASSES == 3) bl = att_frag_cols(o_lo, r0, ks, lane);
-          d = att_mma<PASSES>(bh, bl, vh[ks], vl[ks], d);
+          d = att_mma<PASSES, F16>(bh, bl, vh[ks], vl[ks], d);
         }
         const f32x4_t L4 = *(const f32x4_t*)(lse_s + r0 + 4 * gq);
         const f32x4_t D4 = *(const f32x4_t*)(del_s + r0 + 4 * gq);
@@ -406,18 +414,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttGeom g, cons
         }
       }
       bf16x8_t ph, pl, sh, sl;
-      att_split8(pv, ph, pl);
-      att_split8(dsv, sh, sl);
+      att_split8<F16>(pv, ph, pl);
+      att_split8<F16>(dsv, sh, sl);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const bf16x8_t gh = att_frag_rows(o_hi, 32 * c, df * 16, lane);
         bf16x8_t gl = gh;
         if (PASSES == 3) gl = att_frag_rows(o_lo, 32 * c, df * 16, lane);
-        dv[df] = att_mma<PASSES>(gh, gl, ph, pl, dv[df]);
+        dv[df] = att_mma<PASSES, F16>(gh, gl, ph, pl, dv[df]);
         const bf16x8_t qh = att_frag_rows(q_hi, 32 * c, df * 16, lane);
         bf16x8_t ql = qh;
         if (PASSES == 3) ql = att_frag_rows(q_lo, 32 * c, df * 16, lane);
-        dk[df] = att_mma<PASSES>(qh, ql, sh, sl, dk[df]);
+        dk[df] = att_mma<PASSES, F16>(qh, ql, sh, sl, dk[df]);
       }
     }
     if (kj < g.nk) {
@@ -435,8 +443,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttGeom g, cons
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
           const long o = ktok * gr.tok_stride + hoff + df * 16 + 4 * gq;
-          store_planes4(gr.gh, gr.gl, o + HD, dk[df] * 0.125f);
-          store_planes4(gr.gh, gr.gl, o + 2 * HD, dv[df]);
+          store_planes4(gr.gh, gr.gl, o + HD, dk[df] * 0.125f, gr.g_fmt);
+          store_planes4(gr.gh, gr.gl, o + 2 * HD, dv[df], gr.g_fmt);
         }
       } else {
         float* okp = gr.dk + ktok * gr.tok_stride + hoff;
@@ -471,6 +479,14 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
         EGV_LAUNCH(k1, dim3(ngroups), dim3(1024), lds1, s, g, gr);
         EGV_CHECK_LAUNCH();
         EGV_LAUNCH(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+      } else if (g.f16) {
+        auto k1 = attn_bwd_dq_stream_kernel<NF, 1, true>;
+        auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1, true>;
+        (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        EGV_LAUNCH(k1, dim3(ngroups), dim3(512), lds1, s, g, gr);
+        EGV_CHECK_LAUNCH();
+        EGV_LAUNCH(k2, dim3(ngroups), dim3(512), lds, s, g, gr);
       } else {
         auto k1 = attn_bwd_dq_stream_kernel<NF, 1>;
         auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
@@ -492,6 +508,16 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
     EGV_LAUNCH(k1, dim3(ngroups), dim3(256), lds, s, g, gr);
     EGV_CHECK_LAUNCH();
     EGV_LAUNCH(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+  } else if (MODE == MODE_SPACE && g.f16) {
+    if constexpr (MODE == MODE_SPACE) {
+      auto k1 = attn_bwd_dq_kernel<MODE, NF, 1, true>;
+      auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1, true>;
+      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EGV_LAUNCH(k1, dim3(ngroups), dim3(512), lds, s, g, gr);
+      EGV_CHECK_LAUNCH();
+      EGV_LAUNCH(k2, dim3(ngroups), dim3(512), lds, s, g, gr);
+    }
   } else {
     auto k1 = attn_bwd_dq_kernel<MODE, NF, 1>;
     auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
@@ -523,7 +549,7 @@ int dispatch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, h
 int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* out_hi, const bf16_t* out_lo,
                             const bf16_t* do_hi, const bf16_t* do_lo,
                             const float* lse, float* delta, float* dcls, int B, int T, int n, int H, int passes,
-                            bf16_t* dqkv_hi, bf16_t* dqkv_lo, hipStream_t s) {
+                            bf16_t* dqkv_hi, bf16_t* dqkv_lo, int o_fmt, int g_fmt, int f16, hipStream_t s) {
   AttGeom g;
   const long HD = (long)H * ATT_D;
   g.q = g.k = g.v = nullptr;
@@ -534,6 +560,9 @@ int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf
   g.nq = n; g.nk = n + 1;
   g.mask = nullptr;
   g.drop = egv_make_drop(0.f, 0);
+  g.out_fmt = 0;
+  g.f16 = f16;
+  if (f16 && passes != 1) return EGV_ERR_ARG;
   AttGrad gr;
   gr.dq = gr.dk = gr.dv = nullptr;
   gr.gh = dqkv_hi;
@@ -545,6 +574,7 @@ int egv_attn_space_bwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf
   gr.do_stride = HD;
   gr.oh = out_hi; gr.ol = out_lo;                   // [B*S, H*64] planes, same row stride as d_out
   gr.lse = lse; gr.delta = delta; gr.dcls = dcls;
+  gr.o_fmt = o_fmt; gr.g_fmt = g_fmt;
   return dispatch_bwd<MODE_SPACE>(g, gr, B * T * H, passes, s);
 }
 
@@ -565,6 +595,8 @@ extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v,
   if (ldqkv < HD || lddqkv < HD || ldqkv % 4 != 0 || lddqkv % 4 != 0) return EGV_ERR_ARG;
   if (!(dropout_p >= 0.f && dropout_p < 1.f)) return EGV_ERR_ARG;
   g.drop = egv_make_drop(dropout_p, seed, seed_dev);      // the (p, seed, device seed words) of the matching egv_text_attn_fwd call
+  g.out_fmt = 0;
+  g.f16 = 0;
   AttGrad gr;
   gr.dq = dq; gr.dk = dk; gr.dv = dv;
   gr.gh = gr.gl = nullptr;
@@ -572,5 +604,6 @@ extern "C" int egv_text_attn_bwd(const float* q, const float* k, const float* v,
   gr.d_out = d_out; gr.doh = gr.dol = nullptr; gr.do_stride = HD;
   gr.oh = gr.ol = nullptr;
   gr.lse = lse; gr.delta = delta_work; gr.dcls = nullptr;
+  gr.o_fmt = 0; gr.g_fmt = 0;
   return dispatch_bwd<MODE_TEXT>(g, gr, B * H, passes, (hipStream_t)stream);
 }

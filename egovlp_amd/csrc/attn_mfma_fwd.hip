@@ -22,7 +22,7 @@ namespace {
 // group's keys is written as an un-normalised partial (o[64], m, l) to cls_ws; egv_attn_cls_combine merges the T
 // partials of a (clip, head).  The CLS key is counted for the CLS query in frame-group 0 only.
 // q is NOT pre-scaled: scores are multiplied by 64^-0.5 after the MFMA (exact for the power of two).
-template <int MODE, int NKF, int PASSES>
+template <int MODE, int NKF, int PASSES, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
                                                        bf16_t* __restrict__ out_lo, long out_stride,
                                                        float* __restrict__ lse, float* __restrict__ cls_ws) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
         const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
         bf16x8_t al = ah;
         if (PASSES == 3) al = att_frag_cols(k_lo, kf * 16, ks, lane);
-        s[kf] = att_mma<PASSES>(ah, al, qh[ks], ql[ks], s[kf]);
+        s[kf] = att_mma<PASSES, F16>(ah, al, qh[ks], ql[ks], s[kf]);
       }
     }
     // softmax over keys: lane holds keys kf*16 + 4*gq + r of query qi
@@ -127,13 +127,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
       float pv[8] = {s[2 * c][0], s[2 * c][1], s[2 * c][2], s[2 * c][3],
                      s[2 * c + 1][0], s[2 * c + 1][1], s[2 * c + 1][2], s[2 * c + 1][3]};
       bf16x8_t ph, pl;
-      att_split8(pv, ph, pl);
+      att_split8<F16>(pv, ph, pl);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const bf16x8_t vh = att_frag_rows(v_hi, 32 * c, df * 16, lane);
         bf16x8_t vl = vh;
         if (PASSES == 3) vl = att_frag_rows(v_lo, 32 * c, df * 16, lane);
-        o[df] = att_mma<PASSES>(vh, vl, ph, pl, o[df]);
+        o[df] = att_mma<PASSES, F16>(vh, vl, ph, pl, o[df]);
       }
     }
     if (SP && qi == g.nq) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
 // waves per workgroup (four per SIMD) whose phases interleave, and the 13 query tiles of a ViT-B group run in one round.
 // Measured 137 -> 130 us (profiles/r02_z_attention_streaming.txt): staging a group's K / V (one workgroup per CU, 115 KiB) is still
 // not overlapped with the previous group's tiles -- that needs the K / V chunks themselves streamed through a small LDS ring.
-template <int NKF>
+template <int NKF, bool F16 = false>
 __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
                                                                 bf16_t* __restrict__ out_lo, long out_stride,
                                                                 float* __restrict__ lse, float* __restrict__ cls_ws) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
           const bf16x8_t al = att_frag_cols(k_lo, kf * 16, ks, lane);
-          s[h] = att_mma<3>(ah, al, qh[ks], ql[ks], s[h]);
+          s[h] = att_mma<3, F16>(ah, al, qh[ks], ql[ks], s[h]);
         }
         const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
         s[h] = s[h] * 0.125f + kb;                   // q *= 64^-0.5 (video_transformer.py:106), applied to the scores
@@ -248,12 +248,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
       }
       l = l * alpha + ps;
       bf16x8_t ph, pl;
-      att_split8(pv, ph, pl);
+      att_split8<F16>(pv, ph, pl);
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const bf16x8_t vh = att_frag_rows(v_hi, 32 * c, df * 16, lane);
         const bf16x8_t vl = att_frag_rows(v_lo, 32 * c, df * 16, lane);
-        o[df] = att_mma<3>(vh, vl, ph, pl, o[df] * alpha);
+        o[df] = att_mma<3, F16>(vh, vl, ph, pl, o[df] * alpha);
       }
     }
     l += __shfl_xor(l, 16, 64);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
     } else if (qi < g.nq) {
       const float inv = 1.0f / l;
       bf16_t* oh = out_hi + qtok * out_stride + hoff;
-      bf16_t* ol = out_lo + qtok * out_stride + hoff;
+      bf16_t* ol = out_lo ? out_lo + qtok * out_stride + hoff : nullptr;      // ATT_OUT_F16: no second plane
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         uint32_t h0, h1, l0, l1;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         att_out2(o[df][2] * inv, o[df][3] * inv, g.out_fmt, h1, l1);
         const int d = df * 16 + 4 * gq;
         egv_store<EGV_NT_SPACE_ATTN>(oh + d, (u32x2_t){h0, h1});
-        egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
+        if (ol) egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
       }
       if (gq == 0 && lse) lse[((long)grp.b * g.H + grp.h) * g.S + (qtok - grp.tok0)] = m + __logf(l);
     }
@@ -294,15 +294,28 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
 #define EGV_STREAM18 1      // the streaming kernel for ViT-L/14's 257-key groups as well (17 query tiles on 16 waves: two rounds, and still
 #endif                      // +0.25 % on config 5 against attn_fwd_kernel<0,18,3>: 234.6 vs 234.0 pairs/s, profiles/r05e_ab_config5_stream18.txt; 0: A/B builds
   if constexpr (MODE == MODE_SPACE && (NKF == 14 || (NKF == 18 && EGV_STREAM18))) {   // measured on ViT-B/16 (13 query tiles on 16 waves): 137 -> 130 us
-    if (passes == 3 && ol != nullptr) {
-      auto kern = attn_fwd_stream3_kernel<NKF>;
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      EGV_LAUNCH(kern, dim3(ngroups), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws);
+    if (passes == 3 && (ol != nullptr || g.out_fmt == ATT_OUT_F16)) {
+      if (g.f16) {
+        auto kern = attn_fwd_stream3_kernel<NKF, true>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        EGV_LAUNCH(kern, dim3(ngroups), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws);
+      } else {
+        auto kern = attn_fwd_stream3_kernel<NKF>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        EGV_LAUNCH(kern, dim3(ngroups), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws);
+      }
       EGV_CHECK_LAUNCH();
       return EGV_OK;
     }
   }
-  if (passes == 3) {
+  if (MODE == MODE_SPACE && g.f16) {
+    if (passes != 3) return EGV_ERR_ARG;              // the fp16 forward is the three-product one
+    if constexpr (MODE == MODE_SPACE) {
+      auto kern = attn_fwd_kernel<MODE, NKF, 3, true>;
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EGV_LAUNCH(kern, dim3(ngroups), dim3(512), lds, s, g, oh, ol, ostride, lse, cls_ws);
+    }
+  } else if (passes == 3) {
     auto kern = attn_fwd_kernel<MODE, NKF, 3>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // three-pass mode keeps four K/V planes in LDS (115 KiB: one workgroup per CU), so it runs 8 waves per workgroup to have
@@ -333,9 +346,10 @@ static int dispatch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, b
 }
 
 int egv_attn_space_fwd_impl(const bf16_t* qkv_hi, const bf16_t* qkv_lo, int B, int T, int n, int H, int passes,
-                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, int out_fmt, hipStream_t s) {
+                            bf16_t* out_hi, bf16_t* out_lo, float* lse, float* cls_ws, int out_fmt, int f16, hipStream_t s) {
   AttGeom g;
   g.out_fmt = out_fmt;
+  g.f16 = f16;
   const long HD = (long)H * ATT_D;
   g.q = g.k = g.v = nullptr;
   g.ph = qkv_hi;
@@ -356,6 +370,7 @@ extern "C" int egv_text_attn_fwd(const float* q, const float* k, const float* v,
   if (passes == 3 && !out_lo) return EGV_ERR_ARG;
   AttGeom g;
   g.out_fmt = 0;
+  g.f16 = 0;
   const long HD = (long)H * ATT_D;
   g.q = q; g.k = k; g.v = v;
   g.ph = g.pl = nullptr;

@@ -57,7 +57,14 @@ __global__ __launch_bounds__(256) void attn_cls_combine_kernel(const float* __re
     oo /= ll;
     bf16_t hh, lo2;
     split_bf16(oo, hh, lo2);
-    if (out_fmt) lo2 = __builtin_bit_cast(unsigned short, (_Float16)f16x2_clamp(oo));      // second plane = fp16(value)
+    if (out_fmt == 1) lo2 = __builtin_bit_cast(unsigned short, (_Float16)f16x2_clamp(oo));      // second plane = fp16(value)
+    if (out_fmt == 2) {          // f16x2, first-operand role
+      _Float16 a1, a2;
+      f16x2_a(oo, a1, a2);
+      hh = __builtin_bit_cast(unsigned short, a1);
+      lo2 = __builtin_bit_cast(unsigned short, a2);
+    }
+    if (out_fmt == 3) hh = __builtin_bit_cast(unsigned short, (_Float16)f16x2_clamp(oo));         // the only plane = fp16(value)
     const long off = (long)b * S * H * D + (long)h * D + t;
     out_hi[off] = hh;
     if (out_lo) out_lo[off] = lo2;
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_cls_combine_kernel(const float* __re
 __global__ __launch_bounds__(64) void attn_cls_delta_kernel(const bf16_t* __restrict__ oh, const bf16_t* __restrict__ ol,
                                                             const bf16_t* __restrict__ doh,
                                                             const bf16_t* __restrict__ dol, int S, int H,
-                                                            float* __restrict__ delta, float* __restrict__ dcls) {
+                                                            float* __restrict__ delta, float* __restrict__ dcls, int o_fmt, int f16) {
   const int lane = threadIdx.x;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
   if (dcls) {   // this (clip, head)'s raw dq / dk / dv accumulators start at zero: saves a memset node per attention backward
@@ -77,8 +84,14 @@ __global__ __launch_bounds__(64) void attn_cls_delta_kernel(const bf16_t* __rest
     a[lane] = 0.f; a[64 + lane] = 0.f; a[128 + lane] = 0.f;
   }
   const long off = (long)b * S * H * D + (long)h * D + lane;
-  float o = bf16_to_f32(oh[off]), g = bf16_to_f32(doh[off]);
-  if (ol) o += bf16_to_f32(ol[off]);
+  float o, g = f16 ? (float)__builtin_bit_cast(_Float16, doh[off]) : bf16_to_f32(doh[off]);      // dO: an fp16 plane in the fp16 attention backward
+  if (o_fmt == 2 || o_fmt == 3) {       // the forward wrote fp16 planes (attn_common.h ATT_OUT_F16X2 / ATT_OUT_F16): O from the first one
+    o = (float)__builtin_bit_cast(_Float16, oh[off]);
+    if (o_fmt == 2) o *= 1.0f / (1.0f - F16X2_E);
+  } else {
+    o = bf16_to_f32(oh[off]);
+    if (ol && o_fmt == 0) o += bf16_to_f32(ol[off]);
+  }
   if (dol) g += bf16_to_f32(dol[off]);
   const float d = wave_sum(o * g);
   if (lane == 0) delta[((long)b * H + h) * S] = d;
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(64) void attn_cls_delta_kernel(const bf16_t* __rest
 
 // backward epilogue: the CLS token's accumulated raw dq / dk / dv -> gradient planes of token 0 (q and k carry 64^-0.5)
 __global__ __launch_bounds__(64) void attn_cls_finish_kernel(const float* __restrict__ dcls, int S, int H,
-                                                             bf16_t* __restrict__ gh, bf16_t* __restrict__ gl) {
+                                                             bf16_t* __restrict__ gh, bf16_t* __restrict__ gl, int gfmt) {
   const int lane = threadIdx.x;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
   const float* a = dcls + (long)blockIdx.x * 192;
@@ -97,6 +110,7 @@ __global__ __launch_bounds__(64) void attn_cls_finish_kernel(const float* __rest
   for (int part = 0; part < 3; ++part) {
     bf16_t hh, ll;
     split_bf16(v[part], hh, ll);
+    if (gfmt == 4) hh = __builtin_bit_cast(unsigned short, (_Float16)v[part]);      // un-clamped fp16 (the fp16 backward)
     gh[off + part * HD] = hh;
     if (gl) gl[off + part * HD] = ll;
   }
@@ -105,21 +119,21 @@ __global__ __launch_bounds__(64) void attn_cls_finish_kernel(const float* __rest
 }  // namespace
 
 int egv_attn_time_mfma_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
-                                float* ws, int out_fmt, hipStream_t s);
+                                float* ws, int out_fmt, int f16, hipStream_t s);
 int egv_attn_time_mfma_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
-                                const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s);
+                                const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, int gfmt, int f16, hipStream_t s);
 
 int egv_attn_time_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol,
-                           float* lse, float* ws, int out_fmt, hipStream_t s) {
+                           float* lse, float* ws, int out_fmt, int f16, hipStream_t s) {
   if (T > 16) return EGV_ERR_ARG;
-  return egv_attn_time_mfma_fwd_impl(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
+  return egv_attn_time_mfma_fwd_impl(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, f16, s);
 }
 
 int egv_attn_time_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
-                           const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls,
+                           const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, int gfmt, int f16,
                            hipStream_t s) {
   if (T > 16) return EGV_ERR_ARG;
-  return egv_attn_time_mfma_bwd_impl(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
+  return egv_attn_time_mfma_bwd_impl(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, gfmt, f16, s);
 }
 
 int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_t* oh, bf16_t* ol, float* lse, int out_fmt,
@@ -130,14 +144,14 @@ int egv_attn_cls_combine_impl(const float* ws, int B, int G, int S, int H, bf16_
 }
 
 int egv_attn_cls_delta_impl(const bf16_t* oh, const bf16_t* ol, const bf16_t* doh, const bf16_t* dol, int B, int S, int H,
-                            float* delta, float* dcls, hipStream_t s) {
-  EGV_LAUNCH(attn_cls_delta_kernel, dim3(B * H), dim3(64), 0, s, oh, ol, doh, dol, S, H, delta, dcls);
+                            float* delta, float* dcls, int o_fmt, int f16, hipStream_t s) {
+  EGV_LAUNCH(attn_cls_delta_kernel, dim3(B * H), dim3(64), 0, s, oh, ol, doh, dol, S, H, delta, dcls, o_fmt, f16);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
 
-int egv_attn_cls_finish_impl(const float* dcls, int B, int S, int H, bf16_t* gh, bf16_t* gl, hipStream_t s) {
-  EGV_LAUNCH(attn_cls_finish_kernel, dim3(B * H), dim3(64), 0, s, dcls, S, H, gh, gl);
+int egv_attn_cls_finish_impl(const float* dcls, int B, int S, int H, bf16_t* gh, bf16_t* gl, int gfmt, hipStream_t s) {
+  EGV_LAUNCH(attn_cls_finish_kernel, dim3(B * H), dim3(64), 0, s, dcls, S, H, gh, gl, gfmt);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

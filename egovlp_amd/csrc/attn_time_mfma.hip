@@ -108,20 +108,22 @@ __device__ __forceinline__ float row16_sum(float v) {   // over the 16 lanes of 
 
 // row-contraction B operand from a tile pair's accumulator-layout values: elements 0..3 = rows 4g + j of the 16-row tile,
 // elements 4..7 = rows 16..19 (the CLS tile: its rows live in lane group 0 only -- the callers pass zeros elsewhere)
+template <bool F16 = false>
 __device__ __forceinline__ void pack_b(const float (&a)[4], const float (&x)[4], bf16x8_t& hi, bf16x8_t& lo) {
   const float v[8] = {a[0], a[1], a[2], a[3], x[0], x[1], x[2], x[3]};
-  att_split8(v, hi, lo);
+  att_split8<F16>(v, hi, lo);
 }
+template <bool F16 = false>
 __device__ __forceinline__ void pack_b(const float (&a)[4], float one, bf16x8_t& hi, bf16x8_t& lo) {
   const float x[4] = {one, 0.f, 0.f, 0.f};
-  pack_b(a, x, hi, lo);
+  pack_b<F16>(a, x, hi, lo);
 }
 
-template <int PASSES>
+template <int PASSES, bool F16 = false>
 __device__ __forceinline__ f32x4_t mma2(const bf16x8_t (&ah)[2], const bf16x8_t (&al)[2], const bf16x8_t (&bh)[2], const bf16x8_t (&bl)[2]) {
   f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-  c = att_mma<PASSES>(ah[0], al[0], bh[0], bl[0], c);
-  return att_mma<PASSES>(ah[1], al[1], bh[1], bl[1], c);
+  c = att_mma<PASSES, F16>(ah[0], al[0], bh[0], bl[0], c);
+  return att_mma<PASSES, F16>(ah[1], al[1], bh[1], bl[1], c);
 }
 
 __device__ __forceinline__ void store4(bf16_t* __restrict__ ph, bf16_t* __restrict__ pl, long off, const f32x4_t& v, float scale, int fmt = 0) {
@@ -178,7 +180,7 @@ __device__ __forceinline__ void flush_rows(const char* sh, const char* sl, bf16_
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
-template <int PASSES, int TP>
+template <int PASSES, int TP, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql, int B, int T,
                                                                  int n, int H, bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
                                                                  float* __restrict__ lse, float* __restrict__ cls_ws, int out_fmt) {
@@ -241,10 +243,10 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
 #endif
   constexpr int LO = NPL - 1;
   // S' = K Q^T: rows = keys (4g + j), columns = queries (p)
-  const f32x4_t s00 = mma2<PASSES>(k0[0], k0[LO], q0[0], q0[LO]);      // frame keys x frame queries
-  const f32x4_t s10 = mma2<PASSES>(kc[0], kc[LO], q0[0], q0[LO]);      // CLS key (row 0: group 0, j = 0) x frame queries
-  const f32x4_t s01 = mma2<PASSES>(k0[0], k0[LO], qc[0], qc[LO]);      // frame keys x CLS query (columns c < LOCS)
-  const f32x4_t s11 = mma2<PASSES>(kc[0], kc[LO], qc[0], qc[LO]);      // CLS key x CLS query
+  const f32x4_t s00 = mma2<PASSES, F16>(k0[0], k0[LO], q0[0], q0[LO]);      // frame keys x frame queries
+  const f32x4_t s10 = mma2<PASSES, F16>(kc[0], kc[LO], q0[0], q0[LO]);      // CLS key (row 0: group 0, j = 0) x frame queries
+  const f32x4_t s01 = mma2<PASSES, F16>(k0[0], k0[LO], qc[0], qc[LO]);      // frame keys x CLS query (columns c < LOCS)
+  const f32x4_t s11 = mma2<PASSES, F16>(kc[0], kc[LO], qc[0], qc[LO]);      // CLS key x CLS query
   // the V image takes the place of the Q / K images (LDS operations of a wave execute in order)
 #pragma unroll
   for (int pl = 0; pl < NPL; ++pl) {
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
     for (int j = 0; j < 4; ++j) e[j] = same[j] ? __expf(a[j] - m0) : 0.f;
     const float ec = (g == 0) ? __expf(c - m0) : 0.f;
     l0 = allg_sum(e[0] + e[1] + e[2] + e[3] + ec);
-    pack_b(e, ec, b0h, b0l);
+    pack_b<F16>(e, ec, b0h, b0l);
   }
   {   // the clip's CLS query against the keys of location i0 + p (+ the CLS key, counted in location 0 only): un-normalised partial
     float a[4];
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
     for (int j = 0; j < 4; ++j) e[j] = mine[j] ? __expf(a[j] - m1) : 0.f;
     const float ec = own ? __expf(c - m1) : 0.f;
     l1 = allg_sum(e[0] + e[1] + e[2] + e[3] + ec);
-    pack_b(e, ec, b1h, b1l);
+    pack_b<F16>(e, ec, b1h, b1l);
   }
   const float inv0 = 1.0f / l0;
   const long otok = (long)b * S + row_token<TP>(p, T, n, i0);
@@ -301,8 +303,8 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
     const bf16x8_t ah = frag_rows20(base, 16 * c, lane);
     const bf16x8_t al = PASSES == 3 ? frag_rows20(base + IMG20, 16 * c, lane) : ah;
     f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
-    o0 = att_mma<PASSES>(ah, al, b0h, b0l, o0);
-    o1 = att_mma<PASSES>(ah, al, b1h, b1l, o1);
+    o0 = att_mma<PASSES, F16>(ah, al, b0h, b0l, o0);
+    o1 = att_mma<PASSES, F16>(ah, al, b1h, b1l, o1);
 #ifdef EGV_TMF_OLD_STORES
     if (qv) store4(out_hi, out_lo, otok * HD + (long)h * HD64 + 16 * c + 4 * g, o0, inv0, out_fmt);
 #else
@@ -323,12 +325,12 @@ __global__ __launch_bounds__(256) void attn_time_mfma_fwd_kernel(const bf16_t* _
 // ------------------------------------------------------------------------------------------------------------ backward
 // A workgroup = WPB consecutive units of one (clip, head) (four; two in the three-product mode, whose images are twice as big):
 // the CLS token's raw dq / dk / dv partials of its waves are summed in LDS and leave as one round of 192 atomics.
-template <int PASSES, int WPB, int TP>
+template <int PASSES, int WPB, int TP, bool F16 = false>
 __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16_t* __restrict__ qh, const bf16_t* __restrict__ ql,
                                                                  const bf16_t* __restrict__ doh, const bf16_t* __restrict__ dol,
                                                                  const float* __restrict__ lse, const float* __restrict__ delta, int B, int T,
                                                                  int n, int H, bf16_t* __restrict__ gh, bf16_t* __restrict__ gl,
-                                                                 float* __restrict__ dcls) {
+                                                                 float* __restrict__ dcls, int gfmt) {
   constexpr int NPL = PASSES == 3 ? 2 : 1;
   constexpr int LOCS = 16 / TP;
   constexpr int WAVE_LDS = NPL * (3 * IMG20 + IMG17);       // K, Q, dO (transpose-read too) and V images
@@ -404,10 +406,10 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
     // ---- orientation 1: rows = keys (4g + j), columns = queries (p)  ->  dQ (contraction over keys)
     bf16x8_t dq0h, dq0l, dq1h, dq1l;
     {
-      const f32x4_t s00 = mma2<PASSES>(k0[0], k0[LO], q0[0], q0[LO]), s10 = mma2<PASSES>(kc[0], kc[LO], q0[0], q0[LO]);
-      const f32x4_t s01 = mma2<PASSES>(k0[0], k0[LO], qc[0], qc[LO]), s11 = mma2<PASSES>(kc[0], kc[LO], qc[0], qc[LO]);
-      const f32x4_t d00 = mma2<PASSES>(v0[0], v0[LO], g0[0], g0[LO]), d10 = mma2<PASSES>(vc[0], vc[LO], g0[0], g0[LO]);
-      const f32x4_t d01 = mma2<PASSES>(v0[0], v0[LO], gc[0], gc[LO]), d11 = mma2<PASSES>(vc[0], vc[LO], gc[0], gc[LO]);
+      const f32x4_t s00 = mma2<PASSES, F16>(k0[0], k0[LO], q0[0], q0[LO]), s10 = mma2<PASSES, F16>(kc[0], kc[LO], q0[0], q0[LO]);
+      const f32x4_t s01 = mma2<PASSES, F16>(k0[0], k0[LO], qc[0], qc[LO]), s11 = mma2<PASSES, F16>(kc[0], kc[LO], qc[0], qc[LO]);
+      const f32x4_t d00 = mma2<PASSES, F16>(v0[0], v0[LO], g0[0], g0[LO]), d10 = mma2<PASSES, F16>(vc[0], vc[LO], g0[0], g0[LO]);
+      const f32x4_t d01 = mma2<PASSES, F16>(v0[0], v0[LO], gc[0], gc[LO]), d11 = mma2<PASSES, F16>(vc[0], vc[LO], gc[0], gc[LO]);
       const float Lq = lb[ptok];
       float pr[4], pc, ds[4];
 #pragma unroll
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
       const float dl = allg_sum(pr[0] * d00[0] + pr[1] * d00[1] + pr[2] * d00[2] + pr[3] * d00[3] + pc * d10[0]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) ds[j] = pr[j] * (d00[j] - dl);
-      pack_b(ds, pc * (d10[0] - dl), dq0h, dq0l);
+      pack_b<F16>(ds, pc * (d10[0] - dl), dq0h, dq0l);
       // the CLS query as seen from location i0 + p (columns p < LOCS)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -424,15 +426,15 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
         ds[j] = pj * (d01[j] - dlc);
       }
       const float pcc = (g == 0 && i0 + p == 0) ? __expf(s11[0] * 0.125f - Lc) : 0.f;
-      pack_b(ds, pcc * (d11[0] - dlc), dq1h, dq1l);
+      pack_b<F16>(ds, pcc * (d11[0] - dlc), dq1h, dq1l);
     }
     // ---- orientation 2: rows = queries (4g + j), columns = keys (p)  ->  dK, dV (contraction over queries)
     bf16x8_t dk0h, dk0l, dk1h, dk1l, pv0h, pv0l, pv1h, pv1l;
     {
-      const f32x4_t t00 = mma2<PASSES>(q0[0], q0[LO], k0[0], k0[LO]), t10 = mma2<PASSES>(qc[0], qc[LO], k0[0], k0[LO]);
-      const f32x4_t t01 = mma2<PASSES>(q0[0], q0[LO], kc[0], kc[LO]), t11 = mma2<PASSES>(qc[0], qc[LO], kc[0], kc[LO]);
-      const f32x4_t e00 = mma2<PASSES>(g0[0], g0[LO], v0[0], v0[LO]), e10 = mma2<PASSES>(gc[0], gc[LO], v0[0], v0[LO]);
-      const f32x4_t e01 = mma2<PASSES>(g0[0], g0[LO], vc[0], vc[LO]), e11 = mma2<PASSES>(gc[0], gc[LO], vc[0], vc[LO]);
+      const f32x4_t t00 = mma2<PASSES, F16>(q0[0], q0[LO], k0[0], k0[LO]), t10 = mma2<PASSES, F16>(qc[0], qc[LO], k0[0], k0[LO]);
+      const f32x4_t t01 = mma2<PASSES, F16>(q0[0], q0[LO], kc[0], kc[LO]), t11 = mma2<PASSES, F16>(qc[0], qc[LO], kc[0], kc[LO]);
+      const f32x4_t e00 = mma2<PASSES, F16>(g0[0], g0[LO], v0[0], v0[LO]), e10 = mma2<PASSES, F16>(gc[0], gc[LO], v0[0], v0[LO]);
+      const f32x4_t e01 = mma2<PASSES, F16>(g0[0], g0[LO], vc[0], vc[LO]), e11 = mma2<PASSES, F16>(gc[0], gc[LO], vc[0], vc[LO]);
       float p00[4], p01[4], ds0[4], ds1[4], p10[4], d10[4], p11[4], d11[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -450,10 +452,10 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
         d10[j] = p10[j] * (e10[j] - dlc);
         d11[j] = p11[j] * (e11[j] - dlc);
       }
-      pack_b(ds0, d10, dk0h, dk0l);
-      pack_b(ds1, d11, dk1h, dk1l);
-      pack_b(p00, p10, pv0h, pv0l);
-      pack_b(p01, p11, pv1h, pv1l);
+      pack_b<F16>(ds0, d10, dk0h, dk0l);
+      pack_b<F16>(ds1, d11, dk1h, dk1l);
+      pack_b<F16>(p00, p10, pv0h, pv0l);
+      pack_b<F16>(p01, p11, pv1h, pv1l);
     }
     const long gtok = ((long)b * S + ptok) * ts + (long)h * HD64;
     const bool cls_col = p < LOCS;                                  // columns of the CLS query's partial (masked columns hold zeros)
@@ -466,9 +468,9 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bf16x8_t kth = frag_rows20(kim[0], 16 * c, lane), ktl = PASSES == 3 ? frag_rows20(kim[LO], 16 * c, lane) : kth;
-      const f32x4_t dq = att_mma<PASSES>(kth, ktl, dq0h, dq0l, z);      // rows = channels 16c + 4g + j, columns = frame queries
-      const f32x4_t dqc = att_mma<PASSES>(kth, ktl, dq1h, dq1l, z);     // columns c < LOCS: the CLS query's partials, one per location
-      stage4(sth, stl, p, 16 * c + 4 * g, dq, 0.125f);
+      const f32x4_t dq = att_mma<PASSES, F16>(kth, ktl, dq0h, dq0l, z);      // rows = channels 16c + 4g + j, columns = frame queries
+      const f32x4_t dqc = att_mma<PASSES, F16>(kth, ktl, dq1h, dq1l, z);     // columns c < LOCS: the CLS query's partials, one per location
+      stage4(sth, stl, p, 16 * c + 4 * g, dq, 0.125f, gfmt);
       if (cls_col) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) atomicAdd(&red[wave][16 * c + 4 * g + j], dqc[j]);
@@ -478,18 +480,18 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bf16x8_t qth = frag_rows20(qim[0], 16 * c, lane), qtl = PASSES == 3 ? frag_rows20(qim[LO], 16 * c, lane) : qth;
-      const f32x4_t dk = att_mma<PASSES>(qth, qtl, dk0h, dk0l, z);      // columns = frame keys
-      const f32x4_t dkc = att_mma<PASSES>(qth, qtl, dk1h, dk1l, z);     // column 0: the CLS key's partial
-      stage4(sth, stl, p, 16 * c + 4 * g, dk, 0.125f);
+      const f32x4_t dk = att_mma<PASSES, F16>(qth, qtl, dk0h, dk0l, z);      // columns = frame keys
+      const f32x4_t dkc = att_mma<PASSES, F16>(qth, qtl, dk1h, dk1l, z);     // column 0: the CLS key's partial
+      stage4(sth, stl, p, 16 * c + 4 * g, dk, 0.125f, gfmt);
       if (p == 0) *(f32x4_t*)&red[wave][64 + 16 * c + 4 * g] = dkc;
     }
     flush_rows<TP, EGV_NT_TIME_BWD>(sth, stl, gh, gl, (long)b * S, ts, (long)h * HD64 + HD, T, n, i0, lane);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bf16x8_t gth = frag_rows20(gim[0], 16 * c, lane), gtl = PASSES == 3 ? frag_rows20(gim[LO], 16 * c, lane) : gth;
-      const f32x4_t dv = att_mma<PASSES>(gth, gtl, pv0h, pv0l, z);
-      const f32x4_t dvc = att_mma<PASSES>(gth, gtl, pv1h, pv1l, z);
-      stage4(sth, stl, p, 16 * c + 4 * g, dv, 1.0f);
+      const f32x4_t dv = att_mma<PASSES, F16>(gth, gtl, pv0h, pv0l, z);
+      const f32x4_t dvc = att_mma<PASSES, F16>(gth, gtl, pv1h, pv1l, z);
+      stage4(sth, stl, p, 16 * c + 4 * g, dv, 1.0f, gfmt);
       if (p == 0) *(f32x4_t*)&red[wave][128 + 16 * c + 4 * g] = dvc;
     }
     flush_rows<TP, EGV_NT_TIME_BWD>(sth, stl, gh, gl, (long)b * S, ts, (long)h * HD64 + 2 * HD, T, n, i0, lane);
@@ -500,17 +502,17 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
       const bf16x8_t qth = frag_rows20(qim[0], 16 * c, lane), qtl = PASSES == 3 ? frag_rows20(qim[LO], 16 * c, lane) : qth;
       const bf16x8_t gth = frag_rows20(gim[0], 16 * c, lane), gtl = PASSES == 3 ? frag_rows20(gim[LO], 16 * c, lane) : gth;
       const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4_t dq = att_mma<PASSES>(kth, ktl, dq0h, dq0l, z);      // rows = channels 16c + 4g + j, columns = frame queries
-      const f32x4_t dqc = att_mma<PASSES>(kth, ktl, dq1h, dq1l, z);     // columns c < LOCS: the CLS query's partials, one per location
-      const f32x4_t dk = att_mma<PASSES>(qth, qtl, dk0h, dk0l, z);      // columns = frame keys
-      const f32x4_t dkc = att_mma<PASSES>(qth, qtl, dk1h, dk1l, z);     // column 0: the CLS key's partial
-      const f32x4_t dv = att_mma<PASSES>(gth, gtl, pv0h, pv0l, z);
-      const f32x4_t dvc = att_mma<PASSES>(gth, gtl, pv1h, pv1l, z);
+      const f32x4_t dq = att_mma<PASSES, F16>(kth, ktl, dq0h, dq0l, z);      // rows = channels 16c + 4g + j, columns = frame queries
+      const f32x4_t dqc = att_mma<PASSES, F16>(kth, ktl, dq1h, dq1l, z);     // columns c < LOCS: the CLS query's partials, one per location
+      const f32x4_t dk = att_mma<PASSES, F16>(qth, qtl, dk0h, dk0l, z);      // columns = frame keys
+      const f32x4_t dkc = att_mma<PASSES, F16>(qth, qtl, dk1h, dk1l, z);     // column 0: the CLS key's partial
+      const f32x4_t dv = att_mma<PASSES, F16>(gth, gtl, pv0h, pv0l, z);
+      const f32x4_t dvc = att_mma<PASSES, F16>(gth, gtl, pv1h, pv1l, z);
       if (pv_) {
         const long o = gtok + 16 * c + 4 * g;
-        store4(gh, gl, o, dq, 0.125f);
-        store4(gh, gl, o + HD, dk, 0.125f);
-        store4(gh, gl, o + 2 * HD, dv, 1.0f);
+        store4(gh, gl, o, dq, 0.125f, gfmt);
+        store4(gh, gl, o + HD, dk, 0.125f, gfmt);
+        store4(gh, gl, o + 2 * HD, dv, 1.0f, gfmt);
       }
       if (cls_col) {
 #pragma unroll
@@ -536,11 +538,14 @@ __global__ __launch_bounds__(64 * WPB) void attn_time_mfma_bwd_kernel(const bf16
 
 template <int TP>
 static int launch_fwd(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse, float* ws,
-                      int out_fmt, hipStream_t s) {
+                      int out_fmt, int f16, hipStream_t s) {
   constexpr int LOCS = 16 / TP;
   const long waves = (long)B * ((n + LOCS - 1) / LOCS) * H;
   const dim3 grid((unsigned)((waves + 3) / 4));
-  if (ql)
+  if (f16) {
+    if (!ql) return EGV_ERR_ARG;        // the fp16 forward is the three-product one
+    EGV_LAUNCH((attn_time_mfma_fwd_kernel<3, TP, true>), grid, dim3(256), 0, s, qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt);
+  } else if (ql)
     EGV_LAUNCH((attn_time_mfma_fwd_kernel<3, TP>), grid, dim3(256), 0, s, qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt);
   else
     EGV_LAUNCH((attn_time_mfma_fwd_kernel<1, TP>), grid, dim3(256), 0, s, qh, ql, B, T, n, H, oh, ol, lse, ws, 0);
@@ -550,29 +555,33 @@ static int launch_fwd(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, i
 
 template <int TP>
 static int launch_bwd(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse, const float* delta, int B,
-                      int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s) {
+                      int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, int gfmt, int f16, hipStream_t s) {
   constexpr int LOCS = 16 / TP;
   const int units = (n + LOCS - 1) / LOCS;
-  if (ql && dol)
+  if (f16)
+    EGV_LAUNCH((attn_time_mfma_bwd_kernel<1, 4, TP, true>), dim3((unsigned)((long)B * H * ((units + 3) / 4))), dim3(256), 0, s, qh, nullptr, doh,
+               nullptr, lse, delta, B, T, n, H, gh, gl, dcls, gfmt);
+  else if (ql && dol)
     EGV_LAUNCH((attn_time_mfma_bwd_kernel<3, 2, TP>), dim3((unsigned)((long)B * H * ((units + 1) / 2))), dim3(128), 0, s, qh, ql, doh, dol,
-               lse, delta, B, T, n, H, gh, gl, dcls);
+               lse, delta, B, T, n, H, gh, gl, dcls, gfmt);
   else
     EGV_LAUNCH((attn_time_mfma_bwd_kernel<1, 4, TP>), dim3((unsigned)((long)B * H * ((units + 3) / 4))), dim3(256), 0, s, qh, nullptr, doh,
-               nullptr, lse, delta, B, T, n, H, gh, gl, dcls);
+               nullptr, lse, delta, B, T, n, H, gh, gl, dcls, gfmt);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }
 
 int egv_attn_time_mfma_fwd_impl(const bf16_t* qh, const bf16_t* ql, int B, int T, int n, int H, bf16_t* oh, bf16_t* ol, float* lse,
-                                float* ws, int out_fmt, hipStream_t s) {
-  if (T <= 4) return launch_fwd<4>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
-  if (T <= 8) return launch_fwd<8>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
-  return launch_fwd<16>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, s);
+                                float* ws, int out_fmt, int f16, hipStream_t s) {
+  if (T <= 4) return launch_fwd<4>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, f16, s);
+  if (T <= 8) return launch_fwd<8>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, f16, s);
+  return launch_fwd<16>(qh, ql, B, T, n, H, oh, ol, lse, ws, out_fmt, f16, s);
 }
 
 int egv_attn_time_mfma_bwd_impl(const bf16_t* qh, const bf16_t* ql, const bf16_t* doh, const bf16_t* dol, const float* lse,
-                                const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, hipStream_t s) {
-  if (T <= 4) return launch_bwd<4>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
-  if (T <= 8) return launch_bwd<8>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
-  return launch_bwd<16>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, s);
+                                const float* delta, int B, int T, int n, int H, bf16_t* gh, bf16_t* gl, float* dcls, int gfmt, int f16,
+                                hipStream_t s) {
+  if (T <= 4) return launch_bwd<4>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, gfmt, f16, s);
+  if (T <= 8) return launch_bwd<8>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, gfmt, f16, s);
+  return launch_bwd<16>(qh, ql, doh, dol, lse, delta, B, T, n, H, gh, gl, dcls, gfmt, f16, s);
 }

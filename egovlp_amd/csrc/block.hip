@@ -50,8 +50,12 @@ Geo geo_of(const egv_block_geom& g) {
 
 bool geom_ok(const egv_block_geom& g) {
   if (g.B <= 0 || g.T <= 0 || g.n <= 0 || g.H <= 0 || g.D != g.H * 64 || g.Hd <= 0 || g.D % 32 || g.Hd % 32) return false;
-  if (g.fwd_passes < 1 || g.fwd_passes > 3 || (g.bwd_passes != 1 && g.bwd_passes != 3) || g.bwd_passes > g.fwd_passes) return false;
-  if (g.fwd_passes == 2 && (g.bwd_passes != 1 || (g.train && !g.z_bf16))) return false;   // f16x2 forward: single-pass bf16 backward
+  // bwd_passes: 3 = split-bf16 three-product, 1 = one bf16 product, 4 = one FP16 product on scaled gradients (the fp16 backward: needs
+  // the f16x2 / f16mix forward, whose saved operands ARE fp16 planes -- no bf16 copies are written then)
+  if (g.fwd_passes < 1 || g.fwd_passes > 3 || (g.bwd_passes != 1 && g.bwd_passes != 3 && g.bwd_passes != 4)) return false;
+  if (g.bwd_passes == 3 && g.fwd_passes != 3) return false;
+  if (g.bwd_passes == 4 && g.fwd_passes != 2) return false;
+  if (g.fwd_passes == 2 && (g.bwd_passes == 3 || (g.train && !g.z_bf16))) return false;   // f16x2 forward: single-product backward, 16-bit saved gelu'
   if (g.f16_single < 0 || g.f16_single > 15 || (g.f16_single && g.fwd_passes != 2)) return false;
   return true;
 }
@@ -59,7 +63,8 @@ bool geom_ok(const egv_block_geom& g) {
 FwdLayout fwd_layout(const egv_block_geom& g) {
   const Geo o = geo_of(g);
   const bool lo = o.P != 1;              // split-bf16 (P == 3) and f16x2 (P == 2) operands are two planes
-  const bool bf = o.P == 2 && g.train;
+  const bool h16 = o.Pb == 4;            // fp16 backward: it reads the forward's own fp16 planes
+  const bool bf = o.P == 2 && g.train && !h16;
   FwdLayout L;
   Bump b;
   auto plane = [&](int64_t cols) { return b.take(o.M * cols * 2); };
@@ -70,14 +75,15 @@ FwdLayout fwd_layout(const egv_block_geom& g) {
   L.n3_hi = plane(o.D); L.n3_lo = q1 ? (int64_t)-1 : plane_lo(o.D);
   L.mean3 = b.take(o.M * 4); L.rstd3 = b.take(o.M * 4);
   L.qkvt_hi = plane(3 * o.D); L.qkvt_lo = plane_lo(3 * o.D);
-  L.at_hi = plane(o.D); L.at_lo = plane_lo(o.D);
+  const bool a1p = h16 && (g.f16_single & 8);   // attention output as ONE fp16 plane (one-product proj, fp16 backward)
+  L.at_hi = plane(o.D); L.at_lo = a1p ? (int64_t)-1 : plane_lo(o.D);
   L.lse_t = b.take((int64_t)g.B * g.H * o.S * 4);
   L.work_t = b.take(egv_divided_attn_fwd_work_floats(g.B, g.T, g.n, g.H, 1) * 4);
   L.tr = b.take(o.M * o.D * 4);
   L.n1_hi = plane(o.D); L.n1_lo = q1 ? (int64_t)-1 : plane_lo(o.D);
   L.mean1 = b.take(o.M * 4); L.rstd1 = b.take(o.M * 4);
   L.qkvs_hi = plane(3 * o.D); L.qkvs_lo = plane_lo(3 * o.D);
-  L.as_hi = plane(o.D); L.as_lo = plane_lo(o.D);
+  L.as_hi = plane(o.D); L.as_lo = a1p ? (int64_t)-1 : plane_lo(o.D);
   L.lse_s = b.take((int64_t)g.B * g.H * o.S * 4);
   L.work_s = b.take(egv_divided_attn_fwd_work_floats(g.B, g.T, g.n, g.H, 0) * 4);
   L.sr = b.take(o.M * o.D * 4);
@@ -209,7 +215,17 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
     if (!p.w_hi[i] || (P != 1 && !p.w_lo[i])) return EGV_ERR_ARG;
   const int P_fc1 = (g.f16_single & 1) ? 4 : P, P_fc2 = (g.f16_single & 2) ? 4 : P, P_qkv = (g.f16_single & 4) ? 4 : P;   // 4: ONE fp16 product
   const bool proj1 = (g.f16_single & 8) != 0;      // proj Linears: ONE fp16 product on the attention's fp16(value) plane (its second output plane)
-  const int amode = proj1 ? 2 : 0;
+  const bool h16 = o.Pb == 4;                      // fp16 backward: no bf16 copies; the attention output is fp16 planes only (format 3: ONE
+                                                   // plane of fp16(value), one-product proj; format 2: f16x2 planes, TWO-product proj)
+  const int afmt = h16 ? (proj1 ? 3 : 2) : (proj1 ? 1 : 0);
+  const int amode = (afmt << 1) | (h16 ? 8 : 0);     // fp16 backward: the attention itself runs on fp16 operands (qkv planes = an fp16 split)
+  // the proj GEMM of one attention branch: operand planes and product count by format
+  auto proj_desc = [&](const egv_bf16* a_hi, const egv_bf16* a_lo, int wi) {
+    if (afmt == 3) return nt_desc(a_hi, nullptr, D, p.w_hi[wi], p.w_lo[wi], p.ldw[wi], M, D, D, 4, g.grid_cap);
+    if (afmt == 2) return nt_desc(a_hi, a_lo, D, p.w_hi[wi], p.w_lo[wi], p.ldw[wi], M, D, D, 2, g.grid_cap);
+    if (afmt == 1) return nt_desc(a_lo, nullptr, D, p.w_hi[wi], p.w_lo[wi], p.ldw[wi], M, D, D, 4, g.grid_cap);
+    return nt_desc(a_hi, a_lo, D, p.w_hi[wi], p.w_lo[wi], p.ldw[wi], M, D, D, Pa, g.grid_cap);
+  };
   char* A = (char*)arena;
   // LayerNorm -> operand planes of the qkv / fc1 Linears: split-bf16, or f16x2 (first-operand role, + the bf16 copy the backward reads)
   auto ln = [&](const float* in, const float* gw, const float* gb, egv_bf16* y_hi, egv_bf16* y_lo, int64_t bf_off, float* mean, float* rstd) -> int {
@@ -232,12 +248,12 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   {
     egv_gemm_desc d = nt_desc(n3_hi, n3_lo, D, p.w_hi[0], p.w_lo[0], p.ldw[0], M, 3 * D, D, P_qkv, g.grid_cap);
     d.bias = p.bias[0]; d.out_hi = qt_hi; d.out_lo = qt_lo; d.ldoh = 3 * D;
+    if (h16) d.out_fmt = 3;              // qkv as an fp16 split (fp16(x), fp16(x - hi)): the fp16 attention's operand planes
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   EGV_TRY(egv_divided_attn_fwd(qt_hi, qt_lo, g.B, g.T, g.n, g.H, 1 | amode, Pa, at_hi, at_lo, at<float>(A, L.lse_t), at<float>(A, L.work_t), stream));
   {
-    egv_gemm_desc d = proj1 ? nt_desc(at_lo, nullptr, D, p.w_hi[1], p.w_lo[1], p.ldw[1], M, D, D, 4, g.grid_cap)
-                            : nt_desc(at_hi, at_lo, D, p.w_hi[1], p.w_lo[1], p.ldw[1], M, D, D, Pa, g.grid_cap);
+    egv_gemm_desc d = proj_desc(at_hi, at_lo, 1);
     d.bias = p.bias[1]; d.residual = x; d.ldr = D; d.out_f32 = tr; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
@@ -246,12 +262,12 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
   {
     egv_gemm_desc d = nt_desc(n1_hi, n1_lo, D, p.w_hi[2], p.w_lo[2], p.ldw[2], M, 3 * D, D, P_qkv, g.grid_cap);
     d.bias = p.bias[2]; d.out_hi = qs_hi; d.out_lo = qs_lo; d.ldoh = 3 * D;
+    if (h16) d.out_fmt = 3;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   EGV_TRY(egv_divided_attn_fwd(qs_hi, qs_lo, g.B, g.T, g.n, g.H, 0 | amode, Pa, as_hi, as_lo, at<float>(A, L.lse_s), at<float>(A, L.work_s), stream));
   {
-    egv_gemm_desc d = proj1 ? nt_desc(as_lo, nullptr, D, p.w_hi[3], p.w_lo[3], p.ldw[3], M, D, D, 4, g.grid_cap)
-                            : nt_desc(as_hi, as_lo, D, p.w_hi[3], p.w_lo[3], p.ldw[3], M, D, D, Pa, g.grid_cap);
+    egv_gemm_desc d = proj_desc(as_hi, as_lo, 3);
     d.bias = p.bias[3]; d.residual = x; d.ldr = D; d.out_f32 = sr; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
@@ -264,7 +280,7 @@ extern "C" int egv_block_fwd(const egv_block_geom* gp, const egv_block_params* p
     if (P == 2) { d.out_fmt = P_fc2 == 4 ? 2 : 1; d.out_bf = at<egv_bf16>(A, L.h_bf); }
     if (g.train) {
       d.aux_out = at<float>(A, L.z); d.ldaux = Hd;
-      d.aux_bf16 = g.z_bf16 ? 2 : 0;      // bf16: gelu'(z) itself (the backward is single-pass), else the fp32 pre-activation
+      d.aux_bf16 = g.z_bf16 ? (h16 ? 3 : 2) : 0;      // 16 bits: gelu'(z) itself (bf16; fp16 for the fp16 backward), else the fp32 pre-activation
     }
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
@@ -292,6 +308,15 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   for (int i = 0; i < 6; ++i)
     if (!p.wt_hi[i] || (Pb == 3 && !p.wt_lo[i])) return EGV_ERR_ARG;
   if (Pb == 3 && (!io.dx_lo || (io.g_hi && !io.g_lo))) return EGV_ERR_ARG;
+  // The fp16 backward (Pb == 4).  Every gradient of the pass carries the loss scale S (egv_loss_scale_*; linear all the way, so nothing
+  // here knows S).  Operand planes: dY = ONE plane of un-clamped fp16 (LayerNorm-backward, the GELU' epilogue, the attention backward
+  // write it so; g_hi / dx_hi of the io struct are such planes too); X = plane 1 of the forward's own fp16 operand (plain fp16(x), or
+  // a1 = fp16((1 - e) x) of an f16x2 encoding: the weight gradient is rescaled by 1 / (1 - e)); W^T = fp16 planes in p.wt_hi.  The
+  // attention backward multiplies fp16 as well: q / k / v = the hi plane of the fp16-split qkv planes the forward wrote, dO = an fp16 plane
+  // from the proj dgrad epilogue, P and dS rounded to fp16 (2^-11 per operand; with a bf16 attention backward the weight gradients of the
+  // first blocks stayed at 1.8e-2 whatever the GEMMs did, profiles/r06_fp16_backward_bringup.txt).
+  const bool h16 = Pb == 4;
+  constexpr float A1_INV = 1.0f / (1.0f - 0.015625f);         // csrc/f16x2.h: a1 = fp16((1 - 2^-6) x)
   const char* FA = (const char*)io.fwd_arena;
   char* A = (char*)io.bwd_arena;
   hipStream_t main_s = (hipStream_t)stream;
@@ -299,7 +324,7 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
     ph = at<egv_bf16>(FA, hi);
     pl = Pb == 3 ? at<egv_bf16>(FA, lo) : nullptr;
   };
-  const bool x2 = o.P == 2;              // f16x2 forward: the activations' single-pass operands are their bf16 copies
+  const bool x2 = o.P == 2 && !h16;      // f16x2 forward, bf16 backward: the activations' single-pass operands are their bf16 copies
   const egv_bf16 *n3_hi, *n3_lo, *at_hi, *at_lo, *n1_hi, *n1_lo, *as_hi, *as_lo, *n2_hi, *n2_lo, *h_hi, *h_lo, *qt_hi, *qt_lo, *qs_hi, *qs_lo;
   fpl(x2 ? F.n3_bf : F.n3_hi, F.n3_lo, n3_hi, n3_lo); fpl(F.at_hi, F.at_lo, at_hi, at_lo); fpl(x2 ? F.n1_bf : F.n1_hi, F.n1_lo, n1_hi, n1_lo);
   fpl(F.as_hi, F.as_lo, as_hi, as_lo); fpl(x2 ? F.n2_bf : F.n2_hi, F.n2_lo, n2_hi, n2_lo); fpl(x2 ? F.h_bf : F.h_hi, F.h_lo, h_hi, h_lo);
@@ -308,7 +333,13 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   // (delta = rowsum(dO o O) exact in O: egv_divided_attn_bwd)
   // (not when that plane holds fp16(value) for a single-product proj, egv_block_geom.f16_single bit 3: delta then comes from the bf16 plane)
   const bool proj1 = (g.f16_single & 8) != 0;
-  const egv_bf16 *as_lo_f = proj1 ? nullptr : at<egv_bf16>(FA, F.as_lo), *at_lo_f = proj1 ? nullptr : at<egv_bf16>(FA, F.at_lo);
+  const egv_bf16 *as_lo_f = (proj1 || h16) ? nullptr : at<egv_bf16>(FA, F.as_lo), *at_lo_f = (proj1 || h16) ? nullptr : at<egv_bf16>(FA, F.at_lo);
+  const int afmt = h16 ? (proj1 ? 3 : 2) : (proj1 ? 1 : 0);       // the format egv_block_fwd wrote the attention outputs in
+  const int amode = (afmt << 1) | (h16 ? 8 | 16 : 0);             // + dqkv as fp16, + q / k / v / dO read as fp16 (fp16 products throughout)
+  // weight-gradient rescale: X is a1 of an f16x2 encoding wherever the op does NOT run one product (egv_block_geom.f16_single)
+  const float walpha[6] = {h16 && !(g.f16_single & 4) ? A1_INV : 1.0f, h16 && !proj1 ? A1_INV : 1.0f, h16 && !(g.f16_single & 4) ? A1_INV : 1.0f,
+                           h16 && !proj1 ? A1_INV : 1.0f, h16 && !(g.f16_single & 1) ? A1_INV : 1.0f, h16 && !(g.f16_single & 2) ? A1_INV : 1.0f};
+  const int Pg = Pb;                     // passes code of every GEMM of the pass (4: one fp16 product)
   const float *tr = at<float>(FA, F.tr), *sr = at<float>(FA, F.sr);
   float* grads = io.grads;
 
@@ -326,8 +357,8 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
     egv_gemm_desc d = {};
     d.a_hi = dy_hi; d.a_lo = dy_lo; d.lda = lddy;
     d.b_hi = x_hi; d.b_lo = x_lo; d.ldb = ldx;
-    d.M = (int32_t)N; d.N = (int32_t)K; d.K = M; d.passes = Pb;
-    d.alpha = 1.0f;
+    d.M = (int32_t)N; d.N = (int32_t)K; d.K = M; d.passes = Pg;
+    d.alpha = walpha[i];
     d.out_f32 = grads + goff[i]; d.ldo = K;
     d.ksplit = io.wgrad_ksplit[i] > 1 ? io.wgrad_ksplit[i] : 1;
     d.partial = at<float>(A, L.partial[i]);
@@ -341,72 +372,76 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   const egv_bf16 *g_hi = io.g_hi, *g_lo = Pb == 3 ? io.g_lo : nullptr;
   if (!g_hi) {
     egv_bf16 *gh = at<egv_bf16>(A, L.g_hi), *gl = at<egv_bf16>(A, L.g_lo);
-    EGV_TRY(egv_split_f32(io.g_out, D, M, D, gh, gl, D, nullptr, nullptr, 0, nullptr, stream));
+    if (h16) EGV_TRY(egv_f16x2_encode(io.g_out, D, M, D, gh, nullptr, nullptr, D, 2, stream));
+    else EGV_TRY(egv_split_f32(io.g_out, D, M, D, gh, gl, D, nullptr, nullptr, 0, nullptr, stream));
     g_hi = gh; g_lo = gl;
   }
   // ---- MLP backward: dZ = (G . W2) * gelu'(z) leaves the fc2-dgrad epilogue already split
   egv_bf16 *dz_hi = at<egv_bf16>(A, L.dz_hi), *dz_lo = at<egv_bf16>(A, L.dz_lo);
   {
-    egv_gemm_desc d = nt_desc(g_hi, g_lo, D, p.wt_hi[5], p.wt_lo[5], p.ldwt[5], M, Hd, D, Pb, g.grid_cap);
-    d.act = EGV_ACT_GELU_BWD; d.aux_in = at<float>(FA, F.z); d.ldaux = Hd; d.aux_bf16 = g.z_bf16 ? 2 : 0;
+    egv_gemm_desc d = nt_desc(g_hi, g_lo, D, p.wt_hi[5], p.wt_lo[5], p.ldwt[5], M, Hd, D, Pg, g.grid_cap);
+    d.act = EGV_ACT_GELU_BWD; d.aux_in = at<float>(FA, F.z); d.ldaux = Hd; d.aux_bf16 = g.z_bf16 ? (h16 ? 3 : 2) : 0;
     d.out_hi = dz_hi; d.out_lo = dz_lo; d.ldoh = Hd;
+    if (h16) d.out_fmt = 4;               // dZ as one plane of un-clamped fp16
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   EGV_TRY(wgrad(5, g_hi, g_lo, D, h_hi, h_lo, Hd));
   EGV_TRY(wgrad(4, dz_hi, dz_lo, Hd, n2_hi, n2_lo, D));
   float* d_n2 = at<float>(A, L.d_n2);
   {
-    egv_gemm_desc d = nt_desc(dz_hi, dz_lo, Hd, p.wt_hi[4], p.wt_lo[4], p.ldwt[4], M, D, Hd, Pb, g.grid_cap);
+    egv_gemm_desc d = nt_desc(dz_hi, dz_lo, Hd, p.wt_hi[4], p.wt_lo[4], p.ldwt[4], M, D, Hd, Pg, g.grid_cap);
     d.out_f32 = d_n2; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   float* d_sr = at<float>(A, L.d_sr);
   egv_bf16 *dsr_hi = at<egv_bf16>(A, L.dsr_hi), *dsr_lo = at<egv_bf16>(A, L.dsr_lo);
-  EGV_TRY(egv_layernorm_bwd(d_n2, nullptr, nullptr, D, sr, D, p.n2w, at<float>(FA, F.mean2), at<float>(FA, F.rstd2), M, D, io.g_out, nullptr,
-                            d_sr, D, dsr_hi, dsr_lo, grads + goff[16], grads + goff[17], at<float>(A, L.ln_work), stream));
+  EGV_TRY(egv_layernorm_bwd_fmt(d_n2, nullptr, nullptr, D, sr, D, p.n2w, at<float>(FA, F.mean2), at<float>(FA, F.rstd2), M, D, io.g_out, nullptr,
+                            d_sr, D, dsr_hi, dsr_lo, h16 ? 1 : 0, grads + goff[16], grads + goff[17], at<float>(A, L.ln_work), stream));
   // ---- spatial attention backward
   EGV_TRY(wgrad(3, dsr_hi, dsr_lo, D, as_hi, as_lo, D));
   egv_bf16 *das_hi = at<egv_bf16>(A, L.das_hi), *das_lo = at<egv_bf16>(A, L.das_lo);
   {
-    egv_gemm_desc d = nt_desc(dsr_hi, dsr_lo, D, p.wt_hi[3], p.wt_lo[3], p.ldwt[3], M, D, D, Pb, g.grid_cap);
+    egv_gemm_desc d = nt_desc(dsr_hi, dsr_lo, D, p.wt_hi[3], p.wt_lo[3], p.ldwt[3], M, D, D, Pg, g.grid_cap);
     d.out_hi = das_hi; d.out_lo = das_lo; d.ldoh = D;
+    if (h16) d.out_fmt = 4;              // dO as one plane of un-clamped fp16
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   egv_bf16 *dqs_hi = at<egv_bf16>(A, L.dqkvs_hi), *dqs_lo = at<egv_bf16>(A, L.dqkvs_lo);
-  EGV_TRY(egv_divided_attn_bwd(qs_hi, qs_lo, as_hi, as_lo_f, das_hi, das_lo, at<float>(FA, F.lse_s), g.B, g.T, g.n, g.H, 0, Pb, dqs_hi, dqs_lo,
+  EGV_TRY(egv_divided_attn_bwd(qs_hi, qs_lo, as_hi, as_lo_f, das_hi, das_lo, at<float>(FA, F.lse_s), g.B, g.T, g.n, g.H, 0 | amode, h16 ? 1 : Pb, dqs_hi, dqs_lo,
                                at<float>(A, L.attn_work), stream));
   EGV_TRY(wgrad(2, dqs_hi, dqs_lo, 3 * D, n1_hi, n1_lo, D));
   float* d_n1 = at<float>(A, L.d_n1);
   {
-    egv_gemm_desc d = nt_desc(dqs_hi, dqs_lo, 3 * D, p.wt_hi[2], p.wt_lo[2], p.ldwt[2], M, D, 3 * D, Pb, g.grid_cap);
+    egv_gemm_desc d = nt_desc(dqs_hi, dqs_lo, 3 * D, p.wt_hi[2], p.wt_lo[2], p.ldwt[2], M, D, 3 * D, Pg, g.grid_cap);
     d.out_f32 = d_n1; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   float* d_tr = at<float>(A, L.d_tr);
   egv_bf16 *dtr_hi = at<egv_bf16>(A, L.dtr_hi), *dtr_lo = at<egv_bf16>(A, L.dtr_lo);
-  EGV_TRY(egv_layernorm_bwd(d_n1, nullptr, nullptr, D, tr, D, p.n1w, at<float>(FA, F.mean1), at<float>(FA, F.rstd1), M, D, nullptr, nullptr,
-                            d_tr, D, dtr_hi, dtr_lo, grads + goff[14], grads + goff[15], at<float>(A, L.ln_work), stream));
+  EGV_TRY(egv_layernorm_bwd_fmt(d_n1, nullptr, nullptr, D, tr, D, p.n1w, at<float>(FA, F.mean1), at<float>(FA, F.rstd1), M, D, nullptr, nullptr,
+                            d_tr, D, dtr_hi, dtr_lo, h16 ? 1 : 0, grads + goff[14], grads + goff[15], at<float>(A, L.ln_work), stream));
   // ---- temporal attention backward
   EGV_TRY(wgrad(1, dtr_hi, dtr_lo, D, at_hi, at_lo, D));
   egv_bf16 *dat_hi = at<egv_bf16>(A, L.dat_hi), *dat_lo = at<egv_bf16>(A, L.dat_lo);
   {
-    egv_gemm_desc d = nt_desc(dtr_hi, dtr_lo, D, p.wt_hi[1], p.wt_lo[1], p.ldwt[1], M, D, D, Pb, g.grid_cap);
+    egv_gemm_desc d = nt_desc(dtr_hi, dtr_lo, D, p.wt_hi[1], p.wt_lo[1], p.ldwt[1], M, D, D, Pg, g.grid_cap);
     d.out_hi = dat_hi; d.out_lo = dat_lo; d.ldoh = D;
+    if (h16) d.out_fmt = 4;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   egv_bf16 *dqt_hi = at<egv_bf16>(A, L.dqkvt_hi), *dqt_lo = at<egv_bf16>(A, L.dqkvt_lo);
-  EGV_TRY(egv_divided_attn_bwd(qt_hi, qt_lo, at_hi, at_lo_f, dat_hi, dat_lo, at<float>(FA, F.lse_t), g.B, g.T, g.n, g.H, 1, Pb, dqt_hi, dqt_lo,
+  EGV_TRY(egv_divided_attn_bwd(qt_hi, qt_lo, at_hi, at_lo_f, dat_hi, dat_lo, at<float>(FA, F.lse_t), g.B, g.T, g.n, g.H, 1 | amode, h16 ? 1 : Pb, dqt_hi, dqt_lo,
                                at<float>(A, L.attn_work), stream));
   EGV_TRY(wgrad(0, dqt_hi, dqt_lo, 3 * D, n3_hi, n3_lo, D));
   float* d_n3 = at<float>(A, L.d_n3);
   {
-    egv_gemm_desc d = nt_desc(dqt_hi, dqt_lo, 3 * D, p.wt_hi[0], p.wt_lo[0], p.ldwt[0], M, D, 3 * D, Pb, g.grid_cap);
+    egv_gemm_desc d = nt_desc(dqt_hi, dqt_lo, 3 * D, p.wt_hi[0], p.wt_lo[0], p.ldwt[0], M, D, 3 * D, Pg, g.grid_cap);
     d.out_f32 = d_n3; d.ldo = D;
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   // x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
-  EGV_TRY(egv_layernorm_bwd(d_n3, nullptr, nullptr, D, io.x, D, p.n3w, at<float>(FA, F.mean3), at<float>(FA, F.rstd3), M, D, d_tr, d_sr,
-                            io.d_x, D, io.dx_hi, Pb == 3 ? io.dx_lo : nullptr, grads + goff[12], grads + goff[13], at<float>(A, L.ln_work),
-                            stream));
+  EGV_TRY(egv_layernorm_bwd_fmt(d_n3, nullptr, nullptr, D, io.x, D, p.n3w, at<float>(FA, F.mean3), at<float>(FA, F.rstd3), M, D, d_tr, d_sr,
+                            io.d_x, D, io.dx_hi, Pb == 3 ? io.dx_lo : nullptr, h16 ? 1 : 0, grads + goff[12], grads + goff[13],
+                            at<float>(A, L.ln_work), stream));
   return EGV_OK;
 }

@@ -63,6 +63,32 @@ __device__ __forceinline__ u32x4_t f16_piece8(const float (&v)[8]) {
   for (int e = 0; e < 4; ++e) p[e] = f16x2_pack((_Float16)f16x2_clamp(v[2 * e]), (_Float16)f16x2_clamp(v[2 * e + 1]));
   return p;
 }
+// The same WITHOUT saturation: gradient planes of the fp16 backward.  A scaled gradient beyond fp16's range must become inf (and then
+// NaN / inf in every gradient behind it), because that is what the dynamic loss scale detects and answers with a skipped step and a
+// halved scale (egv_loss_scale_*); a clamp would silently train on a clipped gradient instead.
+__device__ __forceinline__ u32x4_t f16_grad_piece8(const float (&v)[8]) {
+  u32x4_t p;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p[e] = f16x2_pack((_Float16)v[2 * e], (_Float16)v[2 * e + 1]);
+  return p;
+}
+// eight consecutive values -> an fp16 SPLIT (hi = fp16(v), lo = fp16(v - hi); saturating): the qkv planes of the fp16 attention -- the
+// three-product forward multiplies (hi, lo) pairs like the split-bf16 one (fp32-grade), the backward reads hi alone (2^-11)
+__device__ __forceinline__ void f16_split8(const float (&v)[8], u32x4_t& p1, u32x4_t& p2) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a = f16x2_clamp(v[2 * e]), b = f16x2_clamp(v[2 * e + 1]);
+    const _Float16 h0 = (_Float16)a, h1 = (_Float16)b;
+    p1[e] = f16x2_pack(h0, h1);
+    p2[e] = f16x2_pack((_Float16)(a - (float)h0), (_Float16)(b - (float)h1));
+  }
+}
+__device__ __forceinline__ uint32_t f16_grad_pack2(float a, float b) { return f16x2_pack((_Float16)a, (_Float16)b); }
+// two fp16 values of one 32-bit word -> fp32
+__device__ __forceinline__ void f16x2_unpack(uint32_t w, float& a, float& b) {
+  a = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+  b = (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+}
 __device__ __forceinline__ u32x4_t bf16_piece8(const float (&v)[8]) {
   return (u32x4_t){f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]), f32x2_to_bf16x2(v[4], v[5]), f32x2_to_bf16x2(v[6], v[7])};
 }

@@ -21,6 +21,19 @@ __device__ __forceinline__ void encode_piece(const float* __restrict__ x, long l
   if (bf) *(u32x4_t*)(bf + (long)r * ldo + c) = bf16_piece8(v);
 }
 
+// fp32 [rows, cols] -> ONE plane of plain fp16, NOT saturating (role 2: a scaled gradient handed to the fp16 backward as fp32 --
+// the loss gradient arriving at the last block, or a block input gradient whose plane hand-over was dropped)
+__global__ __launch_bounds__(256) void f16_cast_kernel(const float* __restrict__ x, long ldx, int rows, int cols,
+                                                       unsigned short* __restrict__ p1, long ldo) {
+  const long piece = (long)blockIdx.x * 256 + threadIdx.x;
+  if (piece >= (long)rows * (cols >> 3)) return;
+  const int ppr = cols >> 3;
+  const int r = (int)(piece / ppr), c = (int)(piece - (long)r * ppr) * 8;
+  const f32x4_t a = *(const f32x4_t*)(x + (long)r * ldx + c), b = *(const f32x4_t*)(x + (long)r * ldx + c + 4);
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  *(u32x4_t*)(p1 + (long)r * ldo + c) = f16_grad_piece8(v);
+}
+
 template <int ROLE>
 __global__ __launch_bounds__(256) void f16x2_encode_kernel(const float* __restrict__ x, long ldx, int rows, int cols,
                                                            unsigned short* __restrict__ p1, unsigned short* __restrict__ p2,
@@ -121,11 +134,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_f16x2_kernel(
 
 extern "C" int egv_f16x2_encode(const float* x, int64_t ldx, int32_t rows, int32_t cols, uint16_t* p1, uint16_t* p2, egv_bf16* bf,
                                 int64_t ldo, int32_t role, void* stream) {
-  if (!x || !p1 || !p2 || rows <= 0 || cols <= 0 || cols % 8 != 0 || ldo % 8 != 0 || ldx % 4 != 0 || (role != 0 && role != 1))
+  if (!x || !p1 || (!p2 && role != 2) || rows <= 0 || cols <= 0 || cols % 8 != 0 || ldo % 8 != 0 || ldx % 4 != 0 || role < 0 || role > 2)
     return EGV_ERR_ARG;
   const long pieces = (long)rows * (cols >> 3);
   const dim3 grid((unsigned)((pieces + 255) / 256));
-  if (role == 0)
+  if (role == 2)
+    EGV_LAUNCH(f16_cast_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, rows, cols, p1, (long)ldo);
+  else if (role == 0)
     EGV_LAUNCH(f16x2_encode_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, rows, cols, p1, p2, bf, (long)ldo);
   else
     EGV_LAUNCH(f16x2_encode_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)ldx, rows, cols, p1, p2, bf, (long)ldo);

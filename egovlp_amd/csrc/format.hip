@@ -1,6 +1,7 @@
 // Format kernels: fp32 <-> split-bf16 planes, transposes (+ column sums = bias gradients),
 // patch gather, token assembly.  All HBM-bound: 16-byte global accesses, LDS only for transposes.
 #include "common.h"
+#include "f16x2.h"
 #include "egovlp_hip.h"
 
 namespace {
@@ -14,7 +15,9 @@ template <bool SRC_PLANES>
 __device__ __forceinline__ void split_transpose_tile(
     const float* __restrict__ x, const bf16_t* __restrict__ xh, const bf16_t* __restrict__ xl, long ldx, int rows,
     int cols, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long ldo, bf16_t* __restrict__ thi,
-    bf16_t* __restrict__ tlo, long ldt, float* __restrict__ colsum, const int r0, const int c0, const int text) {
+    bf16_t* __restrict__ tlo, long ldt, float* __restrict__ colsum, const int r0, const int c0, const int text,
+    unsigned short* __restrict__ t16 = nullptr) {
+  // t16 (optional): the transposed matrix as ONE plane of plain fp16 [cols, ldt] -- W^T for the dgrad GEMMs of the fp16 backward
   // text: columns of the transposed planes this tensor owns (>= rows; rows .. text-1 are zero-filled)
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
@@ -62,6 +65,18 @@ __device__ __forceinline__ void split_transpose_tile(
       if (c0 + tid < cols) atomicAdd(colsum + c0 + tid, s);
     }
   }
+  if (t16) {
+#pragma unroll
+    for (int cc = 0; cc < 64; cc += 16) {
+      const int c = c0 + cc + tr, r = r0 + tc;
+      if (c < cols && r < text) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (r + e < rows) ? f16x2_clamp(tile[tc + e][cc + tr]) : 0.f;
+        *(u32x2_t*)(t16 + (long)c * ldt + r) = (u32x2_t){f16x2_pack((_Float16)v[0], (_Float16)v[1]), f16x2_pack((_Float16)v[2], (_Float16)v[3])};
+      }
+    }
+  }
   if (thi) {
     // transposed write: output row = column index c, output col = row index r (contiguous over r)
 #pragma unroll
@@ -100,6 +115,7 @@ struct SplitTable {
   bf16_t* lo[SPLIT_MAX_T];
   bf16_t* thi[SPLIT_MAX_T];
   bf16_t* tlo[SPLIT_MAX_T];
+  unsigned short* t16[SPLIT_MAX_T];
   int ldx[SPLIT_MAX_T], ldo[SPLIT_MAX_T], ldt[SPLIT_MAX_T], rows[SPLIT_MAX_T], cols[SPLIT_MAX_T], text[SPLIT_MAX_T];
   int tiles_x[SPLIT_MAX_T];
   int blk_start[SPLIT_MAX_T + 1];
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256) void split_multi_kernel(const SplitTable t) {
   const int local = (int)blockIdx.x - t.blk_start[ti];
   const int ty = local / t.tiles_x[ti], tx = local - ty * t.tiles_x[ti];
   split_transpose_tile<false>(t.x[ti], nullptr, nullptr, t.ldx[ti], t.rows[ti], t.cols[ti], t.hi[ti], t.lo[ti], t.ldo[ti],
-                              t.thi[ti], t.tlo[ti], t.ldt[ti], nullptr, ty * 64, tx * 64, t.text[ti]);
+                              t.thi[ti], t.tlo[ti], t.ldt[ti], nullptr, ty * 64, tx * 64, t.text[ti], t.t16[ti]);
 }
 
 // relu(x) -> split planes (txt_proj's ReLU, model/model.py:73)
@@ -334,10 +350,21 @@ extern "C" int egv_split_f32(const float* x, int64_t ldx, int32_t rows, int32_t 
   return EGV_OK;
 }
 
+extern "C" int egv_split_f32_multi_t16(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows,
+                                       const int32_t* cols, egv_bf16* const* hi, egv_bf16* const* lo, const int64_t* ldo,
+                                       egv_bf16* const* t_hi, egv_bf16* const* t_lo, const int64_t* ldt, const int32_t* t_cols,
+                                       uint16_t* const* t16, void* stream);
 extern "C" int egv_split_f32_multi(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows,
                                    const int32_t* cols, egv_bf16* const* hi, egv_bf16* const* lo, const int64_t* ldo,
                                    egv_bf16* const* t_hi, egv_bf16* const* t_lo, const int64_t* ldt, const int32_t* t_cols,
                                    void* stream) {
+  return egv_split_f32_multi_t16(count, x, ldx, rows, cols, hi, lo, ldo, t_hi, t_lo, ldt, t_cols, nullptr, stream);
+}
+
+extern "C" int egv_split_f32_multi_t16(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows,
+                                       const int32_t* cols, egv_bf16* const* hi, egv_bf16* const* lo, const int64_t* ldo,
+                                       egv_bf16* const* t_hi, egv_bf16* const* t_lo, const int64_t* ldt, const int32_t* t_cols,
+                                       uint16_t* const* t16, void* stream) {
   if (count < 0 || !x || !ldx || !rows || !cols || !hi || !lo || !ldo || !t_hi || !t_lo || !ldt || !t_cols) return EGV_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   SplitTable t;
@@ -353,17 +380,20 @@ extern "C" int egv_split_f32_multi(int32_t count, const float* const* x, const i
     return EGV_OK;
   };
   for (int i = 0; i < count; ++i) {
-    if (!x[i] || rows[i] <= 0 || cols[i] <= 0 || cols[i] % 4 != 0 || (!hi[i] && !t_hi[i])) return EGV_ERR_ARG;
-    if (t_hi[i] && (ldt[i] < rows[i] || ldt[i] % 4 != 0 || t_cols[i] < rows[i] || t_cols[i] > ldt[i] || t_cols[i] % 4 != 0)) return EGV_ERR_ARG;
+    unsigned short* const tf = t16 ? t16[i] : nullptr;
+    const bool has_t = t_hi[i] || tf;
+    if (!x[i] || rows[i] <= 0 || cols[i] <= 0 || cols[i] % 4 != 0 || (!hi[i] && !has_t)) return EGV_ERR_ARG;
+    if (has_t && (ldt[i] < rows[i] || ldt[i] % 4 != 0 || t_cols[i] < rows[i] || t_cols[i] > ldt[i] || t_cols[i] % 4 != 0)) return EGV_ERR_ARG;
     if (ldx[i] > 0x7fffffff || ldo[i] > 0x7fffffff || ldt[i] > 0x7fffffff) return EGV_ERR_ARG;
     if (nt == SPLIT_MAX_T) {
       const int rc = flush();
       if (rc) return rc;
     }
-    const int row_extent = t_hi[i] ? t_cols[i] : rows[i];   // cover this tensor's share of the zero pad of the transposed planes
+    const int row_extent = has_t ? t_cols[i] : rows[i];   // cover this tensor's share of the zero pad of the transposed planes
     const int tx = (cols[i] + 63) / 64, ty = (row_extent + 63) / 64;
     t.x[nt] = x[i]; t.hi[nt] = hi[i]; t.lo[nt] = lo[i]; t.thi[nt] = t_hi[i]; t.tlo[nt] = t_lo[i];
-    t.ldx[nt] = (int)ldx[i]; t.ldo[nt] = (int)ldo[i]; t.ldt[nt] = (int)ldt[i]; t.rows[nt] = rows[i]; t.cols[nt] = cols[i]; t.text[nt] = t_hi[i] ? t_cols[i] : rows[i];
+    t.ldx[nt] = (int)ldx[i]; t.ldo[nt] = (int)ldo[i]; t.ldt[nt] = (int)ldt[i]; t.rows[nt] = rows[i]; t.cols[nt] = cols[i]; t.text[nt] = has_t ? t_cols[i] : rows[i];
+    t.t16[nt] = tf;
     t.tiles_x[nt] = tx;
     t.blk_start[nt] = nb;
     nb += tx * ty;
@@ -487,7 +517,13 @@ extern "C" int egv_embed_bwd(const int64_t* ids, const float* d_e, int32_t B, in
   return EGV_OK;
 }
 
-extern "C" int egv_version(void) { return 1; }
+extern "C" int egv_version(void) { return EGV_ABI_VERSION; }
+extern "C" int egv_abi_check(int32_t abi_version, int64_t sizeof_gemm_desc, int64_t sizeof_block_geom, int64_t sizeof_block_params,
+                             int64_t sizeof_block_bwd_io) {
+  return (abi_version == EGV_ABI_VERSION && sizeof_gemm_desc == (int64_t)sizeof(egv_gemm_desc) &&
+          sizeof_block_geom == (int64_t)sizeof(egv_block_geom) && sizeof_block_params == (int64_t)sizeof(egv_block_params) &&
+          sizeof_block_bwd_io == (int64_t)sizeof(egv_block_bwd_io)) ? 0 : 1;
+}
 
 
 // ---- elementwise dropout (DistilBERT embedding / FFN dropout, HF modeling_distilbert.py Embeddings.forward, FFN.ff_chunk) -------

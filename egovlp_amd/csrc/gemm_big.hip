@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   constexpr bool F3 = PROD >= 2;      // the fused stage layout ([A_hi | A_lo | B_hi | B_lo] x 64 B, 32-deep k-tiles)
   constexpr bool IS_GELU = EPI == EPI_GELU || EPI == EPI_GELU_X2;
   static_assert(PROD >= 0 && PROD <= 3, "");
-  static_assert(!TN || PROD == 0, "weight gradients are single bf16 products");
+  static_assert(!TN || PROD == 0 || PROD == 1, "weight gradients are single products: bf16, or fp16 (PROD 1: the fp16 backward)");
   static_assert(!MIXED || (F3 && MF == 5 && !TN), "mixed row bands: the fused NT instances with 320-row tiles");
   static_assert(EPI != EPI_GELU_X2 || X2 || H1, "fp16 operand outputs are produced by the fp16 instances only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -403,8 +403,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
     }
   };
 
-  const s16x8v ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  // 1.0 in the operand type of this instance (bf16 0x3F80, fp16 0x3C00): the column-sum MFMA of the TN loop
+  constexpr short ONE16 = H1 ? (short)0x3C00 : (short)0x3F80;
+  const s16x8v ones_s = {ONE16, ONE16, ONE16, ONE16, ONE16, ONE16, ONE16, ONE16};
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+  // one product of the plain loops (NT single plane, TN): the bf16 opcode, or -- H1 -- the fp16 one on the same registers
+  auto mma1 = [&](const bf16x8_t& b, const bf16x8_t& a, f32x4_t c) -> f32x4_t {
+    if constexpr (H1) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
+  };
 
   // ---- per-output-tile state (all wave-uniform) ----------------------------------------------------------------
   int m0, n0, z, tn, kt_begin, kt_end, nt;    // current tile
@@ -689,10 +696,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
       //   phase 5: B(7)                phase 6: -               (B two phases ahead, A(k-step 1) four)
       // The DMA of k-tile t+1 (into the stage freed by the barrier that ended t-1) is issued by waves 0-3 over phases
       // 0-3, a few pieces each: a burst of all NP blocks the issuing wave ~1300 cycles on the 64 B/clk L1->LDS path.
-      auto mma1 = [&](const bf16x8_t& b, const bf16x8_t& a, f32x4_t c) -> f32x4_t {
-        if constexpr (H1) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
-        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c, 0, 0, 0);
-      };
       auto k_tile = [&](const int t) {
         const bool HN = t + 1 < nt;            // wave-uniform: scalar branches around the DMA issue and the hand-over
         const int sb = (t & 1) * STAGE;
@@ -805,10 +808,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
           if (c == 0 && cs_on) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
-              cs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, A[TN ? 0 : (ks & 1)][i], cs[i], 0, 0, 0);
+              cs[i] = mma1(ones, A[TN ? 0 : (ks & 1)][i], cs[i]);
           }
-          acc[0][c * NC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph % 3)][0], A[TN ? 0 : (ks & 1)][0],
-                                                                   acc[0][c * NC], 0, 0, 0);
+          acc[0][c * NC] = mma1(Bq[TN ? 0 : (ph % 3)][0], A[TN ? 0 : (ks & 1)][0], acc[0][c * NC]);
           __builtin_amdgcn_sched_barrier(0);
           if (last) {
             if (t + 1 < nt) {
@@ -858,8 +860,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
 #pragma unroll
             for (int i = 0; i < MF; ++i)
               if (jj + i > 0)
-                acc[i][c * NC + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bq[TN ? 0 : (ph % 3)][jj], A[TN ? 0 : (ks & 1)][i],
-                                                                              acc[i][c * NC + jj], 0, 0, 0);
+                acc[i][c * NC + jj] = mma1(Bq[TN ? 0 : (ph % 3)][jj], A[TN ? 0 : (ks & 1)][i], acc[i][c * NC + jj]);
           __builtin_amdgcn_sched_barrier(0);
           if (TN) {   // the asm reads issued above have had this phase's MFMAs to land: wait, then assemble the fragments
             if (last) {
@@ -1026,6 +1027,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             for (int it = 0; EGV_COLD_LOOP(it < 8); ++it) {
               f32x4_t val = *(const f32x4_t*)(smem + ((r32 + it * 1024) ^ ((it & 3) << 5)));
               if (EPI == EPI_LINEAR) val += bias4;
+              if constexpr (TN) val *= p.alpha;    // weight gradients: a static factor of the saved operand's encoding (slabs and direct output alike; the column sums are not scaled)
               egv_store16<EGV_NT_GEMM_F32>(d, val);
               d += ld2;
             }
@@ -1064,7 +1066,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         // f16x2 outputs: the bf16 copy for the backward at a fixed element distance from the first fp16 plane (0: not wanted)
         const long dbf = (EPI == EPI_GELU_X2 && p.out_bf) ? (long)(p.out_bf - p.out_hi) : 0;
         const long ldz4 = 4 * p.ldaux;
-        const bool saved_grad = p.aux_bf16 == 2;
+        const bool saved_grad = p.aux_bf16 >= 2;
+        const bool aux_f16 = (H1 || X2) && p.aux_bf16 == 3;       // the saved gelu' as fp16 (the fp16 backward: bf16's 2^-9 would cap dZ's accuracy)
+        // fp16 plane outputs of the plain epilogues (out_fmt 4: ONE plane of un-clamped fp16 -- a scaled gradient: dZ, the dO of the
+        // attention backward; out_fmt 3: an fp16 split (hi, lo) -- the qkv planes of the fp16 attention)
+        const bool grad_f16 = H1 && (EPI == EPI_GELU_BWD || EPI == EPI_LINEAR) && p.out_fmt == 4;
+        const bool split_f16 = (H1 || X2) && EPI == EPI_LINEAR && p.out_fmt == 3;
         auto row16 = [&](const int it, const f32x4_t zin) {
           const unsigned a0 = (r16 + it * 2048) ^ ((it & 1) << 6);
           f32x4_t v0 = *(const f32x4_t*)(smem + a0) + b0, v1 = *(const f32x4_t*)(smem + (a0 ^ 16u)) + b1;
@@ -1082,13 +1089,28 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
               v1[e] *= c1;
             }
             if (dz) {
-              egv_store16<EGV_NT_SAVED>(dz, (u32x4_t){f32x2_to_bf16x2(s0[0], s0[1]), f32x2_to_bf16x2(s0[2], s0[3]),
-                                        f32x2_to_bf16x2(s1[0], s1[1]), f32x2_to_bf16x2(s1[2], s1[3])});
+              if (aux_f16)
+                egv_store16<EGV_NT_SAVED>(dz, (u32x4_t){f16_grad_pack2(s0[0], s0[1]), f16_grad_pack2(s0[2], s0[3]),
+                                          f16_grad_pack2(s1[0], s1[1]), f16_grad_pack2(s1[2], s1[3])});
+              else
+                egv_store16<EGV_NT_SAVED>(dz, (u32x4_t){f32x2_to_bf16x2(s0[0], s0[1]), f32x2_to_bf16x2(s0[2], s0[3]),
+                                          f32x2_to_bf16x2(s1[0], s1[1]), f32x2_to_bf16x2(s1[2], s1[3])});
               dz += ldz4;
             }
           } else if constexpr (EPI == EPI_GELU_BWD) {
             const u32x4_t zb = __builtin_bit_cast(u32x4_t, zin);
-            if (saved_grad) {
+            if (aux_f16) {
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                float a, b;
+                f16x2_unpack(zb[e], a, b);
+                v0[2 * e] *= a;
+                v0[2 * e + 1] *= b;
+                f16x2_unpack(zb[2 + e], a, b);
+                v1[2 * e] *= a;
+                v1[2 * e + 1] *= b;
+              }
+            } else if (saved_grad) {
 #pragma unroll
               for (int e = 0; e < 2; ++e) {
                 v0[2 * e] *= __uint_as_float(zb[e] << 16);
@@ -1119,6 +1141,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
               egv_store16<PSITE>(dh + dlo, o2);
             }
             if (dbf) egv_store16<PSITE>(dh + dbf, bf16_piece8(vv));
+          } else if (grad_f16) {
+            const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            egv_store16<PSITE>(dh, f16_grad_piece8(vv));
+          } else if (split_f16) {
+            const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            u32x4_t o1, o2;
+            f16_split8(vv, o1, o2);
+            egv_store16<PSITE>(dh, o1);
+            egv_store16<PSITE>(dh + dlo, o2);
           } else {
             uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
             split_bf16x2(v0[0], v0[1], h0, l0);
@@ -1254,17 +1285,30 @@ template <int MF, bool TN, int PROD = 0>
 int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
   // fp16 operand outputs (fc1 -> fc2 of the forward): GELU epilogue of an fp16 product only, planes only; 1 = f16x2 (two planes), 2 = one plain plane
   if (p.out_fmt != 0) {
-    if (!(PROD == 1 || PROD == 2) || (p.out_fmt != 1 && p.out_fmt != 2)) return EGV_ERR_ARG;
-    if (p.act != EGV_ACT_GELU || p.alpha != 1.0f || !p.out_hi || (p.out_fmt == 1 && !p.out_lo) || p.residual || p.out_f32 ||
-        (p.aux_out && !p.aux_bf16) || p.ldoh % 8 != 0 || p.ksplit > 1 || TN)
+    if (!(PROD == 1 || PROD == 2) || p.out_fmt < 1 || p.out_fmt > 4) return EGV_ERR_ARG;
+    // fp16 plane outputs: the GELU epilogue (h for fc2: 1 / 2); the plain epilogue as an fp16 split (3: the qkv planes of the fp16
+    // attention); and -- one fp16 product only -- un-clamped gradient planes (4): dZ from the GELU' epilogue, dO from a plain dgrad
+    const bool gelu_fwd = p.act == EGV_ACT_GELU && (p.out_fmt == 1 || p.out_fmt == 2);
+    const bool gelu_bwd16 = PROD == 1 && p.act == EGV_ACT_GELU_BWD && p.out_fmt == 4 && p.aux_in && p.aux_bf16 >= 2 && !p.bias;
+    const bool lin_split = p.act == EGV_ACT_NONE && p.out_fmt == 3 && p.out_lo;
+    const bool lin_grad = PROD == 1 && p.act == EGV_ACT_NONE && p.out_fmt == 4 && !p.bias;
+    if (!(gelu_fwd || gelu_bwd16 || lin_split || lin_grad) || p.alpha != 1.0f || !p.out_hi || (p.out_fmt == 1 && !p.out_lo) || p.residual ||
+        p.out_f32 || (p.aux_out && !p.aux_bf16) || p.ldoh % 8 != 0 || p.ksplit > 1 || TN)
       return EGV_ERR_ARG;
   }
+  if (p.aux_bf16 == 3 && PROD != 1 && PROD != 2) return EGV_ERR_ARG;         // fp16 saved gelu': the fp16 instances only
   if constexpr (PROD == 1) {
-    // ONE fp16 product: the two forward epilogues of the step that use it (fc2: bias + residual -> fp32; fc1: GELU -> fp16 operand planes)
-    if (p.ksplit > 1 || TN || p.alpha != 1.0f) return EGV_ERR_ARG;
-    if (p.act == EGV_ACT_NONE) return launch_big<MF, false, EPI_LINEAR, 1>(p, s);
-    if (p.act == EGV_ACT_GELU && p.out_fmt != 0) return launch_big<MF, false, EPI_GELU_X2, 1>(p, s);
-    return EGV_ERR_ARG;
+    // ONE fp16 product.  Forward: fc2 / proj (bias + residual -> fp32), qkv (bias -> planes), fc1 (GELU -> fp16 operand planes).  The fp16
+    // backward (scaled gradients): every dgrad (-> fp32 / planes; fc2's with the GELU' epilogue) and, TN, every weight gradient.
+    if constexpr (TN) {
+      return launch_big<4, true, EPI_RAW, 1>(p, s);              // slabs or direct fp32 output, x alpha
+    } else {
+      if (p.ksplit > 1 || p.alpha != 1.0f) return EGV_ERR_ARG;
+      if (p.act == EGV_ACT_NONE) return launch_big<MF, false, EPI_LINEAR, 1>(p, s);
+      if (p.act == EGV_ACT_GELU && p.out_fmt != 0) return launch_big<MF, false, EPI_GELU_X2, 1>(p, s);
+      if (p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD, 1>(p, s);
+      return EGV_ERR_ARG;
+    }
   } else {
     if (p.ksplit > 1 || TN) {
       if (PROD == 2) return EGV_ERR_ARG;                              // f16x2: forward products only (un-split, NT)
@@ -1311,7 +1355,7 @@ bool egv_gemm_big_supports(const egv_gemm_desc& p) {
   if (p.lda % 8 != 0 || p.ldb % 8 != 0) return false;
   if (p.trans)
     return p.M % 8 == 0 && p.N % 8 == 0 && p.out_f32 != nullptr && p.act == EGV_ACT_NONE && !p.bias && !p.residual &&
-           !p.out_hi && p.alpha == 1.0f;
+           !p.out_hi;
   return p.K % KT == 0;
 }
 
@@ -1335,7 +1379,7 @@ int egv_gemm_big_pick_mf(const egv_gemm_desc& p) {
 
 // variant: 0 / 3 = auto; 4 / 5 force MF (diagnostics)
 int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant) {
-  if (p.trans) return launch_epi<4, true>(p, s);
+  if (p.trans) return p.passes == 4 ? launch_epi<4, true, 1>(p, s) : launch_epi<4, true>(p, s);
   int mf = (variant % 10 == 4 || variant % 10 == 5) ? variant % 10 : egv_gemm_big_pick_mf(p);
   if (p.M < mf * 64) mf = 4;
   // bf16x3 (parity-grade) NT products run the fused three-product loop; the three-k-segment form of the plain loop stays

@@ -252,7 +252,7 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   if (!p.a_hi || !p.b_hi) return EGV_ERR_ARG;
   if (p.passes < 1 || p.passes > 4) return EGV_ERR_ARG;
   if ((p.passes == 2 || p.passes == 3) && (!p.a_lo || !p.b_lo)) return EGV_ERR_ARG;
-  if (p.out_fmt < 0 || p.out_fmt > 2) return EGV_ERR_ARG;
+  if (p.out_fmt < 0 || p.out_fmt > 4) return EGV_ERR_ARG;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return EGV_ERR_ARG;
   if (p.N % 4 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0) return EGV_ERR_ARG;
   if (!p.trans && p.K % BK != 0) return EGV_ERR_ARG;
@@ -261,10 +261,15 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
   if (p.grid_cap != 0 && (p.grid_cap < 8 || p.grid_cap > 256 || p.grid_cap % 8 != 0)) return EGV_ERR_ARG;
   const int variant = gemm_variant(p);
   if (variant < 0) return EGV_ERR_ARG;
-  if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // bf16 aux: gemm_big GELU epilogues only
-  // fp16 operands / outputs (csrc/f16x2.h; passes 2 = f16x2, 4 = one plain fp16 plane): the big-tile NT kernel only, un-split
-  if ((p.passes == 2 || p.passes == 4 || p.out_fmt != 0) && (variant < 3 || p.trans || (p.passes != 2 && p.passes != 4) || p.ksplit > 1))
-    return EGV_ERR_ARG;
+  if (p.aux_bf16 < 0 || p.aux_bf16 > 3) return EGV_ERR_ARG;
+  if (p.aux_bf16 && (variant < 3 || p.act == EGV_ACT_RELU_BWD)) return EGV_ERR_ARG;   // 16-bit aux: gemm_big GELU epilogues only
+  if (p.aux_bf16 == 3 && p.passes != 4 && p.passes != 2) return EGV_ERR_ARG;           // fp16 gelu': fp16-product launches only
+  // fp16 operands / outputs (csrc/f16x2.h; passes 2 = f16x2, 4 = one plain fp16 plane): the big-tile kernel only; NT un-split, or
+  // (passes 4) the TN weight gradient of the fp16 backward with its k-slices
+  if ((p.passes == 2 || p.passes == 4 || p.out_fmt != 0) && (variant < 3 || (p.passes != 2 && p.passes != 4))) return EGV_ERR_ARG;
+  if ((p.passes == 2 || p.out_fmt != 0) && (p.trans || p.ksplit > 1)) return EGV_ERR_ARG;
+  if (p.passes == 4 && !p.trans && p.ksplit > 1) return EGV_ERR_ARG;
+  if (p.alpha != 1.0f && p.trans && !(p.alpha > 0.f)) return EGV_ERR_ARG;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int ks = p.ksplit > 1 ? p.ksplit : 1;
   dim3 grid(tiles, ks), block(256);

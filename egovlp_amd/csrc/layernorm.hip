@@ -3,6 +3,7 @@
 // wave shuffles (two-pass mean / centred variance, matching the fp32 reference's numerics), outputs
 // written once as split-bf16 planes (the next GEMM's operand format) and/or fp32.
 #include "common.h"
+#include "f16x2.h"
 #include "egovlp_hip.h"
 
 namespace {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 2) void layernorm_bwd_kernel(
     const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, int rows, int cols, const float* __restrict__ add1,
     const float* __restrict__ add2, float* __restrict__ dx, long lddx, bf16_t* __restrict__ dxh,
-    bf16_t* __restrict__ dxl, float* __restrict__ work, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    bf16_t* __restrict__ dxl, float* __restrict__ work, float* __restrict__ dgamma, float* __restrict__ dbeta, int dx_fmt) {
   __shared__ float red[2][4][NV * 256];   // [dgamma/dbeta][wave][col]
   if (blockIdx.x == 0) {   // the reduce kernel (next launch on the stream) accumulates into these with atomics
     for (int c = threadIdx.x; c < cols; c += 256) {
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 2) void layernorm_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2) + ad[i][e];
         egv_store<EGV_NT_LN>(dx + (long)row * lddx + c4 * 4, o);
-        if (dxh) {   // the same gradient as the next GEMM's operand (row-major split-bf16 planes, ld = cols)
+        if (dxh && dx_fmt == 1) {   // ... as ONE plane of un-clamped fp16 (the fp16 backward: a scaled gradient; overflow -> inf -> skipped step)
+          egv_store<EGV_NT_LN>(dxh + (long)row * cols + c4 * 4, (u32x2_t){f16_grad_pack2(o[0], o[1]), f16_grad_pack2(o[2], o[3])});
+        } else if (dxh) {   // the same gradient as the next GEMM's operand (row-major split-bf16 planes, ld = cols)
           uint32_t h0, h1, l0, l1;
           split_bf16x2(o[0], o[1], h0, l0);
           split_bf16x2(o[2], o[3], h1, l1);
@@ -240,14 +243,24 @@ extern "C" int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const e
                                  const float* mean, const float* rstd, int32_t rows, int32_t cols, const float* add1,
                                  const float* add2, float* dx, int64_t lddx, egv_bf16* dx_hi, egv_bf16* dx_lo,
                                  float* dgamma, float* dbeta, float* work, void* stream) {
+  return egv_layernorm_bwd_fmt(dy, dy_hi, dy_lo, lddy, x, ldx, gamma, mean, rstd, rows, cols, add1, add2, dx, lddx, dx_hi, dx_lo, 0,
+                               dgamma, dbeta, work, stream);
+}
+
+extern "C" int egv_layernorm_bwd_fmt(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
+                                     const float* x, int64_t ldx, const float* gamma,
+                                     const float* mean, const float* rstd, int32_t rows, int32_t cols, const float* add1,
+                                     const float* add2, float* dx, int64_t lddx, egv_bf16* dx_hi, egv_bf16* dx_lo, int32_t dx_fmt,
+                                     float* dgamma, float* dbeta, float* work, void* stream) {
   if ((!dy && !dy_hi) || !x || !gamma || !mean || !rstd || !dx || !work) return EGV_ERR_ARG;
+  if (dx_fmt < 0 || dx_fmt > 1 || (dx_fmt == 1 && dx_lo)) return EGV_ERR_ARG;
   if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
   const int parts = egv_layernorm_bwd_parts(rows);
   hipStream_t s = (hipStream_t)stream;
   const int nv64 = (cols / 4 + 63) / 64;      // float4 per lane
 #define EGV_LN_BWD(NV)                                                                                                      \
   EGV_LAUNCH(layernorm_bwd_kernel<NV>, dim3(parts), dim3(256), 0, s, dy, dy_hi, dy_lo, lddy, x, ldx, gamma, mean, rstd, rows, \
-             cols, add1, add2, dx, lddx, dx_hi, dx_lo, work, dgamma, dbeta)
+             cols, add1, add2, dx, lddx, dx_hi, dx_lo, work, dgamma, dbeta, dx_fmt)
   if (nv64 <= 1) EGV_LN_BWD(1);
   else if (nv64 == 2) EGV_LN_BWD(2);
   else if (nv64 == 3) EGV_LN_BWD(3);

@@ -56,7 +56,7 @@ class _ProjFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2d, w = ctx.saved_tensors
         ec = ctx.ec
-        Pb = ec.bwd_passes
+        Pb = ec.bwd_passes_split
         N, Np = w.shape[0], ctx.Np
         if not ec.on_text_stream():
             ec.poll_backward()          # vid_proj: the first node of the video tower's backward on the main stream

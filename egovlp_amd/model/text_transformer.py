@@ -121,7 +121,7 @@ class _TextLayerFn(torch.autograd.Function):
         B, L, H, eps, drop = ctx.geom
         ec = ctx.ec
         wc = ec.wc
-        Pb = ec.bwd_passes
+        Pb = ec.bwd_passes_split
         if Pb > ctx.P:
             raise RuntimeError("backward precision bf16x3 needs a bf16x3 forward")
         M, D = s1.shape
@@ -165,7 +165,7 @@ def text_calls_ok(ec: ExecContext, M, D, Hd, H):
     """May this layer run through the C layer calls?  (split-bf16 / bf16 precision, no per-kernel timer, widths the TN kernel takes
     without an explicit transpose, and the weight gradients on the layer's own stream: the text tower on its side stream -- the
     default -- or no wgrad side streams at all; everything else keeps the per-kernel path)"""
-    if not ec.block_calls or ec.kernel_timer is not None or ec.fwd_passes_split not in (1, 3) or ec.bwd_passes > ec.fwd_passes_split:
+    if not ec.block_calls or ec.kernel_timer is not None or ec.fwd_passes_split not in (1, 3) or ec.bwd_passes_split > ec.fwd_passes_split:
         return False
     if D < 256 or Hd < 256 or D % 64 or Hd % 64 or D != H * 64:
         return False
@@ -225,7 +225,7 @@ class _TextLayerCFn(torch.autograd.Function):
         D = x.shape[-1]
         M = B * L
         Hd = f1_w.shape[0]
-        P, Pb = ec.fwd_passes_split, ec.bwd_passes
+        P, Pb = ec.fwd_passes_split, ec.bwd_passes_split
         dev = x.device
         x2 = x.contiguous().view(M, D)
         mask = mask.contiguous()
@@ -263,7 +263,7 @@ class _TextLayerCFn(torch.autograd.Function):
         if ctx.arena is None:
             raise RuntimeError("the C layer calls release their forward workspace after the first backward: a second backward through "
                                "the same graph (retain_graph=True) needs the per-kernel path (exec_ctx.set(block_calls=False))")
-        if ec.bwd_passes != g.bwd_passes:
+        if ec.bwd_passes_split != g.bwd_passes:
             raise RuntimeError("the backward precision changed between this layer's forward and its backward")
         B, L, D = g.B, g.L, g.D
         M = B * L

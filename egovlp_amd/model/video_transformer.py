@@ -37,9 +37,17 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, pa
     padded head), so the weight gradient stays on the current stream.
     -> (dx fp32 [M,K] | None, dW fp32 [N,K], db [N])."""
     ec = ops.DEFAULT if ec is None else ec
-    if not isinstance(dy, Planes):
-        dy = ops.split_f32(dy, Pb)[0]
-    x_pl = x_pl.bwd()              # an f16x2 forward operand hands over its bf16 plane
+    alpha = 1.0
+    if Pb == 4:
+        # the fp16 backward: dy = ONE plane of un-clamped fp16 (a scaled gradient), X = plane 1 of the forward's own fp16 operand (the
+        # weight gradient is rescaled when that plane is a1 = fp16((1 - 2^-6) x) of an f16x2 encoding), W^T an fp16 plane
+        if not isinstance(dy, Planes):
+            dy = ops.f16_cast(dy)
+        x_pl, alpha = x_pl.bwd16()
+    else:
+        if not isinstance(dy, Planes):
+            dy = ops.split_f32(dy, Pb)[0]
+        x_pl = x_pl.bwd()              # an f16x2 forward operand hands over its bf16 plane
     M, K = x_pl.rows, x_pl.cols
     N = dy.cols
     dev = x_pl.hi.device
@@ -52,14 +60,18 @@ def _lin_bwd(dy, x_pl: Planes, wt: Planes, Pb, need_dx=True, dx_planes=False, pa
     if allow_side and ec.wgrad_side_stream and not ec.on_text_stream() and not accumulating:
         with ec.side_stream(dy.hi, dy.lo, x_pl.hi, x_pl.lo, cost=float(M) * N * K):
             dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-            db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec)
+            db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec, alpha=alpha)
     else:
         dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-        db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec)
+        db = ops.gemm_tn(dy, x_pl, passes=Pb, out_f32=dW, want_colsum=True, ec=ec, alpha=alpha)
     dx = None
     if need_dx and dx_planes:      # dx feeds a kernel that consumes planes (attention backward): no fp32 copy at all
-        dx = ops.empty_planes(M, K, Pb, dev)
-        ops.gemm_nt(dy, wt, passes=Pb, out_planes=dx, K=N, ec=ec)
+        if Pb == 4:                # dO of the fp16 attention backward: one plane of un-clamped fp16
+            dx = ops.empty_planes_f16x2(M, K, dev, single=True)
+            ops.gemm_nt(dy, wt, passes=4, out_planes=dx, K=N, ec=ec, grad_out=True)
+        else:
+            dx = ops.empty_planes(M, K, Pb, dev)
+            ops.gemm_nt(dy, wt, passes=Pb, out_planes=dx, K=N, ec=ec)
     elif need_dx:
         dx = torch.empty((M, K), dtype=torch.float32, device=dev)
         ops.gemm_nt(dy, wt, passes=Pb, out_f32=dx, K=N, ec=ec)
@@ -91,7 +103,7 @@ def _take_grad_planes(g_out, g2d, Pb):
             PLANE_HANDOFF["hit"] += 1
             return ent[1]
     PLANE_HANDOFF["miss"] += 1
-    return ops.split_f32(g2d, Pb)[0]
+    return ops.f16_cast(g2d) if Pb == 4 else ops.split_f32(g2d, Pb)[0]
 
 
 def f16x2_block_ok(M, D, Hd, train):
@@ -136,42 +148,50 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         wf = "f16x2" if fx2 else "bf16"
         if not fx2:
             single = 0
+        # the fp16 backward (ec.bwd_passes == 4) reads the forward's own fp16 planes: no bf16 copies; the attention output is fp16 planes only
+        # ('f16': one plane for a one-product proj; 'f16x2': the proj runs TWO fp16 products where it ran three bf16 ones)
+        h16 = fx2 and ec.bwd_passes == 4
+        want_bf = train and not h16
         s_fc1, s_fc2, s_qkv, s_proj = bool(single & 1), bool(single & 2), bool(single & 4), bool(single & 8)
-        P_qkv, P_fc1, P_fc2, P_proj = (4 if s_qkv else P), (4 if s_fc1 else P), (4 if s_fc2 else P), (4 if s_proj else Pa)
-        wp = "f16x2" if s_proj else "bf16"       # a single-product proj multiplies fp16(W) (plane 1 of the f16x2 encoding)
+        P_qkv, P_fc1, P_fc2, P_proj = (4 if s_qkv else P), (4 if s_fc1 else P), (4 if s_fc2 else P), (4 if s_proj else (2 if h16 else Pa))
+        wp = "f16x2" if (s_proj or h16) else "bf16"       # a single-product proj multiplies fp16(W) (plane 1 of the f16x2 encoding)
+        afmt = ("f16" if s_proj else "f16x2") if h16 else ("bf16+f16" if s_proj else "bf16")
 
         def W(p, fmt="bf16"):
             return wc.get(p, need_t=False, fmt=fmt)[0]
 
         # ---- temporal attention branch (:166-167)
-        n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P, want_bf=train, single=s_qkv)
-        qkv_t = ops.empty_planes(M, 3 * D, Pa, dev)      # qkv never exists in fp32: the attention kernels read planes
+        n3, _, mean3, rstd3, _ = ops.layernorm_fwd(x2, n3w, n3b, eps, P, want_bf=want_bf, single=s_qkv)
+        # qkv never exists in fp32: the attention kernels read planes (split-bf16; an fp16 split when the backward is fp16: the attention
+        # then multiplies fp16 in both directions)
+        qkv_t = ops.empty_planes_f16x2(M, 3 * D, dev, split=True) if h16 else ops.empty_planes(M, 3 * D, Pa, dev)
         ops.gemm_nt(n3, W(tqkv_w, wf), passes=P_qkv, bias=tqkv_b, out_planes=qkv_t, ec=ec)
-        a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, Pa, out_f16=s_proj)
+        a_t, lse_t = ops.divided_attn_fwd(qkv_t, B, T, n, H, 1, Pa, out_fmt=afmt)
         tr = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(a_t, W(tproj_w, wp), passes=P_proj, bias=tproj_b, residual=x2, out_f32=tr, ec=ec)
         # ---- spatial attention branch (:168-171)
-        n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P, want_bf=train, single=s_qkv)
-        qkv_s = ops.empty_planes(M, 3 * D, Pa, dev)
+        n1, _, mean1, rstd1, _ = ops.layernorm_fwd(tr, n1w, n1b, eps, P, want_bf=want_bf, single=s_qkv)
+        qkv_s = ops.empty_planes_f16x2(M, 3 * D, dev, split=True) if h16 else ops.empty_planes(M, 3 * D, Pa, dev)
         ops.gemm_nt(n1, W(sqkv_w, wf), passes=P_qkv, bias=sqkv_b, out_planes=qkv_s, ec=ec)
-        a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, Pa, out_f16=s_proj)
+        a_s, lse_s = ops.divided_attn_fwd(qkv_s, B, T, n, H, 0, Pa, out_fmt=afmt)
         sr = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(a_s, W(sproj_w, wp), passes=P_proj, bias=sproj_b, residual=x2, out_f32=sr, ec=ec)
         # ---- MLP (:175, Mlp.forward :46-52), exact-erf GELU fused into the fc1 epilogue
-        n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P, want_bf=train, single=s_fc1)
-        h = ops.empty_planes_f16x2(M, Hd, dev, want_bf=train, single=s_fc2) if fx2 else ops.empty_planes(M, Hd, P, dev)
+        n2, _, mean2, rstd2, _ = ops.layernorm_fwd(sr, n2w, n2b, eps, P, want_bf=want_bf, single=s_fc1)
+        h = ops.empty_planes_f16x2(M, Hd, dev, want_bf=want_bf, single=s_fc2) if fx2 else ops.empty_planes(M, Hd, P, dev)
         # saved for backward: the fp32 pre-activation z in the all-bf16x3 parity mode; when backward runs single-pass bf16
         # anyway, gelu'(z) itself as bf16 -- the epilogue has Phi(z) and phi(z) in registers, the buffer is half the bytes,
         # and the fc2-dgrad epilogue becomes one multiply instead of a second erf evaluation over 77 M elements
-        z_dtype = torch.bfloat16 if (ec.bwd_passes == 1 and ops.uses_big_gemm(M, Hd, D, P)) else torch.float32
+        # (the fp16 backward keeps gelu' as fp16: bf16's 2^-9 on the derivative would cap dZ's accuracy)
+        z_dtype = torch.float16 if h16 else (torch.bfloat16 if (ec.bwd_passes in (1, 4) and ops.uses_big_gemm(M, Hd, D, P)) else torch.float32)
         z = torch.empty((M, Hd), dtype=z_dtype, device=dev) if train else None
         ops.gemm_nt(n2, W(fc1_w, wf), passes=P_fc1, bias=fc1_b, act=ACT_GELU, aux_out=z, out_planes=h,
-                    aux_is_grad=z is not None and z_dtype == torch.bfloat16, ec=ec)
+                    aux_is_grad=z is not None and z_dtype != torch.float32, ec=ec)
         out = torch.empty((M, D), dtype=torch.float32, device=dev)
         ops.gemm_nt(h, W(fc2_w, wf), passes=P_fc2, bias=fc2_b, residual=sr, out_f32=out, ec=ec)
 
         if train:
-            ctx.geom, ctx.ec, ctx.P = geom, ec, P
+            ctx.geom, ctx.ec, ctx.P, ctx.h16 = geom, ec, P, h16
             ctx.planes = (n3, a_t, n1, a_s, n2, h, qkv_t, qkv_s)
             ctx.save_for_backward(x2, mean3, rstd3, lse_t, tr, mean1, rstd1, lse_s, sr, mean2, rstd2, z,
                                   n3w, tqkv_w, tproj_w, n1w, sqkv_w, sproj_w, n2w, fc1_w, fc2_w)
@@ -187,32 +207,39 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         wc = ec.wc
         Pb = ec.bwd_passes
         ec.poll_backward()              # gradients of the blocks behind this one are final: the data-parallel exchange may start
-        if Pb > ctx.P:
+        if Pb == 4 and not ctx.h16:
+            if ec.fwd_passes == 2 and ctx.P == 2:
+                raise RuntimeError("the backward precision changed to 'f16' after this block's forward (which wrote bf16 copies, not fp16 planes)")
+            Pb = min(ec.bwd_passes_split, ctx.P)       # a block too small for the fp16 forward format (toy geometries) ran split-bf16
+        if Pb == 3 and ctx.P != 3:
             raise RuntimeError("backward precision bf16x3 needs a bf16x3 forward (the saved activation planes carry no lo part)")
+        h16 = Pb == 4
         M, D = x2.shape
         G = g_out.contiguous().view(M, D)
 
         def Wt(p):
+            if h16:
+                return wc.get(p, need_t=True, fmt="f16x2", t_fmt="f16")[1]
             return wc.get(p, need_t=True)[1]
 
         # ---- MLP backward.  dZ = (G . W2) * gelu'(z) comes out of the fc2-dgrad epilogue already split.
         G_pl = _take_grad_planes(g_out, G, Pb)
         Hd = fc1_w.shape[0]
-        dZ = ops.empty_planes(M, Hd, Pb, G.device)
+        dZ = ops.empty_planes_f16x2(M, Hd, G.device, single=True) if h16 else ops.empty_planes(M, Hd, Pb, G.device)
         ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D,
-                    aux_is_grad=z.dtype == torch.bfloat16, ec=ec)
+                    aux_is_grad=z.dtype != torch.float32, ec=ec)
         _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False, params=(fc2_w,), ec=ec)
         d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, params=(fc1_w,), ec=ec)   # LayerNorm backward reads planes
         # d_sr = G + LN2'(d_n2)
         d_sr, d_n2w, d_n2b, d_sr_pl = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G, planes_passes=Pb)
         # ---- spatial attention backward
         d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb, dx_planes=True, params=(sproj_w,), ec=ec)
-        d_qkv_s = ops.divided_attn_bwd(qkv_s, a_s, d_as, lse_s, B, T, n, H, 0, Pb)
+        d_qkv_s = ops.divided_attn_bwd(qkv_s, a_s, d_as, lse_s, B, T, n, H, 0, 1 if h16 else Pb, grad_f16=h16)
         d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb, params=(sqkv_w,), ec=ec)
         d_tr, d_n1w, d_n1b, d_tr_pl = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1, planes_passes=Pb)
         # ---- temporal attention backward
         d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb, dx_planes=True, params=(tproj_w,), ec=ec)
-        d_qkv_t = ops.divided_attn_bwd(qkv_t, a_t, d_at, lse_t, B, T, n, H, 1, Pb)
+        d_qkv_t = ops.divided_attn_bwd(qkv_t, a_t, d_at, lse_t, B, T, n, H, 1, 1 if h16 else Pb, grad_f16=h16)
         d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb, params=(tqkv_w,), ec=ec)
         # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
         d_x, d_n3w, d_n3b, d_x_pl = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr,
@@ -236,7 +263,8 @@ _W_ORDER = ("tqkv", "tproj", "sqkv", "sproj", "fc1", "fc2")
 def block_calls_ok(ec: ExecContext, M, D, Hd):
     """May this block run through the C block calls?  (split-bf16 / bf16 precision, no per-kernel timer attached, every GEMM of
     the block un-split and at least one 256-wide tile: the per-kernel path covers the toy shapes)"""
-    if not ec.block_calls or ec.kernel_timer is not None or ec.bwd_passes > ec.fwd_passes:
+    if not ec.block_calls or ec.kernel_timer is not None or (ec.bwd_passes == 3 and ec.fwd_passes != 3) or \
+            (ec.bwd_passes == 4 and ec.fwd_passes != 2):
         return False
     if ec.fwd_passes == 2 and not f16x2_block_ok(M, D, Hd, True):
         return False
@@ -253,7 +281,7 @@ def _block_geom(B, T, n, H, D, Hd, P, Pb, train, z_bf16, single, eps, grid):
 _X2_FMTS = ("f16x2", "bf16", "f16x2", "bf16", "f16x2", "f16x2")     # f16x2 mode: qkv / fc1 / fc2 weights in the f16x2 format, proj split-bf16
 
 
-def _block_params(wc, ln, biases, weights, need_t, x2=False, proj_x2=False):
+def _block_params(wc, ln, biases, weights, need_t, x2=False, proj_x2=False, t16=False):
     """egv_block_params from the parameter tensors: LayerNorm affine (n3w, n3b, n1w, n1b, n2w, n2b), the six biases and the
     cached operand planes of the six weights (W^T planes too when `need_t`).  The planes are refreshed IN PLACE after an optimizer
     step, so the struct stays the same from step to step: it is kept on the model's weight cache, keyed by the block's first weight
@@ -262,16 +290,18 @@ def _block_params(wc, ln, biases, weights, need_t, x2=False, proj_x2=False):
     from .._lib import BlockParams
     P6, L6 = C.c_void_p * 6, C.c_int64 * 6
     # proj_x2: the proj Linears run one fp16 product in this block -- their forward weights are f16x2 encodings too
+    # t16 (the fp16 backward): the transposed weights are single fp16 planes (wt_lo unused)
     fmts = [("f16x2" if (proj_x2 and i in (1, 3)) else _X2_FMTS[i]) if x2 else "bf16" for i in range(6)]
-    pls = [wc.get(w, need_t=need_t, fmt=fmts[i]) for i, w in enumerate(weights)]
+    pls = [wc.get(w, need_t=need_t, fmt=fmts[i], t_fmt="f16" if t16 else "bf16") for i, w in enumerate(weights)]
     small = tuple(t.data_ptr() for t in ln) + tuple(b.data_ptr() for b in biases)
-    key = (id(weights[0]), need_t, x2, proj_x2)
+    key = (id(weights[0]), need_t, x2, proj_x2, t16)
     hit = wc.param_structs.get(key)
     if hit is not None and hit[1] == small and all(a[0] is b[0] and a[1] is b[1] for a, b in zip(hit[0], pls)):
         return hit[2]
     whi, wlo, ldw = P6(*[p.hi.data_ptr() for p, _ in pls]), P6(*[p.lo.data_ptr() for p, _ in pls]), L6(*[p.ld for p, _ in pls])
     if need_t:
-        thi, tlo, ldt = P6(*[t.hi.data_ptr() for _, t in pls]), P6(*[t.lo.data_ptr() for _, t in pls]), L6(*[t.ld for _, t in pls])
+        thi, tlo, ldt = P6(*[t.hi.data_ptr() for _, t in pls]), P6(*[(t.lo.data_ptr() if t.lo is not None else None) for _, t in pls]), \
+            L6(*[t.ld for _, t in pls])
     else:
         thi, tlo, ldt = P6(), P6(), L6()
     prm = BlockParams(*[t.data_ptr() for t in ln], P6(*[b.data_ptr() for b in biases]), whi, wlo, ldw, thi, tlo, ldt)
@@ -299,7 +329,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         dev = x.device
         x2 = x.contiguous().view(M, D)
         train = any(ctx.needs_input_grad)
-        z_bf16 = Pb == 1 and ops.uses_big_gemm(M, Hd, D, P)
+        z_bf16 = Pb in (1, 4) and ops.uses_big_gemm(M, Hd, D, P)      # fc1 saves gelu' in 16 bits (bf16; fp16 for the fp16 backward)
         key = (B, T, n, H, D, Hd, P, Pb, train, z_bf16, single)
         g = _block_geom(*key, eps, ec.gemm_grid)
         ent = _BLOCK_CACHE.get(key)
@@ -315,7 +345,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         ln = (n3w, n3b, n1w, n1b, n2w, n2b)
         biases = (tqkv_b, tproj_b, sqkv_b, sproj_b, fc1_b, fc2_b)
         weights = (tqkv_w, tproj_w, sqkv_w, sproj_w, fc1_w, fc2_w)
-        prm = _block_params(ec.wc, ln, biases, weights, need_t=False, x2=P == 2, proj_x2=bool(single & 8))
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=False, x2=P == 2, proj_x2=bool(single & 8) or Pb == 4)
         _lib.check(_lib.lib().egv_block_fwd(C.byref(g), C.byref(prm), x2.data_ptr(), out.data_ptr(), arena.data_ptr(), ops._stream(x2)),
                    "egv_block_fwd")
         if train:
@@ -379,7 +409,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
         _, goff, gtot = ctx.sizes
         grads = torch.empty(gtot, dtype=torch.float32, device=dev)
         d_x = torch.empty((M, D), dtype=torch.float32, device=dev)
-        dx_pl = ops.empty_planes(M, D, Pb, dev)
+        dx_pl = ops.empty_planes_f16x2(M, D, dev, single=True) if Pb == 4 else ops.empty_planes(M, D, Pb, dev)
         used = {s_ for s_ in streams if s_ is not None}          # the side streams read / write these allocations of the main stream
         if used:
             # held until the side streams are joined (end of backward) instead of record_stream-ed: the multi-GB arenas (see
@@ -388,7 +418,7 @@ class _SpaceTimeBlockCFn(torch.autograd.Function):
             # stream with the caching allocator, which polls every outstanding event on every allocation: with 24 blocks and a host
             # that runs two steps ahead that was ~10 ms of host time per ViT-L/14 step (host_enqueue 26 ms against 16 from idle).
             ec.hold_until_join(ctx.arena, barena, grads, *((g_pl.hi, g_pl.lo) if g_hi is not None else ()))
-        prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2, proj_x2=bool(single & 8))
+        prm = _block_params(ec.wc, ln, biases, weights, need_t=True, x2=P == 2, proj_x2=bool(single & 8) or Pb == 4, t16=Pb == 4)
         P6 = C.c_void_p * 6
         io = BlockBwdIO(G.data_ptr(), g_hi, g_lo, x2.data_ptr(), ctx.arena.data_ptr(), barena.data_ptr(),
                         d_x.data_ptr(), dx_pl.hi.data_ptr(), dx_pl.lo.data_ptr() if dx_pl.lo is not None else None, grads.data_ptr(),
@@ -437,7 +467,7 @@ class _PatchTokensFn(torch.autograd.Function):
     def backward(ctx, dx):
         B, T, n, P_, D, T_model = ctx.geom[:6]
         ec = ctx.ec
-        Pb = ec.bwd_passes
+        Pb = ec.bwd_passes_split        # (next to an fp16 backward of the blocks: three bf16 products)
         ec.poll_backward()              # every block's gradients are final here
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
         K = ctx.wshape[1] * ctx.wshape[2] * ctx.wshape[3]

@@ -43,10 +43,18 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # its share of the 1e-3 parity budget allows it: an error injected late in the tower reaches the embedding almost unamplified, one
 # injected in the first blocks is amplified by everything behind it, so the policy is "op X runs single-product from block k_X on"
 # (setting `f16_single`, see single_product_policy and profiles/r05_precision_table.txt).
+_DEFAULT_X2_BWD = os.environ.get("EGV_X2_BWD", "bf16")          # the backward 'f16x2' / 'f16mix' pair with when none is named
 _ENV_F16_SINGLE = os.environ.get("EGV_F16_SINGLE", "auto")     # read once: later Precision.set calls of the process agree
-_PASSES = {"bf16x3": 3, "bf16": 1, "f16x2": 2}
+# "f16" (backward only; passes code 4 = ONE fp16 product): the backward of the video blocks on fp16 operands -- gradients carry a dynamic
+# loss scale (egovlp_amd.optim.LossScaler; S lives in device memory, overflow -> skipped step + halved scale, no host sync), dY planes are
+# un-clamped fp16 written by their producers, X is the forward's own fp16 operand plane (so the f16x2 / f16mix forward writes NO bf16
+# copies), W^T is an fp16 plane.  2^-11 per operand instead of bf16's 2^-8: the weight gradients of the benchmarked mode were 2e-2 from
+# fp32 with the bf16 backward (profiles/r05_backward_fp16_table.txt priced this).  Everything outside the video blocks (text tower, patch
+# embedding, heads: 2 % of the FLOPs) then runs its backward on three bf16 products (`bwd_passes_split`).
+_PASSES = {"bf16x3": 3, "bf16": 1, "f16x2": 2, "f16": 4}
 F16_SINGLE_BITS = {"fc1": 1, "fc2": 2, "qkv": 4, "proj": 8}
-_PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16x2"}
+_PASSES_INV = {3: "bf16x3", 1: "bf16", 2: "f16x2", 4: "f16"}
+A1_INV = 1.0 / (1.0 - 2.0 ** -6)      # csrc/f16x2.h: plane 1 of a first-operand f16x2 encoding is fp16((1 - 2^-6) x)
 _HARD_DEFAULTS = {
     "fwd_passes": 3, "bwd_passes": 3,
     # weight-gradient GEMMs on their own HIP stream.  OFF unless the owner of the gradient hooks turns it on (bench.py and
@@ -119,6 +127,7 @@ class ExecContext:
         self._inflight = []                             # events of the steps the host has enqueued (see _throttle)
         self.flow_wait_s = 0.0                          # seconds the host has waited in _throttle so far
         self._wc = None
+        self._scaler = None
         self._pol_cache = {}
 
     # ---- settings (inherited) ------------------------------------------------------------------------------------------
@@ -162,9 +171,10 @@ class ExecContext:
             single = f16_single if f16_single is not None else (cur if cur not in (None, "none", "", "auto") else _ENV_F16_SINGLE)
         elif f16_single not in (None, "none", ""):
             raise ValueError("f16_single is the per-block policy of the 'f16mix' forward")
-        bwd = bwd if bwd is not None else ("bf16" if fwd == "f16x2" else fwd)
-        if bwd in ("f16x2", "f16mix") or (fwd == "f16x2" and bwd != "bf16"):
-            raise ValueError("'f16x2' / 'f16mix' are forward formats; they pair with the single-pass 'bf16' backward")
+        bwd = bwd if bwd is not None else (_DEFAULT_X2_BWD if fwd == "f16x2" else fwd)
+        if bwd in ("f16x2", "f16mix") or fwd == "f16" or (fwd == "f16x2" and bwd not in ("bf16", "f16")) or (bwd == "f16" and fwd != "f16x2"):
+            raise ValueError("'f16x2' / 'f16mix' are forward formats; they pair with the single-product backwards 'bf16' and 'f16' "
+                             "('f16': fp16 operands under a dynamic loss scale, only behind these fp16 forwards)")
         return self.set(fwd_passes=_PASSES[fwd], bwd_passes=_PASSES[bwd], f16_single=single)
 
     def precision_name(self):
@@ -178,6 +188,9 @@ class ExecContext:
     # attention, proj): the f16x2 mode keeps them split-bf16 three-product
     fwd_passes_split = property(lambda self: 3 if self.get("fwd_passes") == 2 else self.get("fwd_passes"))
     bwd_passes = property(lambda self: self.get("bwd_passes"))
+    # the backward of everything OUTSIDE the video blocks (text tower, patch embedding, projection heads; 2 % of the step's FLOPs): next
+    # to an fp16 backward it runs three bf16 products, so that every weight gradient of the step is fp32-grade
+    bwd_passes_split = property(lambda self: 3 if self.get("bwd_passes") == 4 else self.get("bwd_passes"))
     wgrad_side_stream = property(lambda self: self.get("wgrad_side_stream"))
     text_side_stream = property(lambda self: self.get("text_side_stream"))
     gemm_grid = property(lambda self: self.get("gemm_grid"))
@@ -219,6 +232,14 @@ class ExecContext:
             from .weights import WeightCache
             self._wc = WeightCache()
         return self._wc
+
+    def loss_scaler(self, **kwargs):
+        """The dynamic loss scale of this model's fp16 backward (egovlp_amd.optim.LossScaler), created on first use: what
+        `egoclip_step` multiplies the loss with and hands to `AdamW.step(scaler=...)` when the backward precision is 'f16'."""
+        if self._scaler is None:
+            from .optim import LossScaler
+            self._scaler = LossScaler(**kwargs)
+        return self._scaler
 
     def text_stream(self):
         if self._text["stream"] is None:
@@ -505,6 +526,7 @@ class Planes:
     rows: int
     cols: int                        # logical columns (<= ld)
     fmt: str = "bf16"                # 'bf16' (split planes), 'f16x2' (include/egovlp_hip.h: egv_f16x2_encode; role: first / second operand)
+                                     # or 'f16s' (an fp16 SPLIT: hi = fp16(x), lo = fp16(x - hi): the qkv planes of the fp16 attention)
                                      # or 'f16' (ONE plane of plain fp16 in `hi`, lo = None: the first operand of a single-fp16-product GEMM)
                                      # or 'bf16+f16' (attention output ahead of a single-product proj: hi = bf16(value) for the backward,
                                      # lo = fp16(value), the GEMM's operand)
@@ -526,6 +548,15 @@ class Planes:
         """The plain-fp16 plane a single-product GEMM (passes == 4) reads."""
         return self.hi if self.fmt == "f16" else self.lo
 
+    def bwd16(self):
+        """-> (Planes fmt 'f16' = plane 1 of this fp16 forward operand, alpha): the X operand of a weight gradient of the fp16 backward.
+        alpha = 1 for plain fp16(x) ('f16'), 1 / (1 - 2^-6) for a1 = fp16((1 - 2^-6) x) of an f16x2 first-operand encoding."""
+        if self.fmt == "f16":
+            return self, 1.0
+        if self.fmt == "f16x2":
+            return Planes(self.hi, None, self.rows, self.cols, "f16"), A1_INV
+        raise ValueError(f"the fp16 backward needs an fp16 forward operand, not '{self.fmt}' planes")
+
     def bwd(self):
         """The operand view the backward GEMMs take: the planes themselves, or the bf16 copy of an f16x2 operand."""
         if self.fmt == "bf16":
@@ -545,14 +576,24 @@ def empty_planes(rows, cols, passes, device, ld=None, zero=False):
     return Planes(hi, lo, rows, cols)
 
 
-def empty_planes_f16x2(rows, cols, device, want_bf=False, single=False):
-    """Uninitialised f16x2 operand planes [rows, cols] (cols % 8 == 0); `single`: ONE plain fp16 plane (fmt 'f16')."""
+def empty_planes_f16x2(rows, cols, device, want_bf=False, single=False, split=False):
+    """Uninitialised f16x2 operand planes [rows, cols] (cols % 8 == 0); `single`: ONE plain fp16 plane (fmt 'f16'); `split`: an fp16
+    split (fmt 'f16s')."""
     if cols % 8:
         raise ValueError("f16x2 operands come in 16-byte pieces (cols % 8 == 0)")
     hi = torch.empty((rows, cols), dtype=torch.float16, device=device)
     lo = None if single else torch.empty((rows, cols), dtype=torch.float16, device=device)
     bf = torch.empty((rows, cols), dtype=torch.bfloat16, device=device) if want_bf else None
-    return Planes(hi, lo, rows, cols, "f16" if single else "f16x2", bf)
+    return Planes(hi, lo, rows, cols, "f16" if single else ("f16s" if split else "f16x2"), bf)
+
+
+def f16_cast(x2d: torch.Tensor) -> Planes:
+    """fp32 [rows, cols] -> ONE plane of un-clamped fp16 (fmt 'f16'; egv_f16x2_encode role 2): a scaled gradient entering the fp16 backward."""
+    _need_cuda(x2d)
+    rows, cols = x2d.shape
+    pl = empty_planes_f16x2(rows, cols, x2d.device, single=True)
+    check(_lib.lib().egv_f16x2_encode(_p(x2d), x2d.stride(0), rows, cols, _p(pl.hi), None, None, pl.ld, 2, _stream(x2d)), "egv_f16x2_encode")
+    return pl
 
 
 def f16x2_encode(x2d: torch.Tensor, role: int, want_bf=False) -> Planes:
@@ -633,7 +674,7 @@ def pad32(n):
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_NONE, aux_in=None, aux_out=None,
             out_f32=None, out_planes: Optional[Planes] = None, alpha=1.0, ksplit=None, K=None, aux_is_grad=False,
-            ec: Optional[ExecContext] = None):
+            ec: Optional[ExecContext] = None, grad_out=False):
     """C[M,N] = A[M,K] . B[N,K]^T with the fused epilogue of egv_gemm_nt.  A.rows = M, B.rows = N.
     `aux_is_grad` (bf16 aux only): the GELU epilogue saves gelu'(z) instead of z and the GELU' epilogue multiplies by it.
     `ec`: the caller's execution context (grid cap of the big kernel, kernel timer); DEFAULT when omitted."""
@@ -641,20 +682,26 @@ def gemm_nt(a: Planes, b: Planes, *, passes, bias=None, residual=None, act=ACT_N
     M, N = a.rows, b.rows
     K = a.cols if K is None else K
     # passes 4: ONE fp16 product -- A a plain fp16 plane ('f16'), B the weight's f16x2 encoding (its plane 1 IS fp16(W))
-    if (a.fmt == "f16x2") != (passes == 2) or (a.fmt in ("f16", "bf16+f16")) != (passes == 4) or b.fmt != ("f16x2" if passes in (2, 4) else "bf16"):
+    # (b 'f16' with passes 4: the fp16 W^T plane of a dgrad of the fp16 backward)
+    if (a.fmt == "f16x2") != (passes == 2) or (a.fmt in ("f16", "bf16+f16")) != (passes == 4) or \
+            b.fmt not in (("f16x2", "f16") if passes == 4 else (("f16x2",) if passes == 2 else ("bf16",))):
         raise ValueError(f"gemm_nt: operand formats {a.fmt} / {b.fmt} do not go with passes = {passes}")
     a_hi = a.f16_plane() if passes == 4 else a.hi
     out_fmt = 0
     if out_planes is not None and out_planes.fmt != "bf16":
-        out_fmt = 2 if out_planes.fmt == "f16" else 1
+        # 'f16x2' -> 1; 'f16' -> 2 (an activation: saturating) or 4 (a scaled gradient: un-clamped -- the GELU' epilogue, or grad_out);
+        # 'f16s' -> 3 (an fp16 split: the qkv planes of the fp16 attention)
+        out_fmt = {"f16x2": 1, "f16": 4 if (act == ACT_GELU_BWD or grad_out) else 2, "f16s": 3}[out_planes.fmt]
     if ksplit is None:
         ksplit = 1 if passes in (2, 4) else auto_ksplit_nt(M, N, K)
     aux = aux_in if aux_in is not None else aux_out
-    aux_bf16 = int(aux is not None and aux.dtype == torch.bfloat16)
+    aux_bf16 = int(aux is not None and aux.dtype in (torch.bfloat16, torch.float16))
     if aux_is_grad:
         if not aux_bf16:
-            raise ValueError("aux_is_grad needs a bf16 aux buffer")
-        aux_bf16 = 2
+            raise ValueError("aux_is_grad needs a 16-bit aux buffer")
+        aux_bf16 = 3 if aux.dtype == torch.float16 else 2       # 3: gelu' saved as fp16 (the fp16 backward)
+    elif aux is not None and aux.dtype == torch.float16:
+        raise ValueError("an fp16 aux buffer holds gelu' (aux_is_grad)")
     if aux_bf16 and not uses_big_gemm(M, N, K, passes):
         raise ValueError("bf16 aux buffers are only supported by the big-tile GEMM kernel (see uses_big_gemm)")
     partial = torch.empty((ksplit, M, N), dtype=torch.float32, device=a.hi.device) if ksplit > 1 else None
@@ -705,12 +752,17 @@ def f16x2_gemm_ok(M, N, K):
     return M >= 256 and N >= 256 and K % 64 == 0
 
 
-def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=None, ec: Optional[ExecContext] = None):
+def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=None, ec: Optional[ExecContext] = None, alpha=1.0):
     """C[M,N] = A^T . B with both operands stored k-major: A is [K, M] (a.rows = K, a.cols = M), B is [K, N].
     This is the weight gradient dW = dY^T X with K = #tokens; neither operand is ever transposed in HBM
-    (egv_gemm_nt, trans = 1).  -> colsum[M] = sum_k A[k, :] (the bias gradient) when want_colsum."""
+    (egv_gemm_nt, trans = 1).  -> colsum[M] = sum_k A[k, :] (the bias gradient) when want_colsum.  passes 4: both operands ONE plane of plain
+    fp16 (fmt 'f16', the fp16 backward); alpha rescales the product (not the column sums)."""
     ec = DEFAULT if ec is None else ec
     Kd, M, N = a.rows, a.cols, b.cols
+    if (passes == 4) != (a.fmt == "f16") or (passes == 4) != (b.fmt == "f16"):
+        raise ValueError(f"gemm_tn: operand formats {a.fmt} / {b.fmt} do not go with passes = {passes}")
+    if passes == 4 and (M < 256 or N < 256 or M % 8 or N % 8):
+        raise ValueError("gemm_tn: fp16 weight gradients need the big-tile kernel (M, N >= 256)")
     if b.rows != Kd:
         raise ValueError("gemm_tn: operands disagree on the contraction length")
     dev = a.hi.device
@@ -726,14 +778,14 @@ def gemm_tn(a: Planes, b: Planes, *, passes, out_f32, want_colsum=False, ksplit=
         ksplit = wgrad_ksplit(M, N, Kd, ec, ec.on_side_stream())
     cs = torch.empty(M, dtype=torch.float32, device=dev) if want_colsum else None
     partial = torch.empty(ksplit * (M * N + M), dtype=torch.float32, device=dev) if ksplit > 1 else None
-    d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, Kd, passes, 1.0, ACT_NONE, None,
+    d = GemmDesc(_p(a.hi), _p(a.lo), a.ld, _p(b.hi), _p(b.lo), b.ld, M, N, Kd, passes, float(alpha), ACT_NONE, None,
                  None, 0, None, None, 0, _p(out_f32), out_f32.stride(0), None, None, 0,
                  ksplit, 0, _p(partial), 1, 0, _p(cs), ec.gemm_grid, 0, None)
     timer = ec.kernel_timer
     if timer is not None:
         timer.time("egv_gemm_nt", 2.0 * M * N * Kd,
-                   lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt(trans)"), passes,
-                   key=f"gemm_big TN M={M} N={N} K={Kd} x{passes}")
+                   lambda: check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt(trans)"), 1 if passes == 4 else passes,
+                   key=f"gemm_big TN M={M} N={N} K={Kd} " + ("x1 fp16" if passes == 4 else f"x{passes}"))
     else:
         check(_lib.lib().egv_gemm_nt(C.byref(d), _stream(a.hi)), "egv_gemm_nt(trans)")
     return cs
@@ -778,8 +830,9 @@ def split_f32(x2d: torch.Tensor, passes, *, want_rowmajor=True, want_transposed=
 
 
 def split_f32_multi(jobs, prepare=False):
-    """One launch for many fp32 -> split-plane conversions.  jobs: (x2d [rows, cols] fp32, hi, lo, ldo, t_hi, t_lo, ldt, t_cols)
-    with hi / lo / t_hi / t_lo raw device addresses (or None); see egv_split_f32_multi.
+    """One launch for many fp32 -> split-plane conversions.  jobs: (x2d [rows, cols] fp32, hi, lo, ldo, t_hi, t_lo, ldt, t_cols[, t16])
+    with hi / lo / t_hi / t_lo / t16 raw device addresses (or None); see egv_split_f32_multi[_t16] (t16: the transposed matrix as one
+    plane of plain fp16).
     prepare=True: build the argument tables and return `run(stream_handle)` instead of launching (None for no jobs) -- the weight
     cache replays the same table after every optimizer step."""
     n = len(jobs)
@@ -795,12 +848,13 @@ def split_f32_multi(jobs, prepare=False):
     THI, TLO = vp(*[j[4] for j in jobs]), vp(*[j[5] for j in jobs])
     LDT = i64(*[j[6] for j in jobs])
     TC = i32(*[j[7] for j in jobs])
+    T16 = vp(*[(j[8] if len(j) > 8 else None) for j in jobs])
     for j in jobs:
         _need_cuda(j[0])
-    fn = _lib.lib().egv_split_f32_multi
+    fn = _lib.lib().egv_split_f32_multi_t16
 
     def run(stream):
-        check(fn(n, X, LDX, R, Cc, HI, LO, LDO, THI, TLO, LDT, TC, stream), "egv_split_f32_multi")
+        check(fn(n, X, LDX, R, Cc, HI, LO, LDO, THI, TLO, LDT, TC, T16, stream), "egv_split_f32_multi_t16")
     if prepare:
         return run
     run(_stream(jobs[0][0]))
@@ -872,15 +926,19 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
     db = torch.empty(cols, dtype=torch.float32, device=dev)
     parts = _cached_size("ln_parts", rows)
     work = torch.empty(2 * cols * parts, dtype=torch.float32, device=dev)
-    pl = empty_planes(rows, cols, planes_passes, dev) if planes_passes else None
+    # planes_passes 4: dx also as ONE plane of un-clamped fp16 (fmt 'f16'): the dY operand of the fp16 backward's next GEMMs
+    if planes_passes == 4:
+        pl = empty_planes_f16x2(rows, cols, dev, single=True)
+    else:
+        pl = empty_planes(rows, cols, planes_passes, dev) if planes_passes else None
     if dy_pl is not None:
         dy_args = (None, _p(dy_pl.hi), _p(dy_pl.lo), dy_pl.ld)
     else:
         dy_args = (_p(dy2d), None, None, dy2d.stride(0))
-    check(_lib.lib().egv_layernorm_bwd(*dy_args, _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
-                                       cols, _p(add1), _p(add2), _p(dx), lddx, _p(pl.hi) if pl else None,
-                                       _p(pl.lo) if pl else None, _p(dg), _p(db), _p(work), _stream(x2d)),
-          "egv_layernorm_bwd")
+    check(_lib.lib().egv_layernorm_bwd_fmt(*dy_args, _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
+                                           cols, _p(add1), _p(add2), _p(dx), lddx, _p(pl.hi) if pl else None,
+                                           _p(pl.lo) if pl else None, 1 if planes_passes == 4 else 0, _p(dg), _p(db), _p(work),
+                                           _stream(x2d)), "egv_layernorm_bwd_fmt")
     if planes_passes:
         return dx, dg, db, pl
     return dx, dg, db
@@ -944,18 +1002,31 @@ def assemble_tokens_bwd(dx, B, T, n, D, T_model):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes, out_f16=False):
+ATT_OUT_FMTS = {"bf16": 0, "bf16+f16": 1, "f16x2": 2, "f16": 3}      # csrc/attn_common.h ATT_OUT_*
+
+
+def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes, out_f16=False, out_fmt=None):
     """qkv planes [B*S, 3*H*64] (the qkv GEMM's out_planes) -> (Planes [B*S, H*64], lse [B,H,S]).
-    out_f16 (passes == 3): the second output plane holds fp16(value) instead of the bf16 residual (Planes fmt 'bf16+f16'): the
-    operand of a single-fp16-product proj Linear."""
+    out_fmt (passes == 3; out_f16=True = 'bf16+f16'): the format of the output planes = the fmt of the returned Planes --
+    'bf16' split planes; 'bf16+f16' hi = bf16(value) for a bf16 backward, lo = fp16(value), the operand of a one-product proj;
+    'f16x2' the f16x2 first-operand planes of a TWO-product proj (fp16 backward); 'f16' ONE plane of fp16(value) (one-product proj, fp16
+    backward)."""
     S = 1 + T * n
     dev = qkv.hi.device
-    out = empty_planes(B * S, H * 64, passes, dev)
-    if out_f16:
+    if qkv.fmt == "f16s":
+        mode = mode | 8                      # the qkv planes are an fp16 split: fp16 MFMA products
+    out_fmt = ("bf16+f16" if out_f16 else "bf16") if out_fmt is None else out_fmt
+    if out_fmt != "bf16":
         if passes != 3:
-            raise ValueError("divided_attn_fwd: the fp16 output plane takes the place of the lo plane of a three-pass forward")
-        out = Planes(out.hi, out.lo.view(torch.float16), out.rows, out.cols, "bf16+f16")
-        mode = mode | 2
+            raise ValueError("divided_attn_fwd: fp16 output planes are written by the three-pass forward")
+        if out_fmt in ("f16x2", "f16"):
+            out = empty_planes_f16x2(B * S, H * 64, dev, single=(out_fmt == "f16"))
+        else:
+            out = empty_planes(B * S, H * 64, passes, dev)
+            out = Planes(out.hi, out.lo.view(torch.float16), out.rows, out.cols, "bf16+f16")
+        mode = mode | (ATT_OUT_FMTS[out_fmt] << 1)
+    else:
+        out = empty_planes(B * S, H * 64, passes, dev)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     work = torch.empty(_cached_size("attn_fwd", B, T, n, H, mode & 1), dtype=torch.float32, device=dev)
     check(_lib.lib().egv_divided_attn_fwd(_p(qkv.hi), _p(qkv.lo), B, T, n, H, mode, passes, _p(out.hi), _p(out.lo),
@@ -963,13 +1034,23 @@ def divided_attn_fwd(qkv: Planes, B, T, n, H, mode, passes, out_f16=False):
     return out, lse
 
 
-def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, mode, passes) -> Planes:
-    """-> dqkv planes [B*S, 3*H*64], ready to be the dY operand of the qkv dgrad / wgrad GEMMs."""
+def divided_attn_bwd(qkv: Planes, out: Planes, d_out: Planes, lse, B, T, n, H, mode, passes, grad_f16=False) -> Planes:
+    """-> dqkv planes [B*S, 3*H*64], ready to be the dY operand of the qkv dgrad / wgrad GEMMs.  grad_f16 (passes == 1): dqkv as ONE plane of
+    un-clamped fp16 (the fp16 backward; q / k / v / dO are read as bf16 planes all the same)."""
     S = 1 + T * n
     dev = qkv.hi.device
-    dqkv = empty_planes(B * S, 3 * H * 64, passes, dev)
+    if grad_f16:
+        dqkv = empty_planes_f16x2(B * S, 3 * H * 64, dev, single=True)
+        mode = mode | 8
+    else:
+        dqkv = empty_planes(B * S, 3 * H * 64, passes, dev)
+    mode = mode | (ATT_OUT_FMTS[out.fmt] << 1)          # how the forward wrote `out` (delta = rowsum(dO o O) decodes it)
+    if qkv.fmt == "f16s":
+        if not grad_f16 or d_out.fmt != "f16":
+            raise ValueError("divided_attn_bwd: fp16 qkv planes go with an fp16 dO plane and an fp16 dqkv plane (the fp16 backward)")
+        mode = mode | 16                                # q / k / v / dO are fp16: fp16 products throughout
     work = torch.empty(_cached_size("attn_bwd", B, T, n, H), dtype=torch.float32, device=dev)
-    out_lo = out.lo if out.fmt == "bf16" else None      # an fp16(value) plane is not a residual: delta comes from the bf16 plane alone
+    out_lo = out.lo if out.fmt == "bf16" else None      # an fp16(value) plane is not a residual: delta comes from the first plane alone
     check(_lib.lib().egv_divided_attn_bwd(_p(qkv.hi), _p(qkv.lo), _p(out.hi), _p(out_lo), _p(d_out.hi), _p(d_out.lo),
                                           _p(lse), B, T, n, H, mode, passes, _p(dqkv.hi), _p(dqkv.lo), _p(work),
                                           _stream(qkv.hi)), "egv_divided_attn_bwd")
@@ -1048,6 +1129,22 @@ def egonce_fwd_bwd(text, video, noun, verb, temperature, eps=1e-8, use_noun=True
                                         float(eps), int(use_noun), int(use_verb), _p(loss), _p(sim), _p(dt), _p(dvv),
                                         _p(work), _stream(text)), "egv_egonce_fwd_bwd")
     return loss, sim, dt, dvv
+
+
+def grad_nonfinite_multi(grads, state):
+    """state[2] |= 1 if any gradient holds an inf / NaN (egv_grad_nonfinite_multi); `state`: the int32[8] device block of a LossScaler."""
+    n = len(grads)
+    if n == 0:
+        return
+    G = (C.c_void_p * n)(*[g.data_ptr() for g in grads])
+    N = (C.c_int64 * n)(*[g.numel() for g in grads])
+    check(_lib.lib().egv_grad_nonfinite_multi(n, G, N, _p(state), _stream(grads[0])), "egv_grad_nonfinite_multi")
+
+
+def loss_scale_update(state, hyper_out, lr, beta1, beta2, step, correct_bias, growth, backoff, interval, max_scale, advance):
+    check(_lib.lib().egv_loss_scale_update(_p(state), _p(hyper_out), float(lr), float(beta1), float(beta2), int(step), int(correct_bias),
+                                           float(growth), float(backoff), int(interval), float(max_scale), int(advance), _stream(state)),
+          "egv_loss_scale_update")
 
 
 def adamw_tables(params, ms, vs):

@@ -14,6 +14,64 @@ import torch
 from . import ops, weights
 
 
+class LossScaler:
+    """Dynamic loss scale of the fp16 backward (`exec_ctx.set_precision('f16mix', 'f16')`): torch.cuda.amp.GradScaler's rule, decided
+    entirely on the device.  The reference back-propagates in fp32 (trainer/trainer_egoclip.py:139-141) and needs none of this; fp16
+    gradient planes need the loss multiplied by S (here: `scaler.scale(loss).backward()`), and
+
+      * S, the found-inf flag, the good-step counter and the number of skipped steps live in ONE 32-byte device block (`state`);
+      * `AdamW.step(scaler=...)` enqueues: a scan of every gradient for inf / NaN (egv_grad_nonfinite_multi), the one-thread decision
+        kernel (egv_loss_scale_update: overflow -> skip + S *= backoff_factor; growth_interval good steps in a row -> S *= growth_factor)
+        and the AdamW kernels, which read {lr, step size, 1 / S, skip} from the block and do NOTHING in a skipped step;
+      * the host never reads any of it back during training (no synchronisation per step); `get_scale()` / `skipped_steps()` do, for
+        logs and tests.  The bias correction counts APPLIED steps (host step count minus the device's skipped count).
+    Overflow is detectable because gradient planes are written UN-clamped (csrc/f16x2.h f16_grad_piece8): a value beyond fp16's range
+    becomes inf and poisons every gradient behind it."""
+
+    def __init__(self, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, max_scale=2.0 ** 24, device="cuda"):
+        if not (init_scale >= 1.0 and growth_factor >= 1.0 and 0.0 < backoff_factor <= 1.0 and growth_interval >= 1 and max_scale >= init_scale):
+            raise ValueError("LossScaler: init_scale >= 1, growth_factor >= 1, 0 < backoff_factor <= 1, growth_interval >= 1, max_scale >= init_scale")
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.max_scale = int(growth_interval), float(max_scale)
+        host = torch.zeros(8, dtype=torch.int32)
+        host.view(torch.float32)[0] = float(init_scale)
+        host.view(torch.float32)[6] = 1.0 / float(init_scale)
+        self.state = host.to(device)
+        self._f = self.state.view(torch.float32)
+        self.scale_tensor = self._f[0]          # 0-dim view: `loss * scale_tensor` reads S when the multiplication RUNS on the stream
+        self._extra_hyper = {}                  # parameter-group index > 0 -> its own {lr, step_size, 1 / S, skip} block
+
+    def scale(self, loss):
+        """loss -> S * loss (a device-side multiply: backward() then carries S through every gradient of the step)."""
+        return loss * self.scale_tensor
+
+    def hyper_block(self, group_index):
+        if group_index == 0:
+            return self._f[4:8]
+        blk = self._extra_hyper.get(group_index)
+        if blk is None:
+            blk = self._extra_hyper[group_index] = torch.zeros(4, dtype=torch.float32, device=self.state.device)
+        return blk
+
+    # ---- host readbacks (synchronise: logs, tests, checkpoints) ----
+    def get_scale(self):
+        return float(self._f[0].item())
+
+    def skipped_steps(self):
+        return int(self.state[3].item())
+
+    def state_dict(self):
+        st = self.state.cpu()
+        return {"scale": float(st.view(torch.float32)[0]), "growth_tracker": int(st[1]), "skipped": int(st[3])}
+
+    def load_state_dict(self, d):
+        host = torch.zeros(8, dtype=torch.int32)
+        host.view(torch.float32)[0] = float(d["scale"])
+        host.view(torch.float32)[6] = 1.0 / float(d["scale"])
+        host[1], host[3] = int(d.get("growth_tracker", 0)), int(d.get("skipped", 0))
+        self.state.copy_(host)
+
+
 class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         if lr < 0.0:
@@ -24,14 +82,28 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       correct_bias=correct_bias))
-        self._graph_hyper = None
+        self._scaler = None     # the LossScaler of the step() in progress (None: un-scaled gradients, host-side hyper-parameters)
+        self._scaler_first = False
         self._plans = {}        # id(param group) -> (params, states, exp_avg, exp_avg_sq, argument tables) of the steady-state launch
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step(self, closure=None, grad_scale=1.0, scaler=None):
+        """`scaler` (LossScaler): the gradients carry its scale S -- scan them for inf / NaN, let the device decide whether the step is
+        applied (and with which S next), un-scale inside the update.  No host synchronisation either way."""
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
-            self._update_group(group, [p for p in group["params"] if p.grad is not None], grad_scale)
+        groups = [(g, [p for p in g["params"] if p.grad is not None]) for g in self.param_groups]
+        if scaler is not None:
+            grads = [p.grad for _, ps in groups for p in ps]
+            if any(g.is_sparse or not g.is_contiguous() for g in grads):
+                raise RuntimeError("AdamW (HIP) needs contiguous dense gradients")
+            ops.grad_nonfinite_multi(grads, scaler.state)
+            self._scaler, self._scaler_first = scaler, True
+        try:
+            for gi, (group, params) in enumerate(groups):
+                self._group_index = gi
+                self._update_group(group, params, grad_scale)
+        finally:
+            self._scaler = None
         weights.bump_epoch()   # parameters were written through raw pointers: invalidate the bf16 planes
         return loss
 
@@ -89,9 +161,15 @@ class AdamW(torch.optim.Optimizer):
         if not ps:
             return
         b1, b2 = group["betas"]
-        # graph_hyper: per param group, device floats {lr, step_size} the host refreshes before every HIP-graph replay
-        # (egovlp_amd/graph.py GraphedTrainStep); None in eager mode
-        hyper = self._graph_hyper.get(id(group)) if self._graph_hyper else None
+        hyper = None
+        sc = self._scaler
+        if sc is not None:
+            # the decision kernel of this step (first launch only: scale logic + found-inf reset), then this group's hyper block
+            # {lr, step size at the number of APPLIED steps, 1 / S, skip} -- all on the device, read by the AdamW kernel below
+            hyper = sc.hyper_block(getattr(self, "_group_index", 0))
+            ops.loss_scale_update(sc.state, hyper, group["lr"], b1, b2, step, group["correct_bias"], sc.growth_factor, sc.backoff_factor,
+                                  sc.growth_interval, sc.max_scale, advance=self._scaler_first)
+            self._scaler_first = False
         ops.adamw_multi(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], group["weight_decay"], step,
                         group["correct_bias"], grad_scale, hyper_dev=hyper, tables=tables)
 

@@ -78,11 +78,16 @@ class AllGatherFused(torch.autograd.Function):
         return gv[lo:hi], gt[lo:hi], None, None, None, None
 
 
-def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_head=True, grad_sync=None):
+def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_head=True, grad_sync=None, scaler=None):
     """One optimisation step = trainer/trainer_egoclip.py:123-141 (zero_grad, forward, gathers,
     similarity + loss, backward, optimizer.step).  Returns the (device) loss tensor; no host sync.
     `grad_sync` (egovlp_amd.dist.Bf16GradSync, world size > 1) averages the gradients over the ranks -- its all-reduces
-    are launched by grad-ready hooks during backward; `finish()` waits for them before the optimizer reads p.grad."""
+    are launched by grad-ready hooks during backward; `finish()` waits for them before the optimizer reads p.grad.
+    `scaler` (egovlp_amd.optim.LossScaler; default when the model's backward precision is 'f16': exec_ctx.loss_scaler()): the loss is multiplied by the device-side
+    loss scale before backward() and the optimizer un-scales, or skips the step after an overflow -- no host synchronisation."""
+    ec0 = getattr(getattr(model, 'module', model), 'exec_ctx', None)
+    if scaler is None and ec0 is not None and ec0.bwd_passes == 4:
+        scaler = ec0.loss_scaler()      # fp16 gradient planes flush un-scaled gradients of 1e-6 to zero: the model's own scaler
     optimizer.zero_grad(set_to_none=True)
     text_embeds, video_embeds = model(data)
     n_embeds, v_embeds = data['noun_vec'], data['verb_vec']
@@ -103,13 +108,16 @@ def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_he
             loss = loss_fn(output, sim_v, sim_n)                            # :135
         else:
             loss = loss_fn(output)
-    loss.backward()                                                         # :139
+    (loss if scaler is None else scaler.scale(loss)).backward()             # :139
     ec = getattr(getattr(model, 'module', model), 'exec_ctx', None)
     if ec is not None:
         ec.join_side_stream()       # idempotent; covers a backward whose end-of-pass callback did not run
     if grad_sync is not None:
         grad_sync.finish()
-    optimizer.step()                                                        # :141
+    if scaler is None:
+        optimizer.step()                                                    # :141
+    else:
+        optimizer.step(scaler=scaler)
     return loss.detach()
 
 

@@ -22,12 +22,13 @@ def bump_epoch():
 
 
 class _Entry:
-    __slots__ = ("params", "ver", "pl", "p2", "tp", "ok_token", "ok_epoch", "ok_vers")
+    __slots__ = ("params", "ver", "pl", "p2", "tp", "t16", "ok_token", "ok_epoch", "ok_vers")
 
     def __init__(self, params):
         # pl: split-bf16 planes W[N,K]; p2: the same weight in the f16x2 operand format, second-operand role (forward of the f16x2 mode); tp: split-bf16
-        # W^T[K,N] (dgrad).  An entry owns whichever of the three its callers have asked for so far.
-        self.params, self.ver, self.pl, self.p2, self.tp = params, None, None, None, None
+        # W^T[K,N] (dgrad); t16: W^T[K,N] as ONE plane of plain fp16 (dgrad of the fp16 backward).  An entry owns whichever of the four its
+        # callers have asked for so far.
+        self.params, self.ver, self.pl, self.p2, self.tp, self.t16 = params, None, None, None, None, None
         self.ok_token, self.ok_epoch, self.ok_vers = -1, -1, None
 
     def mark_valid(self, token):
@@ -52,12 +53,13 @@ class _Entry:
         n = sum(p.shape[0] for p in self.params)
         k = self.params[0][0].numel() if self.params[0].dim() > 1 else 1
         own = [x for x in (self.pl, self.p2) if x is not None]
-        if self.tp is not None and (self.tp.rows, self.tp.cols) != (k, n):
-            return False
-        return (bool(own) or self.tp is not None) and all((x.rows, x.cols) == (n, k) for x in own)
+        for t in (self.tp, self.t16):
+            if t is not None and (t.rows, t.cols) != (k, n):
+                return False
+        return (bool(own) or self.tp is not None or self.t16 is not None) and all((x.rows, x.cols) == (n, k) for x in own)
 
-    def has(self, need_t, fmt):
-        return (self.p2 if fmt == "f16x2" else self.pl) is not None and (self.tp is not None or not need_t)
+    def has(self, need_t, fmt, t_fmt="bf16"):
+        return (self.p2 if fmt == "f16x2" else self.pl) is not None and ((self.t16 if t_fmt == "f16" else self.tp) is not None or not need_t)
 
 
 class WeightCache:
@@ -90,7 +92,7 @@ class WeightCache:
         # tables of the two multi-tensor launches are built once and replayed (what changes is the stream)
         def at(pl):
             return 0 if pl is None else (pl.hi.data_ptr(), pl.lo.data_ptr() if pl.lo is not None else 0)
-        sig = tuple((at(ent.pl), at(ent.tp), at(ent.p2), tuple(v[2] for v in ver)) for ent, ver in stale)   # every address in the tables
+        sig = tuple((at(ent.pl), at(ent.tp), at(ent.p2), at(ent.t16), tuple(v[2] for v in ver)) for ent, ver in stale)   # every address in the tables
         if self._prep is None or self._prep[0] != sig:
             jobs, jobs2 = [], []
             for ent, _ in stale:
@@ -101,7 +103,7 @@ class WeightCache:
                         # a non-contiguous parameter is converted through a temporary: nothing to replay
                         w2, sig = w2.contiguous(), None
                     n_i, last = w2.shape[0], i == len(ent.params) - 1
-                    if ent.pl is not None or ent.tp is not None:
+                    if ent.pl is not None or ent.tp is not None or ent.t16 is not None:
                         hi = lo = None
                         ldo = 0
                         if ent.pl is not None:
@@ -114,7 +116,11 @@ class WeightCache:
                         else:
                             thi = tlo = None
                             ldt, tcols = 0, n_i
-                        jobs.append((w2, hi, lo, ldo, thi, tlo, ldt, tcols))
+                        t16 = None
+                        if ent.t16 is not None:       # same geometry as tp (both are [K, pad32(N)]): one job serves both
+                            t16 = ent.t16.hi.data_ptr() + off * 2
+                            ldt, tcols = ent.t16.ld, (ent.t16.ld - off if last else n_i)
+                        jobs.append((w2, hi, lo, ldo, thi, tlo, ldt, tcols, t16))
                     if ent.p2 is not None:
                         jobs2.append((w2, ent.p2.hi.data_ptr() + off * ent.p2.ld * 2, ent.p2.lo.data_ptr() + off * ent.p2.ld * 2, ent.p2.ld))
                     off += n_i
@@ -143,41 +149,50 @@ class WeightCache:
         for ent, _ in stale:
             ent.mark_valid(self._token)
 
-    def _get(self, params, need_t: bool, fmt: str = "bf16"):
+    def _get(self, params, need_t: bool, fmt: str = "bf16", t_fmt: str = "bf16"):
         key = id(params[0]) if len(params) == 1 else tuple(id(p) for p in params)
         ent = self._c.get(key)
-        out = lambda: (ent.p2 if fmt == "f16x2" else ent.pl, ent.tp)
+        out = lambda: (ent.p2 if fmt == "f16x2" else ent.pl, ent.t16 if t_fmt == "f16" else ent.tp)
         if ent is None:
             ent = self._c[key] = _Entry(list(params))
-        elif ent.has(need_t, fmt) and ent.still_valid(self._token):
+        elif ent.has(need_t, fmt, t_fmt) and ent.still_valid(self._token):
             return out()
-        if ent.ver == ent.version() and ent.has(need_t, fmt):
+        if ent.ver == ent.version() and ent.has(need_t, fmt, t_fmt):
             ent.mark_valid(self._token)
             return out()
-        if ent.has(need_t, fmt) and ent.shapes_ok():
+        if ent.has(need_t, fmt, t_fmt) and ent.shapes_ok():
             self._refresh_all()                 # stale after an optimizer step: refresh the whole cache in one launch
             return out()
         # first use (or another form of this weight is wanted for the first time): allocate what is missing, fill this entry alone
         w2 = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], dim=0) if len(params) > 1 \
             else params[0].detach().reshape(params[0].shape[0], -1)
         if not ent.shapes_ok():
-            ent.pl = ent.p2 = ent.tp = None
+            ent.pl = ent.p2 = ent.tp = ent.t16 = None
         want_pl = fmt == "bf16" or ent.pl is not None
-        want_t = need_t or ent.tp is not None
+        want_t = (need_t and t_fmt == "bf16") or ent.tp is not None
+        want_t16 = (need_t and t_fmt == "f16") or ent.t16 is not None
         if want_pl or want_t:
             # planes always carry lo; single-pass GEMMs simply ignore it
             pl, tp, _ = ops.split_f32(w2, 3, want_rowmajor=want_pl, want_transposed=want_t)
             ent.pl = pl if want_pl else None
             ent.tp = tp
+        if want_t16:
+            n, k = w2.shape
+            w2c = w2.contiguous()
+            ld = ops.pad32(n)
+            t = torch.empty((k, ld), dtype=torch.float16, device=w2.device)
+            ent.t16 = ops.Planes(t, None, k, n, "f16")
+            ops.split_f32_multi([(w2c, None, None, 0, None, None, ld, ld, t.data_ptr())])
         if fmt == "f16x2" or ent.p2 is not None:
             ent.p2 = ops.f16x2_encode(w2.contiguous(), role=1)
         ent.ver = ent.version()
         return out()
 
-    def get(self, param: torch.Tensor, need_t: bool, fmt: str = "bf16"):
+    def get(self, param: torch.Tensor, need_t: bool, fmt: str = "bf16", t_fmt: str = "bf16"):
         """-> (Planes [N,K], Planes [K,N] | None).  `param` is [N, ...] (conv weights are flattened to [N, K]).
-        fmt 'f16x2': the [N,K] planes in the f16x2 operand format (second-operand role) (the transposed planes are split-bf16 either way)."""
-        return self._get((param,), need_t, fmt)
+        fmt 'f16x2': the [N,K] planes in the f16x2 operand format (second-operand role); t_fmt 'f16': the transposed weight as ONE plane of
+        plain fp16 (the dgrad operand of the fp16 backward) instead of split-bf16 planes."""
+        return self._get((param,), need_t, fmt, t_fmt)
 
     def get_cat(self, params, need_t: bool, fmt: str = "bf16"):
         """Planes of the row-wise concatenation of several [N_i, K] weights (DistilBERT's q/k/v projections run as ONE

@@ -27,6 +27,12 @@ extern "C" {
 
 typedef uint16_t egv_bf16;
 
+/* Version of this ABI (struct layouts, argument lists, mode / format codes).  egv_version() returns the number the LIBRARY was built
+ * with and egv_abi_check() compares a caller's view of it -- version and the sizes of the ABI structs -- with the library's: a
+ * binding generated from another header fails loudly at load time instead of passing garbage in trailing fields (round 5 grew
+ * egv_block_geom and the mode bits without either).                                                                              */
+#define EGV_ABI_VERSION 6
+
 enum { EGV_ACT_NONE = 0, EGV_ACT_GELU = 1, EGV_ACT_GELU_BWD = 2, EGV_ACT_RELU_BWD = 3 };
 
 /* ---- GEMM --------------------------------------------------------------------------------------
@@ -39,7 +45,9 @@ enum { EGV_ACT_NONE = 0, EGV_ACT_GELU = 1, EGV_ACT_GELU_BWD = 2, EGV_ACT_RELU_BW
  * big-tile NT kernel only, un-split) -- the same fp32-grade product from TWO fp16 MFMA products; passes = 4: ONE fp16 MFMA product of
  * plain fp16 planes (a_hi = fp16(A), b_hi = fp16(B) = plane 1 of a second-operand f16x2 encoding; a_lo / b_lo ignored; big-tile NT
  * kernel only, un-split; epilogues: bias + residual -> fp32 / split planes, or EGV_ACT_GELU -> out_fmt 1 / 2) -- 2^-11 per operand:
- * for the Linears whose share of the 1e-3 parity budget allows it.  Requirements: K % 32 == 0, N % 4 == 0,
+ * for the Linears whose share of the 1e-3 parity budget allows it -- and, with trans == 1, the weight gradient of the
+ * FP16 BACKWARD (dW = dY^T X on fp16(S dY) and the forward's fp16 activation plane, split-K allowed; alpha rescales the product --
+ * 1 / (1 - 2^-6) when X is plane 1 of an f16x2 first-operand encoding -- but not the column sums).  Requirements: K % 32 == 0, N % 4 == 0,
  * lda % 8 == ldb % 8 == 0, 16-byte aligned base pointers.
  *  act = EGV_ACT_GELU      : v = gelu(v); if aux_out != NULL the pre-activation is stored there first
  *  act = EGV_ACT_GELU_BWD  : v *= gelu'(aux_in[m,n])           (fc2 dgrad -> dZ)
@@ -65,6 +73,8 @@ typedef struct egv_gemm_desc {
                        fc2's dgrad: half the bytes when backward runs single-pass bf16 anyway).  Big-tile kernel only.
                        2: the bf16 buffer holds gelu'(pre-activation) itself -- EGV_ACT_GELU stores the derivative (it has
                        Phi and phi in registers) and EGV_ACT_GELU_BWD multiplies by the stored value, no second erf.
+                       3: as 2 with the derivative stored as FP16 (passes == 2 / 4 launches only): the fp16 backward, where bf16's
+                       2^-9 on gelu' would cap the accuracy of dZ.
                        trans = 0: A[M,K], B[N,K] (contraction index contiguous).  1 ("TN", wgrad): A is stored [K, lda] with
                        its M rows as COLUMNS and B is stored [K, ldb] with N columns, C[m,n] = sum_k A[k,m] B[k,n] --
                        no transposed copy of either operand is ever made (CDNA4 transpose-read from LDS).  Requires
@@ -77,7 +87,9 @@ typedef struct egv_gemm_desc {
                        library keeps no state between calls.)                                                         */
   int32_t out_fmt;  /* format of (out_hi, out_lo): 0 = split-bf16 planes; 1 = the f16x2 operand format below, first-operand role
                        (two fp16 planes); 2 = ONE plane of plain fp16 in out_hi (out_lo unused): the operand of a passes == 4
-                       consumer.  1 / 2: EGV_ACT_GELU of a passes == 2 or 4 product only (fc1 -> fc2 of the forward).             */
+                       consumer.  1 / 2: EGV_ACT_GELU of a passes == 2 or 4 product only (fc1 -> fc2 of the forward); 2 also with
+                       EGV_ACT_GELU_BWD of a passes == 4 product: dZ of the fp16 backward as ONE plane of UN-CLAMPED fp16 (a scaled
+                       gradient beyond fp16's range becomes inf, which the loss-scale logic answers with a skipped step).            */
   egv_bf16* out_bf; /* out_fmt != 0, optional: bf16(value) as a further plane [M, ldoh] -- the single-pass operand the backward GEMMs
                        (wgrad) read, since an fp16 plane cannot share an MFMA with bf16 gradients.                               */
 } egv_gemm_desc;
@@ -96,6 +108,12 @@ int egv_split_f32(const float* x, int64_t ldx, int32_t rows, int32_t cols,
 int egv_split_f32_multi(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
                         egv_bf16* const* hi, egv_bf16* const* lo, const int64_t* ldo, egv_bf16* const* t_hi,
                         egv_bf16* const* t_lo, const int64_t* ldt, const int32_t* t_cols, void* stream);
+/* The same with one more optional output per tensor: t16[i] (NULL entries allowed, t16 itself may be NULL) = the TRANSPOSED matrix
+ * as ONE plane of plain fp16 [cols, ldt] (saturating), same geometry rules as t_hi -- W^T for the dgrad GEMMs of the fp16 backward
+ * (egv_gemm_nt passes == 4 with b_hi = this plane).                                                                              */
+int egv_split_f32_multi_t16(int32_t count, const float* const* x, const int64_t* ldx, const int32_t* rows, const int32_t* cols,
+                            egv_bf16* const* hi, egv_bf16* const* lo, const int64_t* ldo, egv_bf16* const* t_hi,
+                            egv_bf16* const* t_lo, const int64_t* ldt, const int32_t* t_cols, uint16_t* const* t16, void* stream);
 /* split planes [rows, cols] -> transposed planes [cols, ldt] (+ zero pad, + colsum of hi+lo).        */
 int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, int32_t rows, int32_t cols,
                          egv_bf16* t_hi, egv_bf16* t_lo, int64_t ldt, float* colsum, void* stream);
@@ -108,7 +126,8 @@ int egv_transpose_planes(const egv_bf16* hi, const egv_bf16* lo, int64_t ldx, in
  * and cancels a1's rounding error rho; the roundings that are not compensated are attenuated by e or 2^-12 / e (~2^-17 per product:
  * 5.3e-6 on random operands where split-bf16 x3 gives 4.4e-6; embeddings 3.2e-5 from the fp32 oracle where it gives 2.7e-5).
  * An operand [rows, cols] (cols % 8 == 0) is two fp16 planes [rows, ld] (ld % 8 == 0) -- the geometry of split-bf16 planes.
- * bf (optional): bf16(x) [rows, ld], the operand of single-pass backward GEMMs.  role: 0 = first operand, 1 = second operand.
+ * bf (optional): bf16(x) [rows, ld], the operand of single-pass backward GEMMs.  role: 0 = first operand, 1 = second operand;
+ * 2 = ONE plane of plain, UN-CLAMPED fp16 in p1 (p2 / bf unused): a scaled gradient entering the fp16 backward as fp32.
  * Replaces nothing in the reference (fp32 there); producers: this converter (weights, tests), egv_layernorm_fwd_f16x2, the
  * EGV_ACT_GELU epilogue with out_fmt = 1.  Range: fp16 (saturating at 65504; below ~4e-3 a2 loses relative, not absolute, accuracy):
  * forward operands only.                                                                                                          */
@@ -224,6 +243,13 @@ int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy
                       const float* mean, const float* rstd, int32_t rows, int32_t cols,
                       const float* add1, const float* add2, float* dx, int64_t lddx,
                       egv_bf16* dx_hi, egv_bf16* dx_lo, float* dgamma, float* dbeta, float* work, void* stream);
+/* The same with the format of the dx planes as an argument: dx_fmt 0 = split-bf16 (dx_hi[, dx_lo]); 1 = ONE plane of UN-CLAMPED
+ * fp16 in dx_hi (dx_lo must be NULL): the operand of the next dgrad / wgrad GEMMs of the fp16 backward.                            */
+int egv_layernorm_bwd_fmt(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
+                          const float* x, int64_t ldx, const float* gamma,
+                          const float* mean, const float* rstd, int32_t rows, int32_t cols,
+                          const float* add1, const float* add2, float* dx, int64_t lddx,
+                          egv_bf16* dx_hi, egv_bf16* dx_lo, int32_t dx_fmt, float* dgamma, float* dbeta, float* work, void* stream);
 
 /* ---- video tokens -------------------------------------------------------------------------------
  * Patch gather for the 16x16/s16 conv (model/video_transformer.py:70-77): video [B*T,C,H,W] fp32 ->
@@ -258,9 +284,11 @@ int egv_assemble_tokens_bwd(const float* dx, int32_t B, int32_t T, int32_t n, in
  * keys, bf16 MFMA as well).  The CLS query row (attends to all S keys, :112) rides in every group as an extra query; its
  * partials are merged by a small combine kernel.  Output: split planes [B, S, H*64]; lse [B, H, S] (log-sum-exp of each
  * query row, saved for backward).  `work`: egv_divided_attn_fwd_work_floats(...) floats.
- * mode bit 1 (mode = 2 space, 3 time; passes == 3 only): out_lo receives fp16(value) instead of the bf16 residual -- the first
- * operand of a proj Linear that runs ONE fp16 product (egv_gemm_nt passes == 4 with a_hi = this plane); out_hi stays bf16(value),
- * which is what the backward reads (egv_divided_attn_bwd then takes out_lo = NULL).                                     */
+ * mode bits 1-2 (mode = 2 fmt + (0 space | 1 time); fmt != 0 with passes == 3 only) = the format of the output planes:
+ *   0  split-bf16 (out_hi = bf16(v), out_lo = bf16(v - out_hi)): a three-product proj;
+ *   1  out_hi = bf16(v) (what a bf16 backward reads), out_lo = fp16(v): the operand of a proj Linear that runs ONE fp16 product;
+ *   2  the f16x2 operand format, first-operand role (out_hi = a1, out_lo = a2): a TWO-product proj whose backward is fp16;
+ *   3  out_hi = fp16(v), out_lo unused (may be NULL): a one-product proj whose backward is fp16 as well.                 */
 int egv_divided_attn_fwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, int32_t B, int32_t T, int32_t n, int32_t H,
                          int32_t mode, int32_t passes, egv_bf16* out_hi, egv_bf16* out_lo, float* lse, float* work,
                          void* stream);
@@ -269,7 +297,10 @@ int64_t egv_divided_attn_fwd_work_floats(int32_t B, int32_t T, int32_t n, int32_
  * epilogue).  dqkv [B,S,3,H,64] is written ONCE as split planes -- every dK / dV row already contains the CLS query's
  * contribution -- i.e. directly in the operand format of the qkv dgrad / wgrad GEMMs.  Only the CLS token's own
  * gradients are accumulated in fp32 (atomics) and converted by a finish kernel.
- * `work`: egv_divided_attn_bwd_work_floats(...) floats.                                                              */
+ * `work`: egv_divided_attn_bwd_work_floats(...) floats.
+ * mode: bit 0 = time; bits 1-2 = the format the forward wrote out_* in (as above: delta = rowsum(dO o O) decodes it; formats 1-3
+ * take out_lo = NULL); bit 3 (passes == 1 only) = dqkv_hi receives ONE plane of UN-CLAMPED fp16 instead of bf16 (the fp16 backward;
+ * q / k / v / dO are still read as bf16 planes).                                                                        */
 int egv_divided_attn_bwd(const egv_bf16* qkv_hi, const egv_bf16* qkv_lo, const egv_bf16* out_hi, const egv_bf16* out_lo,
                          const egv_bf16* dout_hi, const egv_bf16* dout_lo, const float* lse, int32_t B, int32_t T,
                          int32_t n, int32_t H, int32_t mode, int32_t passes, egv_bf16* dqkv_hi, egv_bf16* dqkv_lo,
@@ -370,13 +401,31 @@ int egv_slice_sum_bf16(const egv_bf16* recv, int32_t world, int64_t slice_elems,
  * transformers==4.2.1 AdamW (run/train_egoclip.py:73, configs/pt/egoclip.json:49-54) over a list of
  * tensors given as HOST arrays of device pointers (copied into kernel arguments in chunks), fused with
  * the refresh of the split-bf16 weight planes the GEMMs read (w_hi/w_lo may be NULL per tensor).
- * hyper_dev (optional, DEVICE, 2 floats {lr, step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t)}): when given, the kernel reads
- * the two step-dependent scalars from there instead of taking them from lr / step -- for a step replayed from a HIP graph,
- * whose launch arguments are frozen at capture (the host refreshes the two floats before every replay).             */
+ * hyper_dev (optional, DEVICE, 4 floats {lr, step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t), grad_scale, skip}): when given,
+ * the kernel takes the step-dependent scalars from there instead of lr / step / grad_scale, and does NOTHING when skip != 0 --
+ * the block egv_loss_scale_update writes on the same stream (dynamic loss scale of the fp16 backward: whether the step is applied,
+ * the 1 / S that un-scales the gradients and the bias correction at the number of APPLIED steps are decided on the device).   */
 int egv_adamw_multi(int32_t count, float* const* p, const float* const* g, float* const* m, float* const* v,
                     egv_bf16* const* w_hi, egv_bf16* const* w_lo, const int64_t* numel,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                     int32_t correct_bias, float grad_scale, const float* hyper_dev, void* stream);
+
+/* ---- dynamic loss scale (the fp16 backward) ---------------------------------------------------------------
+ * The reference back-propagates in fp32 (trainer/trainer_egoclip.py:139-141); here the backward GEMMs of the video blocks can run on
+ * fp16 operands, whose range needs the gradients scaled: the loss is multiplied by S before backward() and AdamW divides by it.
+ * S lives in DEVICE memory and follows torch.cuda.amp.GradScaler's rule without any host synchronisation:
+ *   state (8 x 32 bits): [0] float S; [1] int32 good steps since S last changed; [2] int32 found_inf; [3] int32 steps skipped so far;
+ *                        [4..7] float {lr, step_size, 1 / S, skip} -- the hyper_dev block of egv_adamw_multi.
+ * egv_grad_nonfinite_multi: state[2] |= 1 if any of the `count` gradient tensors (HOST arrays of device pointers / sizes) holds an
+ * inf or NaN (an overflowed fp16 plane poisons every gradient behind it: gradient planes are written un-clamped).
+ * egv_loss_scale_update (one thread): advance != 0: found_inf ? (skip = 1, skipped += 1, S = max(S * backoff_factor, 1), good = 0)
+ * : (skip = 0, good += 1; good == growth_interval ? S = min(S * growth_factor, max_scale), good = 0), found_inf = 0, 1 / S of the
+ * scale the step RAN with -> state[6]; then {lr, step_size at t = step - skipped, state[6], state[7]} -> hyper_out (NULL: state + 4;
+ * advance == 0 fills a further parameter group's block from the decision already taken).                                          */
+int egv_grad_nonfinite_multi(int32_t count, const float* const* grads, const int64_t* numel, int32_t* state, void* stream);
+int egv_loss_scale_update(int32_t* state, float* hyper_out, float lr, float beta1, float beta2, int32_t step, int32_t correct_bias,
+                          float growth_factor, float backoff_factor, int32_t growth_interval, float max_scale, int32_t advance,
+                          void* stream);
 
 /* ---- misc -----------------------------------------------------------------------------------------------
  * gather rows: out[r,:] = x[idx_stride * r * ld ...] helper for CLS-row extraction is done with strides in
@@ -385,6 +434,10 @@ int egv_relu_split(const float* x, int64_t ldx, int32_t rows, int32_t cols, egv_
                    int64_t ldo, void* stream);
 /* scatter rows of a small matrix into a zeroed big one: dst[r * ld_dst + c] = src[r, c] (CLS-row grads). */
 int egv_version(void);
+/* 0 = the caller's header agrees with the library: abi_version == EGV_ABI_VERSION and the four struct sizes (sizeof egv_gemm_desc,
+ * egv_block_geom, egv_block_params, egv_block_bwd_io) match; 1 otherwise.                                                          */
+int egv_abi_check(int32_t abi_version, int64_t sizeof_gemm_desc, int64_t sizeof_block_geom, int64_t sizeof_block_params,
+                  int64_t sizeof_block_bwd_io);
 /* diagnostics, not on the product path: `iters` rounds of 40 independent MFMA 16x16x32 bf16 per wave, `waves` (1..8) waves
  * per workgroup, one workgroup per CU, no memory traffic -- the chip's sustained MFMA rate (tools/mfma_peak.py). */
 int egv_diag_mfma_peak(int32_t iters, int32_t waves, float* out, void* stream);
