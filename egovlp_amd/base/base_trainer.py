@@ -163,8 +163,13 @@ class Multi_BaseTrainer_dist:
     # ours load there: one dict {'arch', 'epoch', 'state_dict', 'optimizer', 'monitor_best', 'config'} per file,
     # 'checkpoint-epoch{N}.pth' every save_period epochs and a second copy 'model_best.pth' for a new best.
     def _checkpoint_state(self, epoch):
-        return {'arch': type(self.model).__name__, 'epoch': epoch, 'state_dict': self.model.state_dict(),
-                'optimizer': self.optimizer.state_dict(), 'monitor_best': self.mnt_best, 'config': self.config}
+        state = {'arch': type(self.model).__name__, 'epoch': epoch, 'state_dict': self.model.state_dict(),
+                 'optimizer': self.optimizer.state_dict(), 'monitor_best': self.mnt_best, 'config': self.config}
+        # the dynamic loss scale of an fp16 backward (egovlp_amd.optim.LossScaler; an extra key the reference's loader ignores)
+        ec = getattr(getattr(self.model, 'module', self.model), 'exec_ctx', None)
+        if ec is not None and getattr(ec, '_scaler', None) is not None:
+            state['loss_scaler'] = ec._scaler.state_dict()
+        return state
 
     def _save_checkpoint(self, epoch, save_best=False):
         state = self._checkpoint_state(epoch)
@@ -213,4 +218,7 @@ class Multi_BaseTrainer_dist:
                                 "Optimizer parameters not being resumed.")
         else:
             self.optimizer.load_state_dict(ckpt['optimizer'])
+        ec = getattr(getattr(self.model, 'module', self.model), 'exec_ctx', None)
+        if ec is not None and isinstance(ckpt.get('loss_scaler'), dict):
+            ec.loss_scaler().load_state_dict(ckpt['loss_scaler'])
         self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))

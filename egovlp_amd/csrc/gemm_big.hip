@@ -1304,7 +1304,10 @@ int launch_epi(const egv_gemm_desc& p, hipStream_t s) {
       return launch_big<4, true, EPI_RAW, 1>(p, s);              // slabs or direct fp32 output, x alpha
     } else {
       if (p.ksplit > 1 || p.alpha != 1.0f) return EGV_ERR_ARG;
-      if (p.act == EGV_ACT_NONE) return launch_big<MF, false, EPI_LINEAR, 1>(p, s);
+      if (p.act == EGV_ACT_NONE) {
+        if (!p.bias && !p.residual && !p.out_hi && p.out_f32) return launch_big<MF, false, EPI_RAW, 1>(p, s);     // dgrad -> fp32 (LayerNorm backward reads it)
+        return launch_big<MF, false, EPI_LINEAR, 1>(p, s);
+      }
       if (p.act == EGV_ACT_GELU && p.out_fmt != 0) return launch_big<MF, false, EPI_GELU_X2, 1>(p, s);
       if (p.act == EGV_ACT_GELU_BWD && !p.bias) return launch_big<MF, false, EPI_GELU_BWD, 1>(p, s);
       return EGV_ERR_ARG;

@@ -43,7 +43,8 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # its share of the 1e-3 parity budget allows it: an error injected late in the tower reaches the embedding almost unamplified, one
 # injected in the first blocks is amplified by everything behind it, so the policy is "op X runs single-product from block k_X on"
 # (setting `f16_single`, see single_product_policy and profiles/r05_precision_table.txt).
-_DEFAULT_X2_BWD = os.environ.get("EGV_X2_BWD", "bf16")          # the backward 'f16x2' / 'f16mix' pair with when none is named
+# the backward 'f16x2' / 'f16mix' pair with when none is named: the fp16 backward (round 6); EGV_X2_BWD=bf16: round 5's pairing (A/B runs)
+_DEFAULT_X2_BWD = os.environ.get("EGV_X2_BWD", "f16")
 _ENV_F16_SINGLE = os.environ.get("EGV_F16_SINGLE", "auto")     # read once: later Precision.set calls of the process agree
 # "f16" (backward only; passes code 4 = ONE fp16 product): the backward of the video blocks on fp16 operands -- gradients carry a dynamic
 # loss scale (egovlp_amd.optim.LossScaler; S lives in device memory, overflow -> skipped step + halved scale, no host sync), dY planes are
@@ -157,7 +158,8 @@ class ExecContext:
 
     def set_precision(self, fwd: str = "bf16x3", bwd: Optional[str] = None, f16_single=None):
         """'bf16x3' = split-bf16, three MFMA products, fp32-grade (meets the 1e-3 parity bar); 'bf16' = single pass;
-        'f16x2' (forward only, with a single-pass 'bf16' backward) = two fp16 products, fp32-grade like 'bf16x3' (3e-5 on the embeddings);
+        'f16x2' (forward only; backward 'f16' -- fp16 operands under a dynamic loss scale, the default -- or single-pass 'bf16') = two fp16
+        products, fp32-grade like 'bf16x3' (3e-5 on the embeddings);
         'f16mix' = 'f16x2' in the first quarter of the video blocks, ONE fp16 product in their qkv / fc1 / fc2 Linears behind it and in
         the proj Linears from the middle of the tower on (4e-4).  `f16_single` ('f16mix' only): an explicit single-product policy
         ("fc2:3,fc1:3", a dict, "auto"); default: the policy this context already carries if it is a custom one (so that

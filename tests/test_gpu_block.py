@@ -74,20 +74,23 @@ def test_block_calls_equal_the_per_kernel_path(mode, side, geom):
     assert exact["mlp.fc2.weight"] and exact["mlp.fc2.bias"] and exact["mlp.fc1.weight"], exact     # upstream of any atomics
 
 
+@pytest.mark.parametrize("bwd", ["bf16", "f16"])
 @pytest.mark.parametrize("policy", ["none", "fc2:0", "fc1:0,fc2:0", "qkv:0", "proj:0", "fc2:0,fc1:0,qkv:0,proj:0"])
 @pytest.mark.parametrize("geom", [(8, 4, 196), (2, 16, 196)])
-def test_block_calls_equal_the_per_kernel_path_in_the_fp16_modes(policy, geom):
+def test_block_calls_equal_the_per_kernel_path_in_the_fp16_modes(policy, geom, bwd):
     """The same comparison for the fp16-product forwards: 'f16x2' (policy "none": two fp16 products in qkv / fc1 / fc2) and the
     per-block single-product choices of 'f16mix' (egv_block_geom.f16_single: ONE fp16 product in fc2 / fc1 / both qkv / both proj
-    Linears, their first operand one plain fp16 plane -- for proj the attention kernels' second output plane).  Backward: single-pass
-    bf16 on the bf16 copies."""
+    Linears, their first operand one plain fp16 plane -- for proj the attention kernels' second output plane).  Backward: 'bf16' =
+    single-pass bf16 on the bf16 copies (round 5); 'f16' = the fp16 backward (round 6: no copies, fp16 qkv planes and fp16 attention in
+    both directions, the proj of a block without the 'proj' bit runs TWO fp16 products; the upstream gradient here is O(0.1), i.e.
+    already "scaled")."""
     from egovlp_amd import ops
     B, T, n = geom
     D = 768
     blk = _block(D)
     blk.layer_index, blk.depth = 5, 12
     ec = ops.new_context()
-    ec.set_precision("f16x2")
+    ec.set_precision("f16x2", bwd)
     ec.set(f16_single=policy)
     want = sum(ops.F16_SINGLE_BITS[o.split(":")[0]] for o in policy.split(",")) if policy != "none" else 0
     assert ec.f16_single_mask(5, 12) == want
@@ -255,7 +258,7 @@ def test_arenas_are_released_at_the_join_and_the_pool_stops_growing():
     B, T, n, D = 8, 4, 196, 768
     blks = [_block(D, seed=i) for i in range(3)]
     ec = ops.new_context()
-    ec.set_precision("f16x2")
+    ec.set_precision("f16x2", "f16")
     ec.set(wgrad_side_stream=True)
     x = torch.randn(B, 1 + T * n, D, device="cuda")
     reserved = []

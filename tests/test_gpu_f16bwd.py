@@ -274,3 +274,49 @@ def test_fp16_attention_matches_the_split_bf16_attention_and_beats_the_bf16_back
     assert bool(torch.isinf(huge.hi).any())
     bad = ops.divided_attn_bwd(qkv16, one, huge, lse16, B, T, n, H, mode, 1, grad_f16=True)
     assert not bool(torch.isfinite(bad.hi.float()).all())             # inf / NaN out, never a clamped finite gradient
+
+
+def test_overflowing_steps_are_skipped_and_the_scale_finds_its_range():
+    """The whole EgoClip step in the benchmarked mode ('f16mix' forward, fp16 backward) with a loss scale that starts absurdly high
+    (2^30): fp16 gradient planes overflow to inf, `AdamW.step(scaler=...)` sees it on the device and does NOT touch parameters or
+    moments, the scale halves -- step after step, without any host synchronisation -- until a backward fits fp16's range; from then on
+    the steps are applied, the loss stays finite, and the bias correction has counted only the applied steps."""
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.model.model import FrozenInTime
+    from egovlp_amd.optim import AdamW, LossScaler
+    from egovlp_amd.synth import synth_batch, synth_state_dict
+    from egovlp_amd.trainer.trainer_egoclip import egoclip_step
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 4, "pretrained": True,
+                                   "time_init": "rand"},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"}, projection="minimal",
+                     load_checkpoint="")
+    m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=5))
+    m.text_model.set_dropout(0.0, 0.0)
+    m = m.cuda().train()
+    m.exec_ctx.set_precision("f16mix", "f16")
+    b = synth_batch(4, T=4, L=16, seed=21)
+    dev = {"video": b["video"].cuda(), "text": {k: v.cuda() for k, v in b["text"].items()}, "noun_vec": b["noun_vec"].cuda(),
+           "verb_vec": b["verb_vec"].cuda()}
+    opt = AdamW(m.parameters(), lr=3e-5)
+    sc = LossScaler(init_scale=2.0 ** 30, growth_interval=1000, max_scale=2.0 ** 30)
+    watch = [m.video_model.blocks[0].attn.qkv.weight, m.video_model.blocks[11].mlp.fc2.weight, m.text_model.transformer.layer[0].ffn.lin1.weight]
+    before = [w.detach().clone() for w in watch]
+    losses, scales, skipped = [], [], []
+    for step in range(24):
+        losses.append(egoclip_step(m, EgoNCE(), opt, dev, scaler=sc))
+        scales.append(sc.get_scale())                    # (host readbacks: this is a test)
+        skipped.append(sc.skipped_steps())
+        if skipped[-1] == step + 1:                      # every step so far overflowed: nothing may have moved
+            assert all(torch.equal(w.detach(), b0) for w, b0 in zip(watch, before)), step
+    n_skip = skipped[-1]
+    print("loss scale from 2^30: %d skipped steps, scale settles at 2^%d; losses %s" % (n_skip, int(math.log2(scales[-1])), ["%.4f" % float(x) for x in losses[-4:]]))
+    assert 4 <= n_skip <= 20, (n_skip, scales)
+    assert scales[-1] == 2.0 ** (30 - n_skip)                           # one halving per skipped step, no growth yet
+    assert skipped == sorted(skipped) and all(skipped[i + 1] - skipped[i] in (0, 1) for i in range(len(skipped) - 1))
+    assert all(torch.isfinite(x) for x in losses)
+    assert all(not torch.equal(w.detach(), b0) for w, b0 in zip(watch, before))      # the applied steps did move the weights
+    assert all(bool(torch.isfinite(w).all()) for w in watch)
+    assert float(losses[-1]) < float(losses[0])                          # and in the right direction (same batch every step)
+    # the optimizer's moments saw only finite, un-scaled gradients
+    st = opt.state[watch[0]]
+    assert bool(torch.isfinite(st["exp_avg"]).all()) and float(st["exp_avg"].abs().max()) < 1.0

@@ -32,8 +32,53 @@ X2_BAR = 2e-4
 MIX_BAR = 7e-4
 
 
+# The fp16 backward (round 6: 'f16x2' / 'f16mix' pair with it by default; '.../bf16' names round 5's pairing): ONE fp16 product per
+# backward GEMM and per attention product on loss-scaled gradients -- 2^-11 per operand.  Measured on MI355X against the bf16x3 backward:
+# 2.6e-3 on the deepest tensors (block 0, patch embedding) where the bf16 backward had 2.0e-2 (profiles/r06_fp16_backward_bringup.txt).
+F16_GRAD = 1e-2
+
+
 def _fbar(mode, per_row=False):
-    return {"f16x2": X2_BAR, "f16mix": PARITY if per_row else MIX_BAR}.get(mode, PARITY)
+    return {"f16x2": X2_BAR, "f16mix": PARITY if per_row else MIX_BAR}.get(mode.split("/")[0], PARITY)
+
+
+def _gbar(mode):
+    if mode == "bf16x3":
+        return 3 * PARITY
+    return MIXED_GRAD if (mode == "mixed" or mode.endswith("/bf16")) else F16_GRAD
+
+
+def _set_mode(mode):
+    """'bf16x3', 'mixed' (bf16x3 forward, bf16 backward), 'f16x2' / 'f16mix' (fp16 backward), 'f16x2/bf16' / 'f16mix/bf16'."""
+    from egovlp_amd.ops import Precision
+    if mode == "mixed":
+        Precision.set("bf16x3", "bf16")
+    elif "/" in mode:
+        Precision.set(*mode.split("/"))
+    elif mode in ("f16x2", "f16mix"):
+        Precision.set(mode, "f16")
+    else:
+        Precision.set(mode)
+
+
+def _backward(m, loss, retained=()):
+    """loss.backward() in the model's backward precision: the fp16 backward runs on the loss multiplied by the model's device-side loss
+    scale (what egoclip_step does); the gradients -- parameters and the `retained` non-leaf tensors -- are un-scaled here, as AdamW does
+    inside its update, so that callers compare plain gradients."""
+    ec = m.exec_ctx
+    if ec.bwd_passes != 4:
+        loss.backward()
+        return
+    sc = ec.loss_scaler()
+    S = sc.get_scale()
+    sc.scale(loss).backward()
+    ec.join_side_stream()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.grad is not None:
+                p_.grad.mul_(1.0 / S)
+        for t in retained:
+            t.grad.mul_(1.0 / S)
 
 
 def rel(a, b):
@@ -172,11 +217,12 @@ def test_full_model_golden_in_the_benchmarked_mixed_mode(full, golden_dir):
         m.train()
 
 
-@pytest.mark.parametrize("x2mode", ["f16x2", "f16mix"])
+@pytest.mark.parametrize("x2mode", ["f16x2", "f16mix", "f16x2/bf16", "f16mix/bf16"])
 def test_full_model_golden_in_the_f16x2_mode(full, golden_dir, x2mode):
-    """The fp16-product forwards (+ single-pass bf16 backward) against the reference's golden vectors at B = 4 (M = 3140 tokens: every
-    qkv / fc1 / fc2 GEMM of the 12 blocks runs the two-fp16-product kernel -- 'f16mix': the one-product kernel from block 3 on):
-    embeddings and losses inside X2_BAR / MIX_BAR, gradients inside MIXED_GRAD (the backward is the mixed mode's)."""
+    """The fp16-product forwards against the reference's golden vectors at B = 4 (M = 3140 tokens: every qkv / fc1 / fc2 GEMM of the 12
+    blocks runs the two-fp16-product kernel -- 'f16mix': the one-product kernel from block 3 on): embeddings and losses inside X2_BAR /
+    MIX_BAR; gradients inside F16_GRAD with the fp16 backward (the default pairing: fp16 attention in both directions, scaled loss) and
+    inside MIXED_GRAD with round 5's bf16 backward ('.../bf16')."""
     from egovlp_amd import ops
     from egovlp_amd.model.loss import EgoNCE, NormSoftmaxLoss
     from egovlp_amd.ops import Precision
@@ -185,9 +231,9 @@ def test_full_model_golden_in_the_f16x2_mode(full, golden_dir, x2mode):
     batch = synth_batch(4, T=4, L=32, seed=1234, ragged=True)
     assert ops.f16x2_gemm_ok(4 * 785, 2304, 768) and ops.f16x2_gemm_ok(4 * 785, 768, 3072)
     try:
-        Precision.set(x2mode)
-        assert Precision.name() == (x2mode, "bf16")
-        fbar = _fbar(x2mode)
+        _set_mode(x2mode)
+        assert Precision.name() == (x2mode.split("/")[0], "bf16" if x2mode.endswith("/bf16") else "f16")
+        fbar, gbar = _fbar(x2mode), _gbar(x2mode)
         m.eval()
         d = to_dev(batch)
         te, ve = m(d)
@@ -198,7 +244,10 @@ def test_full_model_golden_in_the_f16x2_mode(full, golden_dir, x2mode):
         print("full B=4 %s: text rel %.2e video rel %.2e egonce rel %.2e infonce rel %.2e" % (x2mode, r_t, r_v, r_e, r_n))
         assert r_t < X2_BAR and r_v < fbar and r_e < fbar and r_n < fbar         # the text tower is three-product in both
         te.retain_grad(); ve.retain_grad()
-        ego.backward()
+        m.train()
+        for p_ in m.parameters():
+            p_.grad = None
+        _backward(m, ego, (te, ve))
         assert rel(te.grad, g["grad_text_embeds"]) < PARITY and rel(ve.grad, g["grad_video_embeds"]) < PARITY
         params = dict(m.named_parameters())
         worst = 0.0
@@ -210,7 +259,7 @@ def test_full_model_golden_in_the_f16x2_mode(full, golden_dir, x2mode):
                 r1 = rel(g2[:8, :64], g[key])
                 r2 = abs(float(gr.norm()) / float(g["gradnorm:" + name]) - 1)
                 worst = max(worst, r1)
-                assert r1 < MIXED_GRAD and r2 < MIXED_GRAD, (name, r1, r2)
+                assert r1 < gbar and r2 < gbar, (name, r1, r2)
         print("full B=4 %s: worst sentinel-gradient rel %.2e" % (x2mode, worst))
     finally:
         Precision.set("bf16x3")
@@ -420,7 +469,8 @@ def test_full_size_train_step_matches_oracle_on_the_whole_batch(full):
     """BASELINE configs[1] at full size (B = 32, T = 4: M = 25 120 tokens -- the only size where the 320-row tiles, split-K 7..28
     and the 25 120-row TN weight gradients all run together): loss, both embedding gradients and sentinel weight gradients of
     ONE backward against the CPU oracle on the whole batch (fp32 autograd, ~1 min on the box's cores), in the parity mode
-    (everything at 1e-3 / 3e-3) and in the benchmarked mixed mode (same forward, gradients inside MIXED_GRAD)."""
+    (everything at 1e-3 / 3e-3), in the bf16-backward modes (gradients inside MIXED_GRAD) and in the BENCHMARKED mode 'f16mix' with its
+    fp16 backward (gradients inside F16_GRAD = 1e-2; round-5 verdict: "MIXED_GRAD tightened to <= 1e-2 at B = 32 vs the oracle")."""
     from egovlp_amd.model.loss import EgoNCE
     from egovlp_amd.ops import Precision
     m, sd = full
@@ -441,18 +491,15 @@ def test_full_size_train_step_matches_oracle_on_the_whole_batch(full):
     dev = to_dev(batch)
     params = dict(m.named_parameters())
     try:
-        for mode, gbound in (("bf16x3", 3 * PARITY), ("mixed", MIXED_GRAD), ("f16x2", MIXED_GRAD), ("f16mix", MIXED_GRAD)):
-            if mode in ("f16x2", "f16mix"):
-                Precision.set(mode)
-            else:
-                Precision.set("bf16x3", "bf16" if mode == "mixed" else "bf16x3")
-            fbar = _fbar(mode)
+        for mode in ("bf16x3", "mixed", "f16x2", "f16mix", "f16mix/bf16"):
+            _set_mode(mode)
+            fbar, gbound = _fbar(mode), _gbar(mode)
             for p_ in m.parameters():
                 p_.grad = None
             te, ve = m(dev)
             te.retain_grad(); ve.retain_grad()
             loss = EgoNCE().fused(te, ve, dev["noun_vec"], dev["verb_vec"])
-            loss.backward()
+            _backward(m, loss, (te, ve))
             r_t, r_v, r_l = rel(te, rt), rel(ve, rv), abs(float(loss) - float(rl)) / abs(float(rl))
             print("B=32 %s: text rel %.2e video rel %.2e loss rel %.2e | d_text %.2e d_video %.2e" % (
                 mode, r_t, r_v, r_l, rel(te.grad, rt.grad), rel(ve.grad, rv.grad)))
@@ -477,9 +524,9 @@ def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T
     from egovlp_amd.model.loss import EgoNCE
     from egovlp_amd.model.model import FrozenInTime
     from egovlp_amd.ops import Precision
-    Precision.set(mode)
+    _set_mode(mode)
     request.addfinalizer(lambda: Precision.set("bf16x3"))
-    fbar, gbar = (_fbar(mode), MIXED_GRAD) if mode in ("f16x2", "f16mix") else (PARITY, 3 * PARITY)
+    fbar, gbar = _fbar(mode), _gbar(mode)
     m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": arch, "num_frames": model_frames,
                                    "pretrained": True, "time_init": "rand"},
                      text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"},
@@ -493,7 +540,7 @@ def test_other_baseline_configs_full_model_and_egonce_match_oracle(name, arch, T
     te, ve = m(dev)
     te.retain_grad(); ve.retain_grad()
     loss = EgoNCE().fused(te, ve, dev["noun_vec"], dev["verb_vec"])
-    loss.backward()
+    _backward(m, loss, (te, ve))
     large = arch == "large_patch14_224"
     cfg = O.VideoCfg(patch_size=14, embed_dim=1024, depth=24, num_heads=16, num_frames=model_frames) if large \
         else O.VideoCfg(num_frames=model_frames)
@@ -622,7 +669,7 @@ def test_other_baseline_configs_at_full_size_match_oracle_rows_and_their_halves(
     loss on the device embeddings' oracle counterparts for the checked rows' sub-batch."""
     from egovlp_amd.model.model import FrozenInTime
     from egovlp_amd.ops import Precision
-    Precision.set(mode)
+    _set_mode(mode)
     request.addfinalizer(lambda: Precision.set("bf16x3"))
     fbar = _fbar(mode, per_row=True)
     m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": arch, "num_frames": model_frames,
