@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-dp-leg", action="store_true", help="skip the secondary leg that runs the N > 1 step policy (process group, RCCL "
                     "gather, hook-free gradient exchange, ONE wgrad stream, 248-workgroup GEMM grid) at world size 1")
+    ap.add_argument("--no-grad-err", action="store_true", help="skip grad_rel_err (two extra backward passes; A/B timing runs)")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 20-step loss / parameter drift comparison of the "
                     "benchmarked precision mode against the all-bf16x3 (fp32-grade gradient) run")
     ap.add_argument("--gemm-grid", type=int, default=0, help="persistent workgroups of the big GEMM (default: 256 at N=1, "
@@ -529,7 +530,7 @@ def main():
     if roof is not None:
         out["roofline"] = roof
     # ---- how far the gradients of THIS precision mode are from the fp32-grade (bf16x3) backward of the same step
-    if args.precision != "bf16x3":
+    if args.precision != "bf16x3" and not args.no_grad_err:
         out["grad_rel_err"] = grad_rel_err(model, loss_fn, data, world, rank, set_precision, args.precision)
     # ---- exchange diagnostics (N > 1): what the step spends in the collectives that backward does not hide
     if use_dist:

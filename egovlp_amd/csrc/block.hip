@@ -119,7 +119,7 @@ void grad_layout(const egv_block_geom& g, int64_t off[18], int64_t& total) {
 
 struct BwdLayout {
   int64_t g_hi, g_lo, dz_hi, dz_lo, d_n2, d_sr, dsr_hi, dsr_lo, das_hi, das_lo, dqkvs_hi, dqkvs_lo, d_n1, d_tr, dtr_hi, dtr_lo, dat_hi,
-      dat_lo, dqkvt_hi, dqkvt_lo, d_n3, ln_work, attn_work, partial[6];
+      dat_lo, dqkvt_hi, dqkvt_lo, d_n3, ln_work[3], attn_work, partial[6];
   int64_t total;
 };
 
@@ -143,7 +143,7 @@ BwdLayout bwd_layout(const egv_block_geom& g, const int32_t* ksplit) {
   L.dat_hi = plane(o.D); L.dat_lo = plane_lo(o.D);
   L.dqkvt_hi = plane(3 * o.D); L.dqkvt_lo = plane_lo(3 * o.D);
   L.d_n3 = b.take(o.M * o.D * 4);
-  L.ln_work = b.take(2 * o.D * (int64_t)egv_layernorm_bwd_parts((int32_t)o.M) * 4);
+  for (int i = 0; i < 3; ++i) L.ln_work[i] = b.take(2 * o.D * (int64_t)egv_layernorm_bwd_parts((int32_t)o.M) * 4);   // one per LayerNorm: reduced together at the end
   L.attn_work = b.take(egv_divided_attn_bwd_work_floats(g.B, g.T, g.n, g.H) * 4);
   for (int i = 0; i < 6; ++i) {
     int64_t N, K;
@@ -395,8 +395,8 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   }
   float* d_sr = at<float>(A, L.d_sr);
   egv_bf16 *dsr_hi = at<egv_bf16>(A, L.dsr_hi), *dsr_lo = at<egv_bf16>(A, L.dsr_lo);
-  EGV_TRY(egv_layernorm_bwd_fmt(d_n2, nullptr, nullptr, D, sr, D, p.n2w, at<float>(FA, F.mean2), at<float>(FA, F.rstd2), M, D, io.g_out, nullptr,
-                            d_sr, D, dsr_hi, dsr_lo, h16 ? 1 : 0, grads + goff[16], grads + goff[17], at<float>(A, L.ln_work), stream));
+  EGV_TRY(egv_layernorm_bwd_partial(d_n2, nullptr, nullptr, D, sr, D, p.n2w, at<float>(FA, F.mean2), at<float>(FA, F.rstd2), M, D, io.g_out, nullptr,
+                            d_sr, D, dsr_hi, dsr_lo, h16 ? 1 : 0, grads + goff[16], grads + goff[17], at<float>(A, L.ln_work[0]), stream));
   // ---- spatial attention backward
   EGV_TRY(wgrad(3, dsr_hi, dsr_lo, D, as_hi, as_lo, D));
   egv_bf16 *das_hi = at<egv_bf16>(A, L.das_hi), *das_lo = at<egv_bf16>(A, L.das_lo);
@@ -418,8 +418,8 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   }
   float* d_tr = at<float>(A, L.d_tr);
   egv_bf16 *dtr_hi = at<egv_bf16>(A, L.dtr_hi), *dtr_lo = at<egv_bf16>(A, L.dtr_lo);
-  EGV_TRY(egv_layernorm_bwd_fmt(d_n1, nullptr, nullptr, D, tr, D, p.n1w, at<float>(FA, F.mean1), at<float>(FA, F.rstd1), M, D, nullptr, nullptr,
-                            d_tr, D, dtr_hi, dtr_lo, h16 ? 1 : 0, grads + goff[14], grads + goff[15], at<float>(A, L.ln_work), stream));
+  EGV_TRY(egv_layernorm_bwd_partial(d_n1, nullptr, nullptr, D, tr, D, p.n1w, at<float>(FA, F.mean1), at<float>(FA, F.rstd1), M, D, nullptr, nullptr,
+                            d_tr, D, dtr_hi, dtr_lo, h16 ? 1 : 0, grads + goff[14], grads + goff[15], at<float>(A, L.ln_work[1]), stream));
   // ---- temporal attention backward
   EGV_TRY(wgrad(1, dtr_hi, dtr_lo, D, at_hi, at_lo, D));
   egv_bf16 *dat_hi = at<egv_bf16>(A, L.dat_hi), *dat_lo = at<egv_bf16>(A, L.dat_lo);
@@ -440,8 +440,15 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
     EGV_TRY(egv_gemm_nt(&d, stream));
   }
   // x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
-  EGV_TRY(egv_layernorm_bwd_fmt(d_n3, nullptr, nullptr, D, io.x, D, p.n3w, at<float>(FA, F.mean3), at<float>(FA, F.rstd3), M, D, d_tr, d_sr,
+  EGV_TRY(egv_layernorm_bwd_partial(d_n3, nullptr, nullptr, D, io.x, D, p.n3w, at<float>(FA, F.mean3), at<float>(FA, F.rstd3), M, D, d_tr, d_sr,
                             io.d_x, D, io.dx_hi, Pb == 3 ? io.dx_lo : nullptr, h16 ? 1 : 0, grads + goff[12], grads + goff[13],
-                            at<float>(A, L.ln_work), stream));
+                            at<float>(A, L.ln_work[2]), stream));
+  // the affine gradients of the three LayerNorms: their per-block partial sums are reduced by ONE launch (three before)
+  {
+    const float* w3[3] = {at<float>(A, L.ln_work[0]), at<float>(A, L.ln_work[1]), at<float>(A, L.ln_work[2])};
+    float* g3[3] = {grads + goff[16], grads + goff[14], grads + goff[12]};
+    float* b3[3] = {grads + goff[17], grads + goff[15], grads + goff[13]};
+    EGV_TRY(egv_layernorm_bwd_reduce(3, w3, M, D, g3, b3, stream));
+  }
   return EGV_OK;
 }

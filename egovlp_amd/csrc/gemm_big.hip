@@ -263,11 +263,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
   const int total = nwg * ksplit;
   const int nkt_total = (p.K + KTD - 1) / KTD;
   const int kt_per = (nkt_total + ksplit - 1) / ksplit;
-  const int nseg = (!F3 && p.passes == 3) ? 3 : 1;
+  // the plain loops run a multi-product GEMM as k-SEGMENTS over the planes (one product per segment, 64-deep k-tiles, the same accumulators):
+  // three for split-bf16 (diagnostics builds: the product path is the fused F3 loop), TWO for f16x2 operands on the fp16 instance
+  // (H1, passes == 2: A_2 B_2 then A_1 B_1 -- a single-product GEMM over the concatenation [A_2 | A_1] . [B_2 | B_1]^T; for short
+  // contractions it beats the fused two-product loop, whose 32-deep k-tiles pay twice the k-tile hand-overs)
+  const int nseg = (!F3 && p.passes == 3) ? 3 : ((H1 && p.passes == 2) ? 2 : 1);
 
-  // k-segments: (A_hi,B_lo), (A_lo,B_hi), (A_hi,B_hi) for passes == 3; (A_hi,B_hi) alone otherwise
-  auto seg_a = [&](int s) -> const bf16_t* { return (nseg == 3 && s == 1) ? p.a_lo : p.a_hi; };
-  auto seg_b = [&](int s) -> const bf16_t* { return (nseg == 3 && s == 0) ? p.b_lo : p.b_hi; };
+  // k-segments: (A_hi,B_lo), (A_lo,B_hi), (A_hi,B_hi) for passes == 3; (A_lo,B_lo), (A_hi,B_hi) for f16x2; (A_hi,B_hi) alone otherwise
+  auto seg_a = [&](int s) -> const bf16_t* { return ((nseg == 3 && s == 1) || (nseg == 2 && s == 0)) ? p.a_lo : p.a_hi; };
+  auto seg_b = [&](int s) -> const bf16_t* { return ((nseg == 3 && s == 0) || (nseg == 2 && s == 0)) ? p.b_lo : p.b_hi; };
 
   // ---- DMA (global -> LDS) source offsets, in elements, relative to the tile origin of the current k-tile -----
   long a_voff, b_voff;
@@ -1392,7 +1396,14 @@ int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant) {
   static const int f3_env = getenv("EGV_GEMM_F3") ? atoi(getenv("EGV_GEMM_F3")) : 1;
   f3 = f3 && f3_env != 0;
 #endif
-  if (p.passes == 2) return mf == 5 ? launch_epi<5, false, 2>(p, s) : launch_epi<4, false, 2>(p, s);      // f16x2
+  if (p.passes == 2) {      // f16x2: the fused two-product loop, or -- short contractions -- two k-segments of the plain fp16 loop
+    // (same box, interleaved: proj 75 -> 68 us, fc2 260 -> 221, fc1 306 -> 292, qkv 208 -> 203; step 950 -> 960.5 pairs/s --
+    // profiles/r06g_x2seg_bench.txt, r06h_ab_x2seg_auxbwd.txt; EGV_X2_SEG=0: the fused loop, 1: only K, N <= 768)
+    static const int seg_env = getenv("EGV_X2_SEG") ? atoi(getenv("EGV_X2_SEG")) : 2;
+    const bool seg = (seg_env & 2) || ((seg_env & 1) && p.K <= 768 && p.N <= 768);
+    if (seg) return mf == 5 ? launch_epi<5, false, 1>(p, s) : launch_epi<4, false, 1>(p, s);
+    return mf == 5 ? launch_epi<5, false, 2>(p, s) : launch_epi<4, false, 2>(p, s);
+  }
   if (p.passes == 4) return mf == 5 ? launch_epi<5, false, 1>(p, s) : launch_epi<4, false, 1>(p, s);      // one fp16 product
   if (f3) return mf == 5 ? launch_epi<5, false, 3>(p, s) : launch_epi<4, false, 3>(p, s);
   if (mf == 5) return launch_epi<5, false>(p, s);

@@ -192,9 +192,15 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 2) void layernorm_bwd_kernel(
 
 // second stage: work[parts][2][cols] -> dgamma/dbeta (zeroed by the launcher).  grid (cols/64, ceil(parts/64)): a block
 // sums 64 parts (16 per wave, all loads in flight at once), one atomicAdd per column per block.
-__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ work, int parts, int cols,
-                                                                   float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta) {
+struct LnReduceTable {          // up to four LayerNorm backwards reduced by ONE launch (blockIdx.z picks the entry)
+  const float* work[4];
+  float* dgamma[4];
+  float* dbeta[4];
+};
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const LnReduceTable t, int parts, int cols) {
+  const float* __restrict__ work = t.work[blockIdx.z];
+  float* __restrict__ dgamma = t.dgamma[blockIdx.z];
+  float* __restrict__ dbeta = t.dbeta[blockIdx.z];
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -252,6 +258,36 @@ extern "C" int egv_layernorm_bwd_fmt(const float* dy, const egv_bf16* dy_hi, con
                                      const float* mean, const float* rstd, int32_t rows, int32_t cols, const float* add1,
                                      const float* add2, float* dx, int64_t lddx, egv_bf16* dx_hi, egv_bf16* dx_lo, int32_t dx_fmt,
                                      float* dgamma, float* dbeta, float* work, void* stream) {
+  const int rc = egv_layernorm_bwd_partial(dy, dy_hi, dy_lo, lddy, x, ldx, gamma, mean, rstd, rows, cols, add1, add2, dx, lddx, dx_hi, dx_lo,
+                                           dx_fmt, dgamma, dbeta, work, stream);
+  if (rc) return rc;
+  const float* w1[1] = {work};
+  float* g1[1] = {dgamma};
+  float* b1[1] = {dbeta};
+  return egv_layernorm_bwd_reduce(1, w1, rows, cols, g1, b1, stream);
+}
+
+// second stage for up to four LayerNorm backwards of the same (rows, cols) in ONE launch: work[i] -> dgamma[i] / dbeta[i]
+extern "C" int egv_layernorm_bwd_reduce(int32_t count, const float* const* work, int32_t rows, int32_t cols, float* const* dgamma,
+                                        float* const* dbeta, void* stream) {
+  if (count < 1 || count > 4 || !work || !dgamma || !dbeta || rows <= 0 || cols <= 0) return EGV_ERR_ARG;
+  LnReduceTable t = {};
+  for (int i = 0; i < count; ++i) {
+    if (!work[i]) return EGV_ERR_ARG;
+    t.work[i] = work[i]; t.dgamma[i] = dgamma[i]; t.dbeta[i] = dbeta[i];
+  }
+  const int parts = egv_layernorm_bwd_parts(rows);
+  EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 63) / 64, (parts + 63) / 64, count), dim3(256), 0, (hipStream_t)stream, t, parts, cols);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
+
+// first stage only: dx (+ planes), per-block partial sums of dgamma / dbeta -> work; dgamma / dbeta are ZEROED (the reduce accumulates)
+extern "C" int egv_layernorm_bwd_partial(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
+                                         const float* x, int64_t ldx, const float* gamma,
+                                         const float* mean, const float* rstd, int32_t rows, int32_t cols, const float* add1,
+                                         const float* add2, float* dx, int64_t lddx, egv_bf16* dx_hi, egv_bf16* dx_lo, int32_t dx_fmt,
+                                         float* dgamma, float* dbeta, float* work, void* stream) {
   if ((!dy && !dy_hi) || !x || !gamma || !mean || !rstd || !dx || !work) return EGV_ERR_ARG;
   if (dx_fmt < 0 || dx_fmt > 1 || (dx_fmt == 1 && dx_lo)) return EGV_ERR_ARG;
   if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
@@ -266,9 +302,6 @@ extern "C" int egv_layernorm_bwd_fmt(const float* dy, const egv_bf16* dy_hi, con
   else if (nv64 == 3) EGV_LN_BWD(3);
   else EGV_LN_BWD(4);
 #undef EGV_LN_BWD
-  EGV_CHECK_LAUNCH();
-  EGV_LAUNCH(layernorm_bwd_reduce_kernel, dim3((cols + 63) / 64, (parts + 63) / 64), dim3(256), 0, s, work, parts,
-             cols, dgamma, dbeta);
   EGV_CHECK_LAUNCH();
   return EGV_OK;
 }

@@ -467,7 +467,9 @@ class _PatchTokensFn(torch.autograd.Function):
     def backward(ctx, dx):
         B, T, n, P_, D, T_model = ctx.geom[:6]
         ec = ctx.ec
-        Pb = ec.bwd_passes_split        # (next to an fp16 backward of the blocks: three bf16 products)
+        # next to an fp16 backward of the blocks: ONE bf16 product.  This wgrad is the last GEMM of backward (nothing left to hide it under),
+        # its dY carries the blocks' 2.5e-3 already, and three products would cost 0.12 ms on the tail for 3.5e-3 -> 2.5e-3 on this one tensor
+        Pb = 1 if ec.bwd_passes == 4 else ec.bwd_passes
         ec.poll_backward()              # every block's gradients are final here
         d_pe, d_cls, d_pos, d_tmp = ops.assemble_tokens_bwd(dx.contiguous(), B, T, n, D, T_model)
         K = ctx.wshape[1] * ctx.wshape[2] * ctx.wshape[3]

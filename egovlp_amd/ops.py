@@ -45,6 +45,7 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3
 # (setting `f16_single`, see single_product_policy and profiles/r05_precision_table.txt).
 # the backward 'f16x2' / 'f16mix' pair with when none is named: the fp16 backward (round 6); EGV_X2_BWD=bf16: round 5's pairing (A/B runs)
 _DEFAULT_X2_BWD = os.environ.get("EGV_X2_BWD", "f16")
+_AUX_BWD = int(os.environ.get("EGV_AUX_BWD", "3"))              # A/B: 1 = the text tower / patch embedding / heads back on ONE bf16 product next to an fp16 backward
 _ENV_F16_SINGLE = os.environ.get("EGV_F16_SINGLE", "auto")     # read once: later Precision.set calls of the process agree
 # "f16" (backward only; passes code 4 = ONE fp16 product): the backward of the video blocks on fp16 operands -- gradients carry a dynamic
 # loss scale (egovlp_amd.optim.LossScaler; S lives in device memory, overflow -> skipped step + halved scale, no host sync), dY planes are
@@ -192,7 +193,7 @@ class ExecContext:
     bwd_passes = property(lambda self: self.get("bwd_passes"))
     # the backward of everything OUTSIDE the video blocks (text tower, patch embedding, projection heads; 2 % of the step's FLOPs): next
     # to an fp16 backward it runs three bf16 products, so that every weight gradient of the step is fp32-grade
-    bwd_passes_split = property(lambda self: 3 if self.get("bwd_passes") == 4 else self.get("bwd_passes"))
+    bwd_passes_split = property(lambda self: _AUX_BWD if self.get("bwd_passes") == 4 else self.get("bwd_passes"))
     wgrad_side_stream = property(lambda self: self.get("wgrad_side_stream"))
     text_side_stream = property(lambda self: self.get("text_side_stream"))
     gemm_grid = property(lambda self: self.get("gemm_grid"))

@@ -251,6 +251,18 @@ int egv_layernorm_bwd_fmt(const float* dy, const egv_bf16* dy_hi, const egv_bf16
                           const float* add1, const float* add2, float* dx, int64_t lddx,
                           egv_bf16* dx_hi, egv_bf16* dx_lo, int32_t dx_fmt, float* dgamma, float* dbeta, float* work, void* stream);
 
+/* The two stages of the backward as separate entry points: egv_layernorm_bwd_partial = everything but the reduction of the per-block
+ * partial sums (dx [+ planes] are final; dgamma / dbeta are zeroed, `work` holds the partials), egv_layernorm_bwd_reduce = ONE launch
+ * that finishes up to four such backwards of the same (rows, cols) (HOST arrays of `count` device pointers) -- egv_block_bwd reduces
+ * the three LayerNorms of a SpaceTimeBlock with one launch instead of three.                                                       */
+int egv_layernorm_bwd_partial(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
+                              const float* x, int64_t ldx, const float* gamma,
+                              const float* mean, const float* rstd, int32_t rows, int32_t cols,
+                              const float* add1, const float* add2, float* dx, int64_t lddx,
+                              egv_bf16* dx_hi, egv_bf16* dx_lo, int32_t dx_fmt, float* dgamma, float* dbeta, float* work, void* stream);
+int egv_layernorm_bwd_reduce(int32_t count, const float* const* work, int32_t rows, int32_t cols, float* const* dgamma,
+                             float* const* dbeta, void* stream);
+
 /* ---- video tokens -------------------------------------------------------------------------------
  * Patch gather for the 16x16/s16 conv (model/video_transformer.py:70-77): video [B*T,C,H,W] fp32 ->
  * A[(bt*gh + py)*gw + px][c*P*P + i*P + j] split planes, K = C*P*P (a multiple of 32 for P=16/C=3).   */
