@@ -274,6 +274,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-dp-leg", action="store_true", help="skip the secondary leg that runs the N > 1 step policy (process group, RCCL "
                     "gather, hook-free gradient exchange, ONE wgrad stream, 248-workgroup GEMM grid) at world size 1")
+    ap.add_argument("--no-guard", action="store_true", help="skip the precision guard's measurement of the per-block policy before the timed steps")
     ap.add_argument("--no-grad-err", action="store_true", help="skip grad_rel_err (two extra backward passes; A/B timing runs)")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 20-step loss / parameter drift comparison of the "
                     "benchmarked precision mode against the all-bf16x3 (fp32-grade gradient) run")
@@ -369,6 +370,13 @@ def main():
     batch = synth_batch(B, T=T, L=L, seed=1234, rank=rank)
     data = {"video": batch["video"].cuda(), "text": {k: v.cuda() for k, v in batch["text"].items()},
             "noun_vec": batch["noun_vec"].cuda(), "verb_vec": batch["verb_vec"].cuda()}
+
+    # the per-block precision policy measured on THESE weights and THIS batch before anything is timed (egovlp_amd.guard): the timed
+    # steps run the policy it leaves in force (on the synthetic Gaussian weights: the shipped one), and the line says what it measured
+    guard_report = None
+    if args.precision in ("f16mix", "f16x2") and not args.no_guard:
+        from egovlp_amd.guard import PrecisionGuard
+        guard_report = PrecisionGuard(model).check(data)
 
     HOST = {}
 
@@ -530,6 +538,10 @@ def main():
     if roof is not None:
         out["roofline"] = roof
     # ---- how far the gradients of THIS precision mode are from the fp32-grade (bf16x3) backward of the same step
+    if guard_report is not None:
+        out["precision_guard"] = {"what": "video embedding of this batch in the policy in force vs the all-bf16x3 forward, measured on the device before the "
+                                          "timed steps (egovlp_amd/guard.py); over budget -> the policy is demoted, logged, and the line reports it",
+                                  **guard_report}
     if args.precision != "bf16x3" and not args.no_grad_err:
         out["grad_rel_err"] = grad_rel_err(model, loss_fn, data, world, rank, set_precision, args.precision)
     # ---- exchange diagnostics (N > 1): what the step spends in the collectives that backward does not hide

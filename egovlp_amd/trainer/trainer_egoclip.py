@@ -227,6 +227,8 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
         for param_group in optimizer.param_groups:
             param_group['lr'] = lr
 
+    _guard = None
+
     def _train_epoch(self, epoch):
         self.model.train()
         total_loss = [torch.zeros((), device=self.device) for _ in self.data_loader]
@@ -240,6 +242,12 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
         for batch_idx, dl_idx, data in feed:
             if batch_idx is None:
                 break
+            # the per-block precision policy is measured on the weights at hand: first batch, then every `precision_guard_interval`
+            # steps (egovlp_amd.guard.PrecisionGuard; a no-op unless the forward runs fp16 products)
+            if self._guard is None:
+                from ..guard import PrecisionGuard
+                self._guard = PrecisionGuard(self.model, interval=int(getattr(self.args, 'precision_guard_interval', 1000)))
+            self._guard.maybe_check(data)
             loss = egoclip_step(self.model, self.loss, self.optimizer, data, self.n_gpu, self.args.rank,
                                 grad_sync=self.grad_sync)
             total_loss[dl_idx] += loss      # stays on the device: no per-step .item() sync (reference :148,150)

@@ -710,3 +710,62 @@ def test_other_baseline_configs_at_full_size_match_oracle_rows_and_their_halves(
     print("%s %s: rows vs oracle worst rel %.2e | halves text %.2e video %.2e | loss rel %.2e" % (name, mode, worst, r_ht, r_hv, r_l))
     # other tile counts: summation order only in bf16x3 (~2e-5); f16x2 has no batch-dependent rounding either
     assert r_ht < 1e-4 and r_hv < 1e-4 and r_l < fbar
+
+
+@pytest.mark.parametrize("dist", ["gauss", "heavy"])
+def test_precision_guard_measures_the_policy_and_demotes_it_on_hostile_weights(dist):
+    """The per-block single-product policy of 'f16mix' was tuned on Gaussian weights (round-5 verdict, weak #1 / advisor): on the
+    HOSTILE distribution (egovlp_amd.synth.heavy_tensor: log-normal channel scales, x30 outlier LayerNorm gains on three residual
+    channels that also carry a token-independent offset, x8 fc1 rows) the shipped policy measures ~1.0e-3 on the video embedding where
+    the fp32-grade modes stay at 4e-4.  egovlp_amd.guard.PrecisionGuard measures the policy against the all-bf16x3 forward of the same
+    batch ON THE DEVICE and demotes it rung by rung until it is inside its budget: on Gaussian weights nothing happens (4.7e-4 < 6e-4),
+    on the hostile ones the demotion fires -- and what is left in force meets the north-star bar against the fp32 CPU oracle, per batch
+    and per row, where the un-guarded policy does not.  Raises nothing, clips nothing silently (the demotion is logged)."""
+    from egovlp_amd.guard import PrecisionGuard
+    from egovlp_amd.model.model import FrozenInTime
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 4, "pretrained": True,
+                                   "time_init": "rand"},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"}, projection="minimal",
+                     load_checkpoint="")
+    sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=0, dist=dist)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    batch = synth_batch(4, T=4, L=32, seed=99, ragged=True)
+    dev = to_dev(batch)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        rt, rv = O.frozen_in_time(batch, sd, O.VideoCfg(num_frames=4), O.TextCfg())
+
+    def video_err():
+        m.eval()
+        with torch.no_grad():
+            _, ve = m(dev)
+        m.train()
+        return rel(ve, rv), max(rel(ve[i], rv[i]) for i in range(ve.shape[0]))
+
+    ec = m.exec_ctx
+    ec.set_precision("f16mix", "f16")
+    unguarded = video_err()
+    g = PrecisionGuard(m)
+    rep = g.check(dev)
+    guarded = video_err()
+    print("precision guard on %s weights: un-guarded policy %.2e (worst row %.2e) from the oracle; guard tried %s -> policy %s, %.2e (worst row %.2e)" % (
+        dist, unguarded[0], unguarded[1], [(str(t["policy"]), "%.2e" % t["err"]) for t in rep["tried"]], rep["policy"], guarded[0], guarded[1]))
+    assert rep["tried"][0]["policy"] == "auto" and all(t["finite"] for t in rep["tried"])
+    assert guarded[0] < 8e-4 and guarded[1] < PARITY                      # what is left in force holds the bar, rows included
+    if dist == "gauss":
+        assert not rep["demoted"] and rep["policy"] == "auto" and ec.precision_name() == ("f16mix", "f16")
+        assert unguarded[0] == guarded[0]
+    else:
+        assert rep["demoted"] and rep["policy"] != "auto" and len(rep["tried"]) >= 2
+        assert unguarded[1] > PARITY > guarded[1]                        # the demotion is what brings the rows back inside the bar
+        assert rep["tried"][-1]["err"] <= g.budget < rep["tried"][0]["err"]
+        assert ec.precision_name()[1] == "f16"                            # the backward precision is the caller's
+    # a second check keeps the rung (no flapping), and a training step runs in the policy left in force
+    again = g.check(dev)
+    assert again["policy"] == rep["policy"] and len(again["tried"]) == 1
+    from egovlp_amd.model.loss import EgoNCE
+    from egovlp_amd.optim import AdamW
+    from egovlp_amd.trainer.trainer_egoclip import egoclip_step
+    loss = egoclip_step(m, EgoNCE(), AdamW(m.parameters(), lr=3e-5), dev)
+    assert bool(torch.isfinite(loss))
