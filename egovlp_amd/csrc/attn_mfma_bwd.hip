@@ -310,6 +310,115 @@ __global__ __launch_bounds__(PASSES == 3 ? 1024 : 512) void attn_bwd_dq_stream_k
   }
 }
 
+// ---- streaming dQ for DistilBERT captions of 65 .. 288 tokens -------------------------------------------------------------------
+// The register-resident dQ kernel keeps P and dP of ALL keys of a 16-query tile in registers: 112 / 144 fp32 at 14 / 18 key fragments
+// -- the three-product instances spilled 33 / 113 VGPRs (round-5 verdict, weak #7: never hit by the 32-token benchmark, but the
+// reference's tokenizer pads to the longest caption of a batch, trainer/trainer_egoclip.py:115-117).  The text attention has no saved
+// output planes to take delta = rowsum(dO o O) from, so this kernel walks the keys TWICE: pass 1 accumulates delta = sum_k P dP, pass 2
+// recomputes P and dP chunk by chunk and contracts dS = P o (dP - delta) with K.  Twice the score MFMAs of a kernel nobody waits for,
+// and nothing but the dQ accumulators live across a chunk.
+template <int NKF, int PASSES>
+__global__ __launch_bounds__(512) void attn_bwd_dq_text_stream_kernel(const AttGeom g, const AttGrad gr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKP = NKF * 16;
+  constexpr int PLANE = NKP * ATT_ROW_BYTES;
+  char* k_hi = smem;
+  char* v_hi = smem + PLANE;
+  char* k_lo = (PASSES == 3) ? smem + 2 * PLANE : nullptr;
+  char* v_lo = (PASSES == 3) ? smem + 3 * PLANE : nullptr;
+  float* kbias = (float*)(smem + ((PASSES == 3) ? 4 : 2) * PLANE);
+
+  const AttGroup<MODE_TEXT> grp(g, blockIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long hoff = (long)grp.h * ATT_D;
+  att_stage(k_hi, k_lo, g.nk, NKP, 1.0f, [&](int r) { return g.k + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  att_stage(v_hi, v_lo, g.nk, NKP, 1.0f, [&](int r) { return g.v + grp.k_tok(g, r) * g.tok_stride + hoff; });
+  for (int j = threadIdx.x; j < NKP; j += blockDim.x)
+    kbias[j] = (j < g.nk && g.mask[(long)grp.b * g.S + j] != 0) ? 0.f : -1e30f;
+  __syncthreads();
+
+  const int gq = lane >> 4;
+  const int ntiles = (g.nq + 15) / 16;
+  const EgvDrop dr = egv_drop_resolve(g.drop);
+  for (int qt = wave; qt < ntiles; qt += (int)(blockDim.x >> 6)) {
+    const int qi = qt * 16 + (lane & 15);
+    const long tok = grp.q_tok(g, min(qi, g.nq - 1));
+    bf16x8_t qh[2], ql[2], gh[2], gl[2];
+    const float* qrow = g.q + tok * g.tok_stride + hoff;
+    const float* grow = gr.d_out + tok * gr.do_stride + hoff;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      att_gfrag(qrow, ks, lane, 1.0f, qh[ks], ql[ks]);
+      att_gfrag(grow, ks, lane, 1.0f, gh[ks], gl[ks]);
+    }
+    const long lrow = ((long)grp.b * g.H + grp.h) * g.S + (tok - grp.tok0);
+    const float L = gr.lse[lrow];
+    const uint64_t rowbase = (((uint64_t)grp.b * g.H + grp.h) * g.S + (uint64_t)min(qi, g.nq - 1)) * g.S;
+    // P and dP of key fragment kf for this lane's four keys (rows 4 gq .. + 3 of the fragment), dropout mask applied to dP
+    auto p_dp = [&](int kf, f32x4_t& pr, f32x4_t& d) {
+      f32x4_t sc = {0.f, 0.f, 0.f, 0.f};
+      d = sc;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
+        bf16x8_t al = ah;
+        if (PASSES == 3) al = att_frag_cols(k_lo, kf * 16, ks, lane);
+        sc = att_mma<PASSES>(ah, al, qh[ks], ql[ks], sc);
+        const bf16x8_t bh = att_frag_cols(v_hi, kf * 16, ks, lane);
+        bf16x8_t bl = bh;
+        if (PASSES == 3) bl = att_frag_cols(v_lo, kf * 16, ks, lane);
+        d = att_mma<PASSES>(bh, bl, gh[ks], gl[ks], d);
+      }
+      const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = __expf(sc[r] * 0.125f + kb[r] - L);
+        if (g.drop.thresh != 0u) d[r] *= egv_drop_scale(dr, rowbase + kf * 16 + 4 * gq + r);      // dP = (dO . V) o M'
+      }
+    };
+    float delta = 0.f;
+#pragma unroll 1
+    for (int kf = 0; kf < NKF; ++kf) {
+      f32x4_t pr, d;
+      p_dp(kf, pr, d);
+      delta += pr[0] * d[0] + pr[1] * d[1] + pr[2] * d[2] + pr[3] * d[3];
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+
+    f32x4_t dq[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) dq[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < NKF / 2; ++c) {
+      float dsv[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4_t pr, d;
+        p_dp(2 * c + h, pr, d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsv[4 * h + r] = pr[r] * (d[r] - delta);
+      }
+      bf16x8_t sh, sl;
+      att_split8(dsv, sh, sl);
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const bf16x8_t kh = att_frag_rows(k_hi, 32 * c, df * 16, lane);
+        bf16x8_t kl = kh;
+        if (PASSES == 3) kl = att_frag_rows(k_lo, 32 * c, df * 16, lane);
+        dq[df] = att_mma<PASSES>(kh, kl, sh, sl, dq[df]);
+      }
+    }
+    if (qi < g.nq) {
+      float* out = gr.dq + tok * gr.tok_stride + hoff;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) *(f32x4_t*)(out + df * 16 + 4 * gq) = dq[df] * 0.125f;
+      if (gq == 0) gr.delta[lrow] = delta;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------- dKV
 template <int MODE, int NQF, int PASSES, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const AttGeom g, const AttGrad gr) {
@@ -499,6 +608,26 @@ int launch_bwd(const AttGeom& g, const AttGrad& gr, int ngroups, int passes, hip
       EGV_CHECK_LAUNCH();
       return EGV_OK;
     }
+  } else if constexpr (MODE == MODE_TEXT && (NF == 14 || NF == 18)) {     // captions of 65 .. 288 tokens: two-pass streaming dQ, then dK / dV
+    if (passes == 3) {
+      auto k1 = attn_bwd_dq_text_stream_kernel<NF, 3>;
+      auto k2 = attn_bwd_dkv_kernel<MODE, NF, 3>;
+      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EGV_LAUNCH(k1, dim3(ngroups), dim3(512), lds, s, g, gr);
+      EGV_CHECK_LAUNCH();
+      EGV_LAUNCH(k2, dim3(ngroups), dim3(256), lds, s, g, gr);
+    } else {
+      auto k1 = attn_bwd_dq_text_stream_kernel<NF, 1>;
+      auto k2 = attn_bwd_dkv_kernel<MODE, NF, 1>;
+      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EGV_LAUNCH(k1, dim3(ngroups), dim3(512), lds, s, g, gr);
+      EGV_CHECK_LAUNCH();
+      EGV_LAUNCH(k2, dim3(ngroups), dim3(512), lds, s, g, gr);
+    }
+    EGV_CHECK_LAUNCH();
+    return EGV_OK;
   } else {        // (else-branch of the if constexpr: the register-resident dQ kernel is not even instantiated for the streamed sizes)
   if (passes == 3) {
     auto k1 = attn_bwd_dq_kernel<MODE, NF, 3>;

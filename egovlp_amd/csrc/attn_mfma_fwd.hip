@@ -307,7 +307,17 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
       EGV_CHECK_LAUNCH();
       return EGV_OK;
     }
-  }
+    // a three-pass space forward of these sizes ALWAYS runs the streaming kernel (a missing second plane is an argument error): the
+    // register-resident attn_fwd_kernel<0, 14, 3> spills and is not instantiated for them
+    if (passes == 3) return EGV_ERR_ARG;
+    {
+      auto kern = attn_fwd_kernel<MODE, NKF, 1>;
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      EGV_LAUNCH(kern, dim3(ngroups), dim3(512), lds, s, g, oh, nullptr, ostride, lse, cls_ws);
+      EGV_CHECK_LAUNCH();
+      return EGV_OK;
+    }
+  } else {
   if (MODE == MODE_SPACE && g.f16) {
     if (passes != 3) return EGV_ERR_ARG;              // the fp16 forward is the three-product one
     if constexpr (MODE == MODE_SPACE) {
@@ -329,6 +339,7 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
   }
   EGV_CHECK_LAUNCH();
   return EGV_OK;
+  }
 }
 
 }  // namespace

@@ -87,7 +87,8 @@ def egoclip_step(model, loss_fn, optimizer, data, world_size=1, rank=0, fused_he
     loss scale before backward() and the optimizer un-scales, or skips the step after an overflow -- no host synchronisation."""
     ec0 = getattr(getattr(model, 'module', model), 'exec_ctx', None)
     if scaler is None and ec0 is not None and ec0.bwd_passes == 4:
-        scaler = ec0.loss_scaler()      # fp16 gradient planes flush un-scaled gradients of 1e-6 to zero: the model's own scaler
+        # fp16 gradient planes flush un-scaled gradients of 1e-6 to zero: the model's own scaler (on the device its parameters live on)
+        scaler = ec0.loss_scaler(device=next(getattr(model, 'module', model).parameters()).device)
     optimizer.zero_grad(set_to_none=True)
     text_embeds, video_embeds = model(data)
     n_embeds, v_embeds = data['noun_vec'], data['verb_vec']

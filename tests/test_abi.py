@@ -127,3 +127,29 @@ def test_small_gemm_splitk_policy():
             for K in (256, 768, 3072):
                 ks = ops.auto_ksplit_nt(M, N, K)
                 assert 1 <= ks <= 4 and (ks == 1 or (K // 32) // ks >= 6 or (K // 32) // 6 >= ks)
+
+
+def test_abi_version_handshake():
+    """A binding written against another header must fail at LOAD time (round-5 advisor: the ABI grew -- a trailing struct field, new
+    passes / mode codes -- with nothing a stale caller could trip over): egv_abi_check compares the caller's EGV_ABI_VERSION and struct
+    sizes with the library's; egovlp_amd._lib.lib() refuses a mismatch."""
+    from egovlp_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libegovlp_hip.so not built (run __graft_entry__.build())")
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    h.egv_abi_check.argtypes = [ctypes.c_int32] + [ctypes.c_int64] * 4
+    h.egv_abi_check.restype = ctypes.c_int32
+    sizes = [ctypes.sizeof(c) for c in (_lib.GemmDesc, _lib.BlockGeom, _lib.BlockParams, _lib.BlockBwdIO)]
+    txt = open(os.path.join(ROOT, "include", "egovlp_hip.h")).read()
+    assert int(re.search(r"#define EGV_ABI_VERSION (\d+)", txt).group(1)) == _lib.ABI_VERSION == h.egv_version()
+    assert h.egv_abi_check(_lib.ABI_VERSION, *sizes) == 0
+    assert h.egv_abi_check(_lib.ABI_VERSION - 1, *sizes) == 1                   # an older binding
+    assert h.egv_abi_check(_lib.ABI_VERSION, sizes[0] - 8, *sizes[1:]) == 1     # a caller whose egv_gemm_desc lacks the last field
+    assert h.egv_abi_check(_lib.ABI_VERSION, sizes[0], sizes[1] - 4, *sizes[2:]) == 1
+    saved, saved_ver = _lib._lib, _lib.ABI_VERSION
+    try:
+        _lib._lib, _lib.ABI_VERSION = None, saved_ver + 1
+        with pytest.raises(_lib.EgovlpHipError, match="ABI mismatch"):
+            _lib.lib()
+    finally:
+        _lib._lib, _lib.ABI_VERSION = saved, saved_ver

@@ -54,8 +54,8 @@ def test_full_step_wiring_and_launch_census(model):
     assert c["egv_divided_attn_fwd"] == 24 and c["egv_divided_attn_bwd"] == 24
     assert c["egv_text_attn_fwd"] == 6 and c["egv_text_attn_bwd"] == 6
     assert c["egv_egonce_fwd_bwd"] == 1 and c["egv_adamw_multi"] >= 1
-    assert c["egv_layernorm_fwd"] == 12 * 3 + 1 + 6 * 2 + 1 and c["egv_layernorm_bwd"] == c["egv_layernorm_fwd"]
-    assert c["egv_split_f32_multi"] == 1          # ONE weight-plane refresh per step for both towers (shared context)
+    assert c["egv_layernorm_fwd"] == 12 * 3 + 1 + 6 * 2 + 1 and c["egv_layernorm_bwd_fmt"] == c["egv_layernorm_fwd"]
+    assert c["egv_split_f32_multi_t16"] == 1          # ONE weight-plane refresh per step for both towers (shared context)
     # GEMM calls: 12 video blocks x (6 forward + 6 dgrad + 6 wgrad), patch embed (forward + wgrad), 6 DistilBERT layers x
     # (4 forward + 4 dgrad + 4 wgrad; q/k/v fused), two projections x (forward + dgrad + wgrad)
     assert c["egv_gemm_nt"] == 12 * 18 + 2 + 6 * 12 + 2 * 3, c["egv_gemm_nt"]
@@ -256,19 +256,24 @@ def test_block_parameter_structs_follow_the_weight_planes(model):
     assert other.exec_ctx.wc.param_structs is not ec.wc.param_structs and not other.exec_ctx.wc.param_structs
 
 
-def test_f16x2_mode_wiring(model):
-    """Precision 'f16x2' (two-fp16-product forward of the video blocks' qkv / fc1 / fc2 Linears, single-pass bf16 backward) through the
-    host code: the block calls carry fwd_passes = 2, the weights of those Linears are refreshed with ONE f16x2 multi-encode per step
-    (second-operand role) next to the split-bf16 refresh of everything else, every parameter receives a gradient."""
+@pytest.mark.parametrize("bwd", ["f16", "bf16"])
+def test_f16x2_mode_wiring(model, bwd):
+    """Precision 'f16x2' (two-fp16-product forward of the video blocks' qkv / fc1 / fc2 Linears) through the host code, with both
+    backwards it pairs with -- 'f16' (the default: fp16 operands under the model's device-side loss scale, created by egoclip_step) and
+    round 5's single-pass 'bf16': the block calls carry fwd_passes = 2 and the backward's passes code, the weights of those Linears are
+    refreshed with ONE f16x2 multi-encode per step (second-operand role) next to the one split launch of everything else (which also
+    writes the fp16 W^T planes of the fp16 backward), the loss-scale kernels run once per step, every parameter receives a gradient."""
     from egovlp_amd.model.loss import EgoNCE
     from egovlp_amd.optim import AdamW
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
     opt = AdamW(model.parameters(), lr=3e-5)
     ec = model.exec_ctx
+    ec.wc.clear()
     with mock_hip() as calls:
-        ec.set_precision("f16x2")
+        ec.set_precision("f16x2") if bwd == "f16" else ec.set_precision("f16x2", "bf16")
         try:
-            assert ec.precision_name() == ("f16x2", "bf16") and ec.fwd_passes == 2 and ec.fwd_passes_split == 3
+            assert ec.precision_name() == ("f16x2", bwd) and ec.fwd_passes == 2 and ec.fwd_passes_split == 3
+            assert ec.bwd_passes == (4 if bwd == "f16" else 1) and ec.bwd_passes_split == (3 if bwd == "f16" else 1)
             for p in model.parameters():
                 p.grad = None
             egoclip_step(model, EgoNCE(), opt, _batch(B=8, T=4), 1, 0)
@@ -282,12 +287,21 @@ def test_f16x2_mode_wiring(model):
             ent_proj = ec.wc._c[id(model.video_model.blocks[0].attn.proj.weight)]
         finally:
             ec.unset("fwd_passes", "bwd_passes")
-    assert c["egv_block_fwd"] == 12 and c["egv_block_bwd"] == 12 and c["egv_f16x2_encode_multi"] == 1 and c["egv_split_f32_multi"] == 1
+    assert c["egv_block_fwd"] == 12 and c["egv_block_bwd"] == 12 and c["egv_f16x2_encode_multi"] == 1 and c["egv_split_f32_multi_t16"] == 1
     assert ok
-    assert ent.p2 is not None and ent.p2.fmt == "f16x2" and ent.tp is not None        # forward planes f16x2, dgrad planes split-bf16
-    assert ent_proj.pl is not None and ent_proj.p2 is None                            # the proj Linears stay split-bf16
+    assert ent.p2 is not None and ent.p2.fmt == "f16x2"                               # forward planes f16x2 ...
+    if bwd == "f16":
+        assert ent.t16 is not None and ent.t16.fmt == "f16" and ent.tp is None and ent.pl is None      # ... dgrad plane: ONE fp16 W^T plane, nothing bf16
+        assert ent_proj.p2 is not None and ent_proj.pl is None                        # the proj Linears run two fp16 products as well
+        assert c["egv_grad_nonfinite_multi"] == 1 and c["egv_loss_scale_update"] == 1 and ec._scaler is not None
+    else:
+        assert ent.tp is not None and ent.t16 is None                                 # ... dgrad planes split-bf16
+        assert ent_proj.pl is not None and ent_proj.p2 is None                        # the proj Linears stay split-bf16
+        assert c["egv_grad_nonfinite_multi"] == 0 and c["egv_loss_scale_update"] == 0
     with pytest.raises(ValueError):
         ec.set_precision("f16x2", "bf16x3")
+    with pytest.raises(ValueError):
+        ec.set_precision("bf16x3", "f16")               # the fp16 backward reads the fp16 forward's planes
 
 
 def test_f16mix_mode_wiring(model):
@@ -315,6 +329,6 @@ def test_f16mix_mode_wiring(model):
                 seen[name] = (list(calls.block_single), ec.precision_name())
         finally:
             ec.unset("fwd_passes", "bwd_passes", "f16_single")
-    assert seen["f16mix"] == ([0, 0, 0] + [7] * 3 + [15] * 6, ("f16mix", "bf16")), seen["f16mix"]
-    assert seen["policy"] == ([2] * 6 + [3] * 6, ("f16mix", "bf16")), seen["policy"]
-    assert seen["f16x2"] == ([0] * 12, ("f16x2", "bf16")), seen["f16x2"]
+    assert seen["f16mix"] == ([0, 0, 0] + [7] * 3 + [15] * 6, ("f16mix", "f16")), seen["f16mix"]
+    assert seen["policy"] == ([2] * 6 + [3] * 6, ("f16mix", "f16")), seen["policy"]
+    assert seen["f16x2"] == ([0] * 12, ("f16x2", "f16")), seen["f16x2"]
