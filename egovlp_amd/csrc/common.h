@@ -140,7 +140,7 @@ struct EgvDrop {
   float scale;               // 1 / (1 - p); 0 threshold and scale 1 when p == 0
   const uint32_t* dev;       // optional DEVICE seed words {lo, hi}, XOR-ed into (s0, s1) by the kernel: a step captured into a
                              // HIP graph keeps its host-side seed as a launch argument forever, so what changes from replay to
-                             // replay has to live in memory the graph reads (egovlp_amd/graph.py GraphedTrainStep)
+                             // replay has to live in memory the graph reads (a caller that captures a training step; none in this package)
 };
 __device__ __forceinline__ EgvDrop egv_drop_resolve(EgvDrop d) {   // once per kernel, before the first egv_drop_scale
   if (d.dev) {

@@ -115,6 +115,11 @@ class PrecisionGuard:
                 self.rung += 1
         finally:
             self.model.train(was_training)
+            # the measurement built operand planes of formats the training step does not use (split-bf16 planes of every video weight for
+            # the reference forward, planes of the rungs tried): a cache entry refreshes everything it owns after every optimizer step, so
+            # drop them all -- the next forward rebuilds exactly what the policy in force needs
+            ec.join_side_stream()
+            ec.wc.clear()
         # data-parallel ranks keep the same kernels: everyone takes the most conservative rung any rank chose
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             t = torch.tensor([self.rung], device=video.device, dtype=torch.int32)

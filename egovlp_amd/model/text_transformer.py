@@ -354,9 +354,11 @@ class DistilBertModel(nn.Module):
         self.transformer = Transformer(self.config)
         self.exec_ctx = ops.new_context()     # FrozenInTime replaces it with the dual encoder's shared context
         self.seed_rank = 0                    # mixed into the dropout seeds: data-parallel ranks must not draw the same masks
-        # HIP-graph replay of the training step (egovlp_amd/graph.py): a device int64[1] whose value is XOR-ed into every
-        # dropout seed by the kernels, and the host-side call counter stops advancing -- what changes from replay to replay
-        # must live in device memory, launch arguments are frozen at capture
+        # Capture-safe dropout seeds (part of the C ABI: `seed_dev` of egv_dropout / egv_text_attn_* / egv_text_geom): a device int64[1]
+        # whose value is XOR-ed into every dropout seed by the kernels; when set, the host-side call counter stops advancing -- a caller
+        # that replays a captured training step from a HIP graph changes the masks by writing this word, launch arguments being frozen
+        # at capture.  Nothing in the package sets it since the graphed train step was retired in round 5 (eager is faster on ROCm 7.2,
+        # DESIGN 6); egovlp_amd/graph.py::GraphedForward captures evaluation forwards, which draw no masks.
         self.seed_device = None
         # HF init (initializer_range 0.02) so random-init statistics match `DistilBertModel(DistilBertConfig())`
         for m in self.modules():

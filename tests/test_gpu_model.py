@@ -610,7 +610,10 @@ def test_padded_patch_embedding_gradient_with_the_wgrad_side_stream():
                                   "config": dict(vocab_size=30522, dim=768, n_layers=1, n_heads=12, hidden_dim=3072)},
                      projection="minimal", load_checkpoint="").cuda().train()
     m.text_model.set_dropout(0.0, 0.0)
-    m.exec_ctx.set_precision("bf16x3", "bf16")
+    # the all-bf16x3 backward: no bf16 rounding sits behind the CLS rows' fp32 atomics, so the two runs agree to the atomics' own ~1e-6 and
+    # the bar can be TIGHT (round-5 advisor: with a single-pass backward one bf16 flip was worth 4e-4 and the bar had been loosened to
+    # 2e-3, which a partial race -- a few stale rows -- could have hidden under); the stream policy under test is the same in every mode
+    m.exec_ctx.set_precision("bf16x3", "bf16x3")
     batch = to_dev(synth_batch(4, T=4, L=16, seed=5))
     w = m.video_model.patch_embed.proj.weight
 
@@ -626,11 +629,12 @@ def test_padded_patch_embedding_gradient_with_the_wgrad_side_stream():
     ref = grad(False)
     assert float(ref.abs().max()) > 0
     for _ in range(3):
-        r = rel(grad(True), ref)
-        # same kernels, same inputs: what differs is the order of the fp32 atomics of the CLS rows -- one bf16 flip of the single-pass
-        # backward behind them is worth up to 4e-4 on this one-block model (seen once in ~10 runs); the race this test guards against
-        # made the gradient 100 % wrong
-        assert r < 2e-3, r
+        got = grad(True)
+        r = rel(got, ref)
+        worst = float((got - ref).abs().max() / ref.abs().max())
+        # same kernels, same inputs: what differs is the order of the fp32 atomics of the CLS rows; the race this test guards against made
+        # the gradient 100 % wrong, a partial one (stale rows) would show in the max-abs element error
+        assert r < 1e-4 and worst < 1e-3, (r, worst)
 
 
 def test_retrieval_heads_match_the_reference_golden(full, golden_dir):
