@@ -214,6 +214,57 @@ def trajectory_drift(model, loss_fn, make_opt, steps=20, B=8, T=4, L=32, modes=(
     return out
 
 
+def measure_gemm_traffic(args, timeout_s=240):
+    """roofline.traffic, measured in THIS run: two child runs of this script (2 timed steps, every secondary leg off, same precision /
+    size) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- separate passes, as the counters do not fit one
+    and as MI355X_MICROARCH.md prescribes; never combined with sys / hip traces -- and the mean over every gemm_big_kernel launch of
+    bytes = 2048 x FETCH_SIZE[KiB] + 1024 x WRITE_SIZE[KiB]: the guide's gfx950 correction (a reported FETCH KiB stands for 2048 bytes of
+    a wide coalesced read), confirmed on this kernel's own load / store paths by a 1 GiB calibration copy
+    (profiles/r03_traffic_calibration.json, tools/traffic_calib.py).  Infinity-Cache hits are counted: fabric traffic, an upper bound of
+    DRAM traffic.  -> (dict | None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found on this box"
+    raw = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="egv_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--batch", str(args.batch), "--frames", str(args.frames), "--arch", args.arch,
+               "--precision", args.precision, "--no-cpu-baseline", "--no-kernel-timing", "--no-fast-mode", "--no-trajectory", "--no-h2d-leg",
+               "--no-dp-leg", "--no-grad-err", "--no-guard", "--no-traffic"]
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"the rocprofv3 --pmc {counter} pass did not finish in {timeout_s} s"
+        files = glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"the rocprofv3 --pmc {counter} pass failed (exit {p.returncode}): {(p.stderr or '')[-200:]}"
+        tot, n = 0.0, 0
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") == counter and "gemm_big_kernel" in r.get("Kernel_Name", ""):
+                    tot += float(r["Counter_Value"])
+                    n += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if n == 0:
+            return None, f"no gemm_big_kernel launches in the --pmc {counter} pass"
+        raw[counter] = (tot / n, n)
+    f_kib, w_kib = raw["FETCH_SIZE"][0], raw["WRITE_SIZE"][0]
+    return {"hbm_bytes_per_launch": round((2.0 * f_kib + w_kib) * 1024.0), "fetch_kib_raw": round(f_kib, 1), "write_kib_raw": round(w_kib, 1),
+            "launches_counted": [raw["FETCH_SIZE"][1], raw["WRITE_SIZE"][1]],
+            "how": "this run: two child runs of this command (2 timed steps) under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+                   "(separate passes); mean over all gemm_big_kernel launches of 2048 x FETCH_SIZE[KiB] + 1024 x WRITE_SIZE[KiB] (gfx950 "
+                   "correction of MI355X_MICROARCH.md, calibrated in profiles/r03_traffic_calibration.json); Infinity-Cache hits included "
+                   "(fabric traffic)"}, None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script on this node with
     torch.distributed.run (one process per GPU, RCCL rendezvous on 127.0.0.1) and return its exit code.  Fails loudly, before
@@ -274,6 +325,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-dp-leg", action="store_true", help="skip the secondary leg that runs the N > 1 step policy (process group, RCCL "
                     "gather, hook-free gradient exchange, ONE wgrad stream, 248-workgroup GEMM grid) at world size 1")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic (N = 1 only)")
     ap.add_argument("--no-guard", action="store_true", help="skip the precision guard's measurement of the per-block policy before the timed steps")
     ap.add_argument("--no-grad-err", action="store_true", help="skip grad_rel_err (two extra backward passes; A/B timing runs)")
     ap.add_argument("--no-trajectory", action="store_true", help="skip the 20-step loss / parameter drift comparison of the "
@@ -470,8 +522,19 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             traffic_ref = {"from": "profiles/gemm_traffic.json (separate rocprofv3 --pmc passes of this command on a builder box): "
-                                   + str(tj.get("source")), "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")}
+                                   + str(tj.get("source")), "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch"),
+                           "measured_at_commit": tj.get("measured_at_commit"), "precision": tj.get("precision")}
+        # algorithmic bytes of a launch (SURVEY 8(d)'s accounting: each operand and the result once, 16 bits per element), mean over the step's launches
+        import re as _re
+        alg_bytes = 0.0
+        for k_, v_ in big.items():
+            mm = _re.search(r"M=(\d+) N=(\d+) K=(\d+)", k_)
+            if mm:
+                m_, n_, kk_ = (int(x) for x in mm.groups())
+                alg_bytes += v_["launches"] * 2.0 * (m_ * kk_ + n_ * kk_ + m_ * n_)
+        alg_bytes_per_launch = alg_bytes / max(g["launches"], 1)
         roof = {"bound": "mfma", "kernel": "gemm_big_kernel (every launch of the step: NT forward / dgrad, TN wgrad incl. its split-K reduce)",
+                "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_reference": traffic_ref,
                 "launches_per_step": g["launches"] // 2,
@@ -486,7 +549,8 @@ def main():
                 "note": "achieved = algorithmic 2*M*N*K of the gemm_big launches of a step / their summed HIP-event time "
                         "(events on the launch stream around each C-ABI call); bf16x3 launches issue 3 MFMA passes per "
                         "algorithmic product (mfma_issue_tflops counts them); traffic = (FETCH_SIZE x 2 + WRITE_SIZE) per "
-                        "launch can only come from separate rocprofv3 --pmc passes: null here, the committed summary is quoted in traffic_reference"}
+                        "launch comes from two rocprofv3 --pmc child runs of this command at the end of THIS run (traffic_measurement; "
+                        "traffic_missing_because says why not, and traffic_reference quotes the committed summary of an earlier run)"}
     key = (args.arch, T)
     step_frac = None
     if key in FWD_GFLOP_PER_PAIR:
@@ -679,6 +743,22 @@ def main():
             _libc.fflush(None)
             os.dup2(saved_fd1, 1)
             os.close(saved_fd1)
+    # roofline.traffic of THIS run (N = 1): PMC counters need their own profiler passes, so two short child runs of this command
+    if rank == 0 and world == 1 and not args.no_traffic and out.get("roofline") is not None:
+        try:
+            torch.cuda.empty_cache()              # the children allocate their own ~40 GB next to this process
+            tr, why = measure_gemm_traffic(args)
+        except Exception as e:                    # a secondary leg must never cost the line
+            tr, why = None, f"{type(e).__name__}: {e}"[:200]
+        if tr is not None:
+            out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_unit"] = "bytes per gemm_big_kernel launch (fabric: HBM + Infinity-Cache hits)"
+            out["roofline"]["traffic_measurement"] = tr
+            alg = out["roofline"].get("algorithmic_bytes_per_launch")
+            if alg:
+                out["roofline"]["traffic_over_algorithmic"] = round(tr["hbm_bytes_per_launch"] / alg, 2)
+        else:
+            out["roofline"]["traffic_missing_because"] = why
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     _libc.fflush(None)        # anything native code buffered on stdout (RCCL's banner at N > 1) goes out BEFORE the line
