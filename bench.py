@@ -562,16 +562,21 @@ def main():
                   f"clip-pairs/sec (whole node), {T}f/224^2 {args.arch} + 32-tok text, B={B}/GPU, train step (fwd+gather+EgoNCE+bwd+AdamW)",
         "value": round(pairs, 2), "unit": "clip-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f16mix": "fp16 (forward Linears of the video blocks) + bf16 (attention, early proj, text tower, backward) MFMA operands, fp32 accumulate",
-                  "f16x2": "fp16 (forward Linears of the video blocks) + bf16 (attention, proj, text tower, backward) MFMA operands, fp32 accumulate"
-                  }.get(ec.precision_name()[0], "bf16"), "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
+        "dtype": ("fp16 (every Linear and both attentions of the video blocks, forward and backward) + bf16 (patch embedding, text tower, heads) MFMA "
+                  "operands, fp32 accumulate" if ec.precision_name()[1] == "f16" else
+                  {"f16mix": "fp16 (forward Linears of the video blocks) + bf16 (attention, early proj, text tower, backward) MFMA operands, fp32 accumulate",
+                   "f16x2": "fp16 (forward Linears of the video blocks) + bf16 (attention, proj, text tower, backward) MFMA operands, fp32 accumulate"
+                   }.get(ec.precision_name()[0], "bf16")), "data": "synthetic (random frames/tokens/noun-verb vectors, random-init weights)",
         "config": {"workload": f"EgoClip step: {T}x3x224x224 frames + {L}-tok text, {args.arch} + DistilBERT, EgoNCE, "
                                f"B={B}/GPU, global batch {B * world}", "global_batch": B * world,
                    "parallelism": f"dp{world}", "precision": "/".join(ec.precision_name()),
                    "mfma_products": "forward: " + {"f16mix": "per-block precision policy k = " + json.dumps(ec.f16_single_policy(len(model.video_model.blocks)))
                                                              + " (profiles/r05_precision_table.txt): qkv / fc1 / fc2 of the video blocks 2 x fp16 MFMA (f16x2 "
-                                                             "operands) in blocks [0, k), 1 x fp16 MFMA in blocks [k, depth); proj 3 x bf16 MFMA in blocks "
-                                                             "[0, k_proj), 1 x fp16 MFMA behind; attention / patch embedding / text tower / heads 3 x bf16 MFMA",
+                                                             "operands) in blocks [0, k), 1 x fp16 MFMA in blocks [k, depth); proj "
+                                                             + ("2 x fp16" if ec.precision_name()[1] == "f16" else "3 x bf16") + " MFMA in blocks "
+                                                             "[0, k_proj), 1 x fp16 MFMA behind; attention 3 x "
+                                                             + ("fp16 (fp16-split qkv planes)" if ec.precision_name()[1] == "f16" else "bf16")
+                                                             + " MFMA; patch embedding / text tower / heads 3 x bf16 MFMA",
                                                    "f16x2": "qkv / fc1 / fc2 of the video blocks 2 x fp16 MFMA (f16x2 operands), proj / attention / "
                                                             "text tower / heads 3 x bf16 MFMA",
                                                    "bf16x3": "3 x bf16 MFMA per product", "bf16": "1 x bf16 MFMA per product"}[ec.precision_name()[0]]

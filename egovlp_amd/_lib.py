@@ -128,6 +128,7 @@ PROTOTYPES = {
     "egv_layernorm_bwd_fmt": (i32, [c_p, c_p, c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, i32, c_p, c_p, c_p, c_p]),
     "egv_layernorm_bwd_partial": (i32, [c_p, c_p, c_p, i64, c_p, i64, c_p, c_p, c_p, i32, i32, c_p, c_p, c_p, i64, c_p, c_p, i32, c_p, c_p, c_p, c_p]),
     "egv_layernorm_bwd_reduce": (i32, [i32, c_p, i32, i32, c_p, c_p, c_p]),
+    "egv_splitk_reduce_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "egv_grad_nonfinite_multi": (i32, [i32, c_p, c_p, c_p, c_p]),
     "egv_loss_scale_update": (i32, [c_p, c_p, f32, f32, f32, i32, i32, f32, f32, i32, f32, i32, c_p]),
     "egv_split_f32_multi": (i32, [i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -343,6 +343,14 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   const float *tr = at<float>(FA, F.tr), *sr = at<float>(FA, F.sr);
   float* grads = io.grads;
 
+  // The split-K slabs of the six weight gradients are reduced by ONE launch at the end of the call (egv_splitk_reduce_multi) when all
+  // six run on the same stream -- the single wgrad side stream, or the main stream --: 12 reduce launches per step instead of 72 on
+  // the stream whose queue drains last.  Weight gradients dealt to different streams keep their own reduce.
+  bool defer_reduce = true;
+  for (int i = 1; i < 6; ++i) defer_reduce = defer_reduce && io.side_stream[i] == io.side_stream[0];
+#ifdef EGV_NO_MULTI_REDUCE
+  defer_reduce = false;
+#endif
   // the weight gradient dW[N,K] = dY^T X (TN kernel, bias gradient from the same pass) of weight i, on its side stream if it has one
   auto wgrad = [&](int i, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy, const egv_bf16* x_hi, const egv_bf16* x_lo,
                    int64_t ldx) -> int {
@@ -365,6 +373,7 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
     d.trans = 1;
     d.colsum = grads + goff[6 + i];
     d.grid_cap = g.grid_cap;
+    if (defer_reduce && d.ksplit > 1) d.accumulate = 2;        // slabs only; reduced below
     return egv_gemm_nt(&d, s);
   };
 
@@ -443,6 +452,20 @@ extern "C" int egv_block_bwd(const egv_block_geom* gp, const egv_block_params* p
   EGV_TRY(egv_layernorm_bwd_partial(d_n3, nullptr, nullptr, D, io.x, D, p.n3w, at<float>(FA, F.mean3), at<float>(FA, F.rstd3), M, D, d_tr, d_sr,
                             io.d_x, D, io.dx_hi, Pb == 3 ? io.dx_lo : nullptr, h16 ? 1 : 0, grads + goff[12], grads + goff[13],
                             at<float>(A, L.ln_work[2]), stream));
+  if (defer_reduce) {
+    const float* part[6]; float* outp[6]; float* csp[6]; int64_t mn[6]; int32_t ksv[6], mv[6];
+    int cnt = 0;
+    for (int i = 0; i < 6; ++i) {
+      if (io.wgrad_ksplit[i] <= 1) continue;
+      int64_t N, K;
+      wshape(o, i, N, K);
+      part[cnt] = at<float>(A, L.partial[i]); outp[cnt] = grads + goff[i]; csp[cnt] = grads + goff[6 + i];
+      mn[cnt] = N * K; ksv[cnt] = io.wgrad_ksplit[i]; mv[cnt] = (int32_t)N;
+      ++cnt;
+    }
+    // on the stream the weight gradients ran on (stream order: behind the last of them)
+    if (cnt) EGV_TRY(egv_splitk_reduce_multi(cnt, part, outp, mn, ksv, csp, mv, io.side_stream[0] ? io.side_stream[0] : stream));
+  }
   // the affine gradients of the three LayerNorms: their per-block partial sums are reduced by ONE launch (three before)
   {
     const float* w3[3] = {at<float>(A, L.ln_work[0]), at<float>(A, L.ln_work[1]), at<float>(A, L.ln_work[2])};

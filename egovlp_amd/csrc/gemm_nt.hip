@@ -216,7 +216,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   egv_store<EGV_NT_WGRAD>(out + i4, s);
 }
 
+// The same reduction for SEVERAL weight gradients in one launch (egv_splitk_reduce_multi): the six TN GEMMs of a SpaceTimeBlock backward
+// leave their slabs un-reduced (egv_gemm_desc.accumulate == 2) and the block call finishes them together -- 12 reduce launches per
+// step on the wgrad stream instead of 72.
+constexpr int RED_MAX_T = 8;
+struct ReduceTable {
+  const float* partial[RED_MAX_T];
+  float* out[RED_MAX_T];
+  float* colsum[RED_MAX_T];
+  long mn[RED_MAX_T];
+  int m[RED_MAX_T], ks[RED_MAX_T];
+  int blk_start[RED_MAX_T + 1];     // first block of entry i (its product slab blocks, then its column-sum blocks)
+  int blocks1[RED_MAX_T];           // product-slab blocks of entry i
+  int count;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(const ReduceTable t) {
+  int e = 0;
+  while (e + 1 < t.count && (int)blockIdx.x >= t.blk_start[e + 1]) ++e;
+  const int local = (int)blockIdx.x - t.blk_start[e];
+  const int ks = t.ks[e];
+  const float* partial = t.partial[e];
+  float* out = t.out[e];
+  long mn = t.mn[e];
+  long i4;
+  if (local >= t.blocks1[e]) {      // the ksplit x M column-sum slab behind the product slab
+    partial += (long)ks * mn;
+    out = t.colsum[e];
+    mn = t.m[e];
+    i4 = ((long)(local - t.blocks1[e]) * 256 + threadIdx.x) * 4;
+  } else {
+    i4 = ((long)local * 256 + threadIdx.x) * 4;
+  }
+  if (i4 >= mn) return;
+  f32x4_t s = egv_load<EGV_NT_REDUCE_LD, f32x4_t>(partial + i4);
+  for (int z = 1; z < ks; ++z) s += egv_load<EGV_NT_REDUCE_LD, f32x4_t>(partial + (long)z * mn + i4);
+  egv_store<EGV_NT_WGRAD>(out + i4, s);
+}
+
 }  // namespace
+
+extern "C" int egv_splitk_reduce_multi(int32_t count, const float* const* partial, float* const* out, const int64_t* mn, const int32_t* ksplit,
+                                       float* const* colsum, const int32_t* m, void* stream) {
+  if (count < 1 || count > RED_MAX_T || !partial || !out || !mn || !ksplit) return EGV_ERR_ARG;
+  ReduceTable t = {};
+  int nb = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!partial[i] || !out[i] || mn[i] <= 0 || mn[i] % 4 != 0 || ksplit[i] < 2) return EGV_ERR_ARG;
+    const bool cs = colsum && colsum[i];
+    if (cs && (!m || m[i] <= 0 || m[i] % 4 != 0)) return EGV_ERR_ARG;
+    t.partial[i] = partial[i]; t.out[i] = out[i]; t.colsum[i] = cs ? colsum[i] : nullptr;
+    t.mn[i] = mn[i]; t.m[i] = cs ? m[i] : 0; t.ks[i] = ksplit[i];
+    t.blk_start[i] = nb;
+    t.blocks1[i] = (int)((mn[i] / 4 + 255) / 256);
+    nb += t.blocks1[i] + (cs ? (m[i] / 4 + 255) / 256 : 0);
+  }
+  t.blk_start[count] = nb;
+  t.count = count;
+  EGV_LAUNCH(splitk_reduce_multi_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, t);
+  EGV_CHECK_LAUNCH();
+  return EGV_OK;
+}
 
 int egv_gemm_big_launch(const egv_gemm_desc& p, hipStream_t s, int variant);  // gemm_big.hip
 bool egv_gemm_big_supports(const egv_gemm_desc& p);
@@ -289,6 +348,9 @@ extern "C" int egv_gemm_nt(const egv_gemm_desc* d, void* stream) {
     const long mn4 = (long)p.M * p.N / 4;
     EGV_LAUNCH(splitk_reduce_epilogue_kernel, dim3((int)((mn4 + 255) / 256)), dim3(256), 0, s, p, ks);
     EGV_CHECK_LAUNCH();
+  } else if (ks > 1 && p.accumulate == 2) {
+    // the caller reduces the slabs itself (egv_splitk_reduce_multi: several weight gradients in one launch)
+    if (!p.trans || !p.out_f32 || p.ldo != p.N) return EGV_ERR_ARG;
   } else if (ks > 1) {
     if (!p.out_f32 || p.ldo != p.N) return EGV_ERR_ARG;
     const long mn = (long)p.M * p.N;

@@ -54,7 +54,8 @@ enum { EGV_ACT_NONE = 0, EGV_ACT_GELU = 1, EGV_ACT_GELU_BWD = 2, EGV_ACT_RELU_BW
  *  act = EGV_ACT_RELU_BWD  : v  = aux_in[m,n] > 0 ? v : 0
  * Outputs: any subset of out_f32 / (out_hi[, out_lo]).  Split-K (ksplit > 1, used by wgrad where
  * K = #tokens): raw partial sums go to partial[ksplit][M][N] and a second kernel reduces them into
- * out_f32 (ldo must equal N; accumulate != 0 adds to the existing contents); no epilogue then.   */
+ * out_f32 (ldo must equal N; accumulate == 1 adds to the existing contents; accumulate == 2, trans == 1 only: the slabs are left
+ * un-reduced for egv_splitk_reduce_multi); no epilogue then.   */
 typedef struct egv_gemm_desc {
   const egv_bf16* a_hi; const egv_bf16* a_lo; int64_t lda;
   const egv_bf16* b_hi; const egv_bf16* b_lo; int64_t ldb;
@@ -94,6 +95,13 @@ typedef struct egv_gemm_desc {
                        (wgrad) read, since an fp16 plane cannot share an MFMA with bf16 gradients.                               */
 } egv_gemm_desc;
 int egv_gemm_nt(const egv_gemm_desc* d, void* stream);
+/* The split-K reduction of SEVERAL trans == 1 launches (weight gradients) in ONE launch: a descriptor with ksplit > 1 and
+ * accumulate == 2 leaves its slabs in `partial` (ksplit x M x N products, then ksplit x M column sums) and writes nothing else;
+ * this call sums them: out[i][0 .. mn[i]) = sum_z partial[i][z], colsum[i][0 .. m[i]) likewise (colsum / its entries may be NULL).
+ * HOST arrays of `count` <= 8 device pointers / sizes; mn[i] = M x N of launch i (a multiple of 4), ksplit[i] >= 2.  egv_block_bwd
+ * finishes the six weight gradients of a SpaceTimeBlock this way when they share one stream.                                      */
+int egv_splitk_reduce_multi(int32_t count, const float* const* partial, float* const* out, const int64_t* mn, const int32_t* ksplit,
+                            float* const* colsum, const int32_t* m, void* stream);
 /* ---- format kernels (HBM-bound) -----------------------------------------------------------------
  * fp32 [rows, cols] -> split planes, optionally also the TRANSPOSED planes t_*[cols, ldt] (ldt >= rows,
  * columns rows..ldt-1 are zero-filled so a following GEMM can contract over a K padded to 32) and the
