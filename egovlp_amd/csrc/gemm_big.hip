@@ -1070,6 +1070,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
         // f16x2 outputs: the bf16 copy for the backward at a fixed element distance from the first fp16 plane (0: not wanted)
         const long dbf = (EPI == EPI_GELU_X2 && p.out_bf) ? (long)(p.out_bf - p.out_hi) : 0;
         const long ldz4 = 4 * p.ldaux;
+#ifdef EGV_DIAG
+        // DIAGNOSTIC (`make diag`, EGV_GEMM_DBG=90; results invalid): the fast plane epilogue with every global STORE replaced by a register
+        // sink -- all of its loads, LDS traffic and arithmetic (bias, erf-GELU, gelu', conversions) still run.  What the fc1 forward spends
+        // in its epilogue beyond this is store traffic; what remains is VALU work (profiles/r06_fc1_epilogue_valu_vs_stores.txt)
+        const bool sink_stores = (dbg & 0xfff) == 90;
+#else
+        constexpr bool sink_stores = false;
+#endif
+        auto st16 = [&](auto site, void* ptr, u32x4_t v) {
+          if (sink_stores) asm volatile("" ::"v"(v));
+          else egv_store16<decltype(site)::value>(ptr, v);
+        };
         const bool saved_grad = p.aux_bf16 >= 2;
         const bool aux_f16 = (H1 || X2) && p.aux_bf16 == 3;       // the saved gelu' as fp16 (the fp16 backward: bf16's 2^-9 would cap dZ's accuracy)
         // fp16 plane outputs of the plain epilogues (out_fmt 4: ONE plane of un-clamped fp16 -- a scaled gradient: dZ, the dO of the
@@ -1094,11 +1106,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             }
             if (dz) {
               if (aux_f16)
-                egv_store16<EGV_NT_SAVED>(dz, (u32x4_t){f16_grad_pack2(s0[0], s0[1]), f16_grad_pack2(s0[2], s0[3]),
-                                          f16_grad_pack2(s1[0], s1[1]), f16_grad_pack2(s1[2], s1[3])});
+                st16(std::integral_constant<int, EGV_NT_SAVED>{}, dz, (u32x4_t){f16_grad_pack2(s0[0], s0[1]), f16_grad_pack2(s0[2], s0[3]),
+                                                                                f16_grad_pack2(s1[0], s1[1]), f16_grad_pack2(s1[2], s1[3])});
               else
-                egv_store16<EGV_NT_SAVED>(dz, (u32x4_t){f32x2_to_bf16x2(s0[0], s0[1]), f32x2_to_bf16x2(s0[2], s0[3]),
-                                          f32x2_to_bf16x2(s1[0], s1[1]), f32x2_to_bf16x2(s1[2], s1[3])});
+                st16(std::integral_constant<int, EGV_NT_SAVED>{}, dz, (u32x4_t){f32x2_to_bf16x2(s0[0], s0[1]), f32x2_to_bf16x2(s0[2], s0[3]),
+                                                                                f32x2_to_bf16x2(s1[0], s1[1]), f32x2_to_bf16x2(s1[2], s1[3])});
               dz += ldz4;
             }
           } else if constexpr (EPI == EPI_GELU_BWD) {
@@ -1137,14 +1149,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const egv_gemm_desc p,
             // the activation in the f16x2 operand format (first-operand role): two fp16 planes [+ the bf16 copy]
             const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if (p.out_fmt == 2) {       // ONE plane of plain fp16: the consumer runs a single fp16 product
-              egv_store16<PSITE>(dh, f16_piece8(vv));
+              st16(std::integral_constant<int, PSITE>{}, dh, f16_piece8(vv));
             } else {
               u32x4_t o1, o2;
               f16x2_encode8<0>(vv, o1, o2);
-              egv_store16<PSITE>(dh, o1);
-              egv_store16<PSITE>(dh + dlo, o2);
+              st16(std::integral_constant<int, PSITE>{}, dh, o1);
+              st16(std::integral_constant<int, PSITE>{}, dh + dlo, o2);
             }
-            if (dbf) egv_store16<PSITE>(dh + dbf, bf16_piece8(vv));
+            if (dbf) st16(std::integral_constant<int, PSITE>{}, dh + dbf, bf16_piece8(vv));
           } else if (grad_f16) {
             const float vv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             egv_store16<PSITE>(dh, f16_grad_piece8(vv));

@@ -27,3 +27,26 @@ for mode, name in ((0, "space"), (1, "time")):
     for _ in range(10): f()
     e1.record(); torch.cuda.synchronize()
     print("passes=1 %s attention bwd: %.1f us" % (name, e0.elapsed_time(e1) * 100))
+
+# the fp16 attention of the fp16 backward mode (round 6): qkv planes = an fp16 split, three-product forward, single-product backward on fp16
+x = torch.randn(B * S, 3 * H * 64, device="cuda")
+hi = x.to(torch.float16)
+qkv16 = ops.Planes(hi, (x - hi.float()).to(torch.float16), B * S, 3 * H * 64, "f16s")
+for mode, name in ((0, "space"), (1, "time")):
+    for fmt in ("f16x2", "f16"):
+        f = lambda: ops.divided_attn_fwd(qkv16, B, T, n, H, mode, 3, out_fmt=fmt)
+        for _ in range(3): f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): f()
+        e1.record(); torch.cuda.synchronize()
+        print("fp16 x3 %s attention fwd (output %s): %.1f us" % (name, fmt, e0.elapsed_time(e1) * 100))
+    out, lse = ops.divided_attn_fwd(qkv16, B, T, n, H, mode, 3, out_fmt="f16")
+    d_out = ops.f16_cast(torch.randn(B * S, H * 64, device="cuda"))
+    f = lambda: ops.divided_attn_bwd(qkv16, out, d_out, lse, B, T, n, H, mode, 1, grad_f16=True)
+    for _ in range(3): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): f()
+    e1.record(); torch.cuda.synchronize()
+    print("fp16 x1 %s attention bwd: %.1f us" % (name, e0.elapsed_time(e1) * 100))

@@ -22,8 +22,10 @@ D, H3, HD = 768, 2304, 3072
 dev = "cuda"
 
 
-def rnd(r, c, p, role=0):
+def rnd(r, c, p, role=0, plain16=False):
     x = torch.rand(r, c, device=dev) * 2 - 1
+    if plain16:              # ONE plane of plain fp16 (fmt 'f16'): every operand of the fp16 backward (dY, X, W^T)
+        return ops.Planes(x.to(torch.float16), None, r, c, "f16")
     if p == 2:               # f16x2 operands: role 0 = first operand (activations), 1 = second (weights)
         return ops.f16x2_encode(x, role)
     if p == 4:               # ONE fp16 product: a plain fp16 activation plane x the weight's f16x2 encoding (plane 1 = fp16(W))
@@ -37,8 +39,10 @@ def cases(P, Pb, single=0):
     P_qkv, P_fc1, P_fc2 = (4 if single & 4 else P), (4 if single & 1 else P), (4 if single & 2 else P)
     out = []
 
-    def nt(name, m, n, k, p, kw=None):
-        a, b = rnd(m, k, p, 0), rnd(n, k, p, 1)
+    h16 = Pb == 4           # the fp16 backward (round 6): fp16 dY / X / W^T planes, fp16 saved gelu', fp16-split qkv planes, no bf16 copies
+
+    def nt(name, m, n, k, p, kw=None, bwd=False):
+        a, b = rnd(m, k, p, 0, plain16=bwd and h16), rnd(n, k, p, 1, plain16=bwd and h16)
         bias = torch.zeros(n, device=dev)
         if EPI != "real":
             if EPI == "bf16":
@@ -51,33 +55,34 @@ def cases(P, Pb, single=0):
         out.append((name, m, n, k, p, lambda: ops.gemm_nt(a, b, passes=p, **kw(bias))))
 
     def tn(name, m, n, k, p):
-        a, b = rnd(k, m, p), rnd(k, n, p)
+        a, b = rnd(k, m, p, plain16=h16 and p == 4), rnd(k, n, p, plain16=h16 and p == 4)
         o = torch.empty(m, n, device=dev)
-        out.append((name, m, n, k, p, lambda: ops.gemm_tn(a, b, passes=p, out_f32=o, want_colsum=True)))
+        out.append((name, m, n, k, p, lambda: ops.gemm_tn(a, b, passes=p, out_f32=o, want_colsum=True, alpha=ops.A1_INV if (h16 and p == 4) else 1.0)))
 
     res = torch.rand(M, D, device=dev)
     o32 = torch.empty(M, D, device=dev)
     Pa = 3 if P == 2 else P          # the f16x2 mode (P = 2): qkv / fc1 / fc2 forward as two fp16 products, proj / text split-bf16 x3
-    qkv_pl = ops.empty_planes(M, H3, Pa, dev)
-    h_pl = ops.empty_planes_f16x2(M, HD, dev, want_bf=True, single=bool(single & 2)) if P == 2 else ops.empty_planes(M, HD, P, dev)
-    z = torch.empty(M, HD, device=dev, dtype=torch.bfloat16 if Pb == 1 else torch.float32)
+    P_proj = (4 if single & 8 else 2) if h16 else Pa      # fp16 backward: the proj runs two fp16 products (f16x2 attention output) or one
+    qkv_pl = ops.empty_planes_f16x2(M, H3, dev, split=True) if h16 else ops.empty_planes(M, H3, Pa, dev)
+    h_pl = ops.empty_planes_f16x2(M, HD, dev, want_bf=not h16, single=bool(single & 2)) if P == 2 else ops.empty_planes(M, HD, P, dev)
+    z = torch.empty(M, HD, device=dev, dtype=torch.float16 if h16 else (torch.bfloat16 if Pb == 1 else torch.float32))
     zin = (torch.rand(M, HD, device=dev) * 4 - 2).to(z.dtype)
-    dz_pl = ops.empty_planes(M, HD, Pb, dev)
-    dx_pl = ops.empty_planes(M, D, Pb, dev)
+    dz_pl = ops.empty_planes_f16x2(M, HD, dev, single=True) if h16 else ops.empty_planes(M, HD, Pb, dev)
+    dx_pl = ops.empty_planes_f16x2(M, D, dev, single=True) if h16 else ops.empty_planes(M, D, Pb, dev)
     nt("qkv   fwd", M, H3, D, P_qkv, kw=lambda bias: dict(bias=bias, out_planes=qkv_pl))
-    nt("proj  fwd", M, D, D, Pa, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
-    nt("fc1   fwd", M, HD, D, P_fc1, kw=lambda bias: dict(bias=bias, act=ops.ACT_GELU, aux_out=z, out_planes=h_pl, aux_is_grad=Pb == 1))
+    nt("proj  fwd", M, D, D, P_proj, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
+    nt("fc1   fwd", M, HD, D, P_fc1, kw=lambda bias: dict(bias=bias, act=ops.ACT_GELU, aux_out=z, out_planes=h_pl, aux_is_grad=Pb in (1, 4)))
     nt("fc2   fwd", M, D, HD, P_fc2, kw=lambda bias: dict(bias=bias, residual=res, out_f32=o32))
-    nt("fc2 dgrad", M, HD, D, Pb, kw=lambda bias: dict(act=ops.ACT_GELU_BWD, aux_in=zin, out_planes=dz_pl, aux_is_grad=Pb == 1))
-    nt("fc1 dgrad", M, D, HD, Pb, kw=lambda bias: dict(out_f32=o32))
-    nt("proj dgrad", M, D, D, Pb, kw=lambda bias: dict(out_planes=dx_pl))
-    nt("qkv dgrad", M, D, H3, Pb, kw=lambda bias: dict(out_f32=o32))
+    nt("fc2 dgrad", M, HD, D, Pb, kw=lambda bias: dict(act=ops.ACT_GELU_BWD, aux_in=zin, out_planes=dz_pl, aux_is_grad=Pb in (1, 4)), bwd=True)
+    nt("fc1 dgrad", M, D, HD, Pb, kw=lambda bias: dict(out_f32=o32), bwd=True)
+    nt("proj dgrad", M, D, D, Pb, kw=lambda bias: dict(out_planes=dx_pl, grad_out=h16), bwd=True)
+    nt("qkv dgrad", M, D, H3, Pb, kw=lambda bias: dict(out_f32=o32), bwd=True)
     tn("qkv wgrad", H3, D, M, Pb)
     tn("proj wgrad", D, D, M, Pb)
     tn("fc1 wgrad", HD, D, M, Pb)
     tn("fc2 wgrad", D, HD, M, Pb)
     nt("text  lin", 1024, D, D, Pa, kw=lambda bias: dict(bias=bias, out_f32=torch.empty(1024, D, device=dev)))
-    tn("text wgrad", D, D, 1024, Pb)
+    tn("text wgrad", D, D, 1024, 3 if h16 else Pb)
     return out
 
 

@@ -22,8 +22,8 @@ def case_list():
     import gemm_bench as gb
     out = []
     seen = set()
-    for single, tag in ((0, "x2"), (7, "x1")):
-        for name, m, n, k, p, run in gb.cases(2, 1, single):
+    for single, tag in ((0, "x2"), (15, "x1")):
+        for name, m, n, k, p, run in gb.cases(2, int(os.environ.get("PMC_BWD", "4")), single):       # 4: the fp16 backward (round 6); 1: bf16
             key = (name, p)
             if key in seen or name.startswith("text"):
                 continue
