@@ -48,6 +48,12 @@ class Multi_BaseTrainer_dist:
         from .. import ops
         ec = getattr(self.model, "exec_ctx", None) or ops.DEFAULT
         ec.set(wgrad_side_stream=os.environ.get("EGV_WGRAD_SIDE", "1") == "1")
+        # precision mode of the run: `args.precision` ("bf16x3" = the library's parity-grade default, "f16mix" = the benchmarked mode:
+        # fp16-product forward under the measured per-block policy + fp16 backward under the device-side loss scale, "f16x2", "mixed"),
+        # or EGOVLP_PRECISION; the reference has no such switch (fp32 everywhere)
+        prec = getattr(args, "precision", None) or os.environ.get("EGOVLP_PRECISION")
+        if prec:
+            ec.set_precision("bf16x3", "bf16") if prec == "mixed" else ec.set_precision(*prec.split("/"))
         self.grad_sync = None
         if self.world_size > 1:
             from ..dist import Bf16GradSync

@@ -37,7 +37,7 @@ timeout 300 python tools/host_overhead.py f16mix 2>&1 | grep -v amdgpu > $O/host
 timeout 900 python bench.py --steps 20 --warmup 5 --frames 16 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg --no-dp-leg > $O/bench_config4_T16_B16.json 2>> $O/bench_default.err
 timeout 900 python bench.py --steps 20 --warmup 5 --arch large_patch14_224 --batch 16 --no-cpu-baseline --no-trajectory --no-h2d-leg --no-dp-leg > $O/bench_config5_vitl14_B16.json 2>> $O/bench_default.err
 # same-box interleaved A/B of the backward pairing at the headline size
-bash tools/gpu_ab_env2.sh $1/ab_bwd 2 "EGV_X2_BWD=bf16" "EGV_X2_BWD=f16" > /dev/null 2>&1; cp $O/ab_bwd/ab.txt $O/ab_backward_pairing.txt
+TAG=$(basename $O); bash tools/gpu_ab_env2.sh $TAG/ab_bwd 2 "EGV_X2_BWD=bf16" "EGV_X2_BWD=f16" > /dev/null 2>&1; cp $O/ab_bwd/ab.txt $O/ab_backward_pairing.txt
 # the data-parallel code path (process group, RCCL streams, gradient exchange, 248-workgroup grid) at world size 1
 ( timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 5 $LEGS --force-dist 2>&1 | grep "^{" ) > $O/bench_force_dist_w1.json
 tail -4 $O/pytest_gpu.txt; cat $O/smoke.log | tail -3; cut -c1-300 $O/bench_default.json; tail -3 $O/bench_gpus2_on_1gpu_box.txt; head -3 $O/kernel_stats_timed_f16mix_f16.csv; head -6 $O/stream_timeline.txt; cat $O/ab_backward_pairing.txt
