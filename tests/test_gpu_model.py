@@ -773,3 +773,50 @@ def test_precision_guard_measures_the_policy_and_demotes_it_on_hostile_weights(d
     from egovlp_amd.trainer.trainer_egoclip import egoclip_step
     loss = egoclip_step(m, EgoNCE(), AdamW(m.parameters(), lr=3e-5), dev)
     assert bool(torch.isfinite(loss))
+
+
+def test_precision_guard_answers_fp16_saturation_with_the_bf16x3_forward():
+    """fp16 operand planes are written saturating (csrc/f16x2.h f16x2_clamp: an activation beyond +-65504 is clipped, not inf) -- the
+    advisor's round-5 point: nothing in the fp16-product forward itself notices.  The guard does: block 5's fc1 scaled by 1e5 (and fc2
+    by 1e-5: the product is unchanged in exact arithmetic, model/video_transformer.py:41-52) puts |gelu(z)| near 1e5 and fc2's weights
+    into fp16's subnormals; every fp16 rung of the ladder measures far outside the budget, the guard ends on the all-bf16x3 forward
+    (bf16's exponent range), and what it leaves in force is inside the parity bar against the fp32 CPU oracle."""
+    from egovlp_amd.guard import PrecisionGuard
+    from egovlp_amd.model.model import FrozenInTime
+    m = FrozenInTime(video_params={"model": "SpaceTimeTransformer", "arch_config": "base_patch16_224", "num_frames": 4, "pretrained": True,
+                                   "time_init": "rand"},
+                     text_params={"model": "distilbert-base-uncased", "pretrained": True, "input": "text"}, projection="minimal",
+                     load_checkpoint="")
+    sd = synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed=0)
+    for k in list(sd):
+        if k.startswith("video_model.blocks.5.mlp.fc1."):
+            sd[k] = sd[k] * 1e5
+        if k == "video_model.blocks.5.mlp.fc2.weight":
+            sd[k] = sd[k] * 1e-5
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    batch = synth_batch(4, T=4, L=32, seed=99, ragged=True)
+    dev = to_dev(batch)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        _, rv = O.frozen_in_time(batch, sd, O.VideoCfg(num_frames=4), O.TextCfg())
+
+    def video_err():
+        m.eval()
+        with torch.no_grad():
+            _, ve = m(dev)
+        m.train()
+        return rel(ve, rv)
+
+    ec = m.exec_ctx
+    ec.set_precision("f16mix", "f16")
+    unguarded = video_err()
+    g = PrecisionGuard(m)
+    rep = g.check(dev)
+    guarded = video_err()
+    print("saturating fc1 (x 1e5): un-guarded %.2e from the oracle; guard tried %s -> %s, %.2e" % (
+        unguarded, [(str(t["policy"]), "%.2e" % t["err"]) for t in rep["tried"]], rep["policy"], guarded))
+    assert unguarded > 10 * PARITY                       # the clipped activations are a gross error, and a silent one
+    assert rep["demoted"] and rep["policy"] == "bf16x3" and ec.precision_name() == ("bf16x3", "bf16")
+    assert [str(t["policy"]) for t in rep["tried"]][0] == "auto" and len(rep["tried"]) == 5
+    assert guarded < PARITY
