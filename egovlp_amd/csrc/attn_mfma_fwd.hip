@@ -11,6 +11,7 @@
 // transpose read.  q/k/v are read directly out of the fused qkv buffer with index arithmetic; none
 // of the reference's rearrange / repeat / cat copies exist.
 #include <cstdlib>
+#include <type_traits>
 
 #include "attn_common.h"
 #include "egovlp_hip.h"
@@ -176,10 +177,29 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttGeom g, bf16_t* 
 // waves per workgroup (four per SIMD) whose phases interleave, and the 13 query tiles of a ViT-B group run in one round.
 // Measured 137 -> 130 us (profiles/r02_z_attention_streaming.txt): staging a group's K / V (one workgroup per CU, 115 KiB) is still
 // not overlapped with the previous group's tiles -- that needs the K / V chunks themselves streamed through a small LDS ring.
+// PERSISTENT (round 6): one workgroup per CU walks the groups gid, gid + grid, ... and fetches the NEXT group's operands into registers
+// while it works on the current group's query tiles -- the staging round trip (every CU pulling 115 KiB at the same moment, six times per
+// launch, then every wave its q fragments) was most of a group's 23 us with the matrix pipe and the VALU idle (a group's MFMAs are ~5 us):
+//   * the hi planes of K / V (this thread's pieces: 16 VGPRs) at the top of the tile;
+//   * the lo planes (16) and the wave's NEXT q fragments (16) behind the last Q.K^T of the tile, when the q registers and the score
+//     registers of the earlier chunks are dead -- all 48 live at once with the tile's own 90 registers do not fit the 128 a 16-wave
+//     workgroup has (both planes up front spilled);
+//   * between two barriers, when every wave is done, the pieces go to LDS and the next group starts with its q in registers.
+// A wave owns query tile `wave` of every group (13 tiles on 16 waves for 197 keys; waves without a tile only fetch); further tiles
+// (257-key groups: 17 tiles) are run behind it with their q fetched on the spot.  Groups of more than 256 keys (3 pieces per plane and
+// thread) fetch everything behind the tile.
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_planes(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for_planes<B + 1, E>(f);
+  }
+}
+
 template <int NKF, bool F16 = false>
 __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g, bf16_t* __restrict__ out_hi,
                                                                 bf16_t* __restrict__ out_lo, long out_stride,
-                                                                float* __restrict__ lse, float* __restrict__ cls_ws) {
+                                                                float* __restrict__ lse, float* __restrict__ cls_ws, const int ngroups) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKP = NKF * 16;
   constexpr int PLANE = NKP * ATT_ROW_BYTES;
@@ -189,34 +209,89 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
   char* v_lo = smem + 3 * PLANE;
   float* kbias = (float*)(smem + 4 * PLANE);
 
-  const AttGroup<MODE_SPACE> grp(g, blockIdx.x);
-  const int lane = threadIdx.x & 63;
+  // `tidx` / `lane` are made opaque at the top of every group (below): everything derived from them -- piece offsets, LDS fragment
+  // addresses -- is recomputed per group instead of being hoisted out of the group loop, where it is live across all of it and spills
+  int tidx = threadIdx.x;
+  int lane = tidx & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long hoff = (long)grp.h * ATT_D;
   const long HD = (long)g.H * ATT_D;
 
-  att_stage_planes(k_hi, k_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + HD + hoff; });
-  att_stage_planes(v_hi, v_lo, g.ph, g.pl, g.nk, NKP, [&](int r) { return grp.k_tok(g, r) * g.tok_stride + 2 * HD + hoff; });
+  // this thread's pieces of a group's K / V image: piece t = tid + 1024 i -> row t / 8, 16-B chunk t % 8 (att_stage_planes' layout)
+  constexpr int NLD = (NKP * 8 + 1023) / 1024;
+  constexpr int EARLY = NLD <= 2 ? 2 : 0;            // planes fetched at the top of the tile: k_hi, v_hi
+  u32x4_t pre[NLD][4];                               // [i][k_hi, v_hi, k_lo, v_lo]
+  auto fetch = [&](const AttGroup<MODE_SPACE>& gr, auto P0, auto P1) {   // planes [P0, P1); branch-free (clamped rows)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int t = min(tidx + 1024 * i, NKP * 8 - 1);
+      const int row = min(t >> 3, g.nk - 1), chunk = t & 7;
+      const long off = gr.k_tok(g, row) * g.tok_stride + HD + (long)gr.h * ATT_D + chunk * 8;
+      static_for_planes<decltype(P0)::value, decltype(P1)::value>([&](auto Pc) {
+        constexpr int pp = decltype(Pc)::value;
+        pre[i][pp] = *(const u32x4_t*)((pp >= 2 ? g.pl : g.ph) + off + ((pp & 1) ? HD : 0));
+      });
+    }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using CE = std::integral_constant<int, EARLY>;
+  using C4 = std::integral_constant<int, 4>;
+  using CM = std::integral_constant<int, NLD <= 2 ? 3 : EARLY>;      // planes [EARLY, CM) (k_lo) are fetched behind the last Q.K^T of the tile,
+                                                                     // [CM, 4) (v_lo) behind its last P.V: the registers are free by then
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int t = tidx + 1024 * i;
+      if (t < NKP * 8) {
+        const int row = t >> 3, chunk = t & 7;
+        const bool live = row < g.nk;                // rows past the group's keys are zeros (their scores are masked by kbias)
+        const u32x4_t zero = {0u, 0u, 0u, 0u};
+        const int o = row * ATT_ROW_BYTES + ((chunk ^ (row & 7)) << 4);
+        *(u32x4_t*)(k_hi + o) = live ? pre[i][0] : zero;
+        *(u32x4_t*)(v_hi + o) = live ? pre[i][1] : zero;
+        *(u32x4_t*)(k_lo + o) = live ? pre[i][2] : zero;
+        *(u32x4_t*)(v_lo + o) = live ? pre[i][3] : zero;
+      }
+    }
+  };
+
+  const int nq_all = g.nq + 1;                       // + the CLS query row (see attn_fwd_kernel)
+  const int ntiles = (nq_all + 15) / 16;
+  const bool has_tile = wave < ntiles;               // wave-uniform
+  // q fragments of query tile qt of a group: (hi, lo) x two 32-wide k-steps
+  auto load_q = [&](const AttGroup<MODE_SPACE>& gr, int qt, bf16x8_t (&h)[2], bf16x8_t (&l)[2]) {
+    const int qi = qt * 16 + (lane & 15);
+    const long qtok = qi >= g.nq ? gr.tok0 : gr.q_tok(g, min(qi, g.nq - 1));
+    const long off = qtok * g.tok_stride + (long)gr.h * ATT_D + (lane >> 4) * 8;
+    // (both planes exist in this kernel: plain loads -- att_gfrag_planes' "lo = hi" fallback makes the compiler wait for the hi load)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      h[ks] = *(const bf16x8_t*)(g.ph + off + 32 * ks);
+      l[ks] = *(const bf16x8_t*)(g.pl + off + 32 * ks);
+    }
+  };
+
+  int gid = blockIdx.x;
+  AttGroup<MODE_SPACE> grp(g, gid);
+  bf16x8_t qh[2], ql[2];
+  if constexpr (NKF <= 16) load_q(grp, has_tile ? wave : 0, qh, ql);
+  fetch(grp, C0{}, C4{});
+  commit();
   for (int j = threadIdx.x; j < NKP; j += blockDim.x) kbias[j] = (j < g.nk) ? 0.f : -1e30f;
   __syncthreads();
 
-  const int gq = lane >> 4;
-  const int nq_all = g.nq + 1;                       // + the CLS query row (see attn_fwd_kernel)
-  const int ntiles = (nq_all + 15) / 16;
-  for (int qt = wave; qt < ntiles; qt += (int)(blockDim.x >> 6)) {
+  // One query tile: NKF / 2 chunks of 32 keys with the running-max / running-sum recurrence; `mid` runs behind the LAST chunk's Q.K^T
+  // (the q fragments are dead from there on).
+  auto run_tile = [&](const AttGroup<MODE_SPACE>& gr, const int qt, const bf16x8_t (&tqh)[2], const bf16x8_t (&tql)[2], auto&& mid, auto&& post) {
+    const long hoff = (long)gr.h * ATT_D;
+    const int gq = lane >> 4;
     const int qi = qt * 16 + (lane & 15);
     const bool is_cls = qi >= g.nq;
-    const long qtok = is_cls ? grp.tok0 : grp.q_tok(g, min(qi, g.nq - 1));
-    bf16x8_t qh[2], ql[2];
-    att_gfrag_planes(g.ph, g.pl, qtok * g.tok_stride + hoff, 0, lane, qh[0], ql[0]);
-    att_gfrag_planes(g.ph, g.pl, qtok * g.tok_stride + hoff, 1, lane, qh[1], ql[1]);
+    const long qtok = is_cls ? gr.tok0 : gr.q_tok(g, min(qi, g.nq - 1));
     float m = -3e38f, l = 0.f;                       // m: uniform over the four lane groups of a query; l: this lane group's part
     f32x4_t o[4];
 #pragma unroll
     for (int df = 0; df < 4; ++df) o[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int c = 0; c < NKF / 2; ++c) {
-      f32x4_t s[2];
+    auto scores = [&](const int c, f32x4_t (&s)[2]) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int kf = 2 * c + h;
@@ -225,12 +300,14 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
           const bf16x8_t al = att_frag_cols(k_lo, kf * 16, ks, lane);
-          s[h] = att_mma<3, F16>(ah, al, qh[ks], ql[ks], s[h]);
+          s[h] = att_mma<3, F16>(ah, al, tqh[ks], tql[ks], s[h]);
         }
         const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
         s[h] = s[h] * 0.125f + kb;                   // q *= 64^-0.5 (video_transformer.py:106), applied to the scores
       }
-      if (c == 0 && is_cls && grp.f > 0 && gq == 0) s[0][0] = -1e30f;   // CLS key x CLS query: group 0 only
+      if (c == 0 && is_cls && gr.f > 0 && gq == 0) s[0][0] = -1e30f;   // CLS key x CLS query: group 0 only
+    };
+    auto accumulate = [&](const int c, const f32x4_t (&s)[2]) {
       float cm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
                        fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
       cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
@@ -255,12 +332,29 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         const bf16x8_t vl = att_frag_rows(v_lo, 32 * c, df * 16, lane);
         o[df] = att_mma<3, F16>(vh, vl, ph, pl, o[df] * alpha);
       }
+    };
+#pragma unroll 1
+    for (int c = 0; c < NKF / 2 - 1; ++c) {
+      f32x4_t s[2];
+      scores(c, s);
+      accumulate(c, s);
     }
+    {
+      f32x4_t s[2];
+      scores(NKF / 2 - 1, s);
+      asm volatile("" ::: "memory");
+      mid();
+      asm volatile("" ::: "memory");
+      accumulate(NKF / 2 - 1, s);
+    }
+    asm volatile("" ::: "memory");
+    post();
+    asm volatile("" ::: "memory");
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     if (qi == g.nq) {
       // CLS query x this frame's keys: un-normalised partial for egv_attn_cls_combine
-      float* w = cls_ws + (((long)grp.b * g.H + grp.h) * g.T + grp.f) * 68;
+      float* w = cls_ws + (((long)gr.b * g.H + gr.h) * g.T + gr.f) * 68;
 #pragma unroll
       for (int df = 0; df < 4; ++df) *(f32x4_t*)(w + df * 16 + 4 * gq) = o[df];
       if (gq == 0) {
@@ -280,7 +374,46 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         egv_store<EGV_NT_SPACE_ATTN>(oh + d, (u32x2_t){h0, h1});
         if (ol) egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
       }
-      if (gq == 0 && lse) lse[((long)grp.b * g.H + grp.h) * g.S + (qtok - grp.tok0)] = m + __logf(l);
+      if (gq == 0 && lse) lse[((long)gr.b * g.H + gr.h) * g.S + (qtok - gr.tok0)] = m + __logf(l);
+    }
+  };
+
+  for (;;) {
+    asm volatile("" : "+v"(tidx), "+v"(lane));
+    const int gnext = gid + (int)gridDim.x;
+    const bool more = gnext < ngroups;
+    const AttGroup<MODE_SPACE> nxt(g, more ? gnext : gid);     // the last group re-reads its own operands and drops them
+    bf16x8_t nqh[2], nql[2];
+    if (has_tile) {
+      if constexpr (NKF > 16) {                      // more than 16 query tiles (only groups of more than 256 keys): the further ones FIRST,
+        for (int qt = wave + (int)(blockDim.x >> 6); qt < ntiles; qt += (int)(blockDim.x >> 6)) {     // nothing fetched ahead is live under them
+          bf16x8_t xh[2], xl[2];
+          load_q(grp, qt, xh, xl);
+          run_tile(grp, qt, xh, xl, []() {}, []() {});
+        }
+      }
+      if constexpr (NKF > 16) load_q(grp, wave, qh, ql);     // (these groups fetch nothing ahead but K / V behind the last tile: registers)
+      fetch(nxt, C0{}, CE{});                        // behind this wave's q loads, which are a whole group old
+      run_tile(grp, wave, qh, ql, [&]() {
+        if constexpr (NKF <= 16) load_q(nxt, wave, nqh, nql);
+        fetch(nxt, CE{}, CM{});
+      }, [&]() { fetch(nxt, CM{}, C4{}); });
+    } else {
+      if constexpr (NKF <= 16) load_q(nxt, 0, nqh, nql);     // (unused: keeps the hand-over below branch-free)
+      fetch(nxt, C0{}, C4{});
+    }
+    if (!more) break;
+    __syncthreads();                                 // every wave is done with this group's K / V
+    commit();
+    __syncthreads();
+    gid = gnext;
+    grp = nxt;
+    if constexpr (NKF <= 16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qh[ks] = nqh[ks];
+        ql[ks] = nql[ks];
+      }
     }
   }
 }
@@ -295,14 +428,17 @@ int launch_fwd(const AttGeom& g, int ngroups, int passes, bf16_t* oh, bf16_t* ol
 #endif                      // +0.25 % on config 5 against attn_fwd_kernel<0,18,3>: 234.6 vs 234.0 pairs/s, profiles/r05e_ab_config5_stream18.txt; 0: A/B builds
   if constexpr (MODE == MODE_SPACE && (NKF == 14 || (NKF == 18 && EGV_STREAM18))) {   // measured on ViT-B/16 (13 query tiles on 16 waves): 137 -> 130 us
     if (passes == 3 && (ol != nullptr || g.out_fmt == ATT_OUT_F16)) {
+      // persistent: one 16-wave workgroup per CU (115 / 148 KiB of LDS); EGV_ATTN_PERSIST=0 restores one workgroup per group (A/B)
+      static const int persist = getenv("EGV_ATTN_PERSIST") ? atoi(getenv("EGV_ATTN_PERSIST")) : 1;
+      const int grid = persist ? (ngroups < 256 ? ngroups : 256) : ngroups;
       if (g.f16) {
         auto kern = attn_fwd_stream3_kernel<NKF, true>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        EGV_LAUNCH(kern, dim3(ngroups), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws);
+        EGV_LAUNCH(kern, dim3(grid), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws, ngroups);
       } else {
         auto kern = attn_fwd_stream3_kernel<NKF>;
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        EGV_LAUNCH(kern, dim3(ngroups), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws);
+        EGV_LAUNCH(kern, dim3(grid), dim3(1024), lds, s, g, oh, ol, ostride, lse, cls_ws, ngroups);
       }
       EGV_CHECK_LAUNCH();
       return EGV_OK;
