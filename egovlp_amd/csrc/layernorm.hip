@@ -117,7 +117,13 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 2) void layernorm_bwd_kernel(
       xh[i] = gy[i];
       ad[i] = gy[i];
       if (full || c4 < nv) {
-        if (dyh) {   // dy as split-bf16 planes (written by the dgrad GEMM epilogue): half the bytes of fp32
+        if (dyh && (dx_fmt & 2)) {   // dy as ONE plane of un-clamped fp16 (the dgrad GEMMs of the fp16 backward write it so): 2 B per element
+          const u32x2_t a = *(const u32x2_t*)(dyh + (long)row * lddy + c4 * 4);
+          float a0, a1, a2, a3;
+          f16x2_unpack(a[0], a0, a1);
+          f16x2_unpack(a[1], a2, a3);
+          gy[i] = (f32x4_t){a0, a1, a2, a3};
+        } else if (dyh) {   // dy as split-bf16 planes (written by the dgrad GEMM epilogue): half the bytes of fp32
           const u32x2_t a = *(const u32x2_t*)(dyh + (long)row * lddy + c4 * 4);
           gy[i] = (f32x4_t){__uint_as_float(a[0] << 16), __uint_as_float(a[0] & 0xffff0000u), __uint_as_float(a[1] << 16),
                             __uint_as_float(a[1] & 0xffff0000u)};
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 2) void layernorm_bwd_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - c1 - xh[i][e] * c2) + ad[i][e];
         egv_store<EGV_NT_LN>(dx + (long)row * lddx + c4 * 4, o);
-        if (dxh && dx_fmt == 1) {   // ... as ONE plane of un-clamped fp16 (the fp16 backward: a scaled gradient; overflow -> inf -> skipped step)
+        if (dxh && (dx_fmt & 1)) {   // ... as ONE plane of un-clamped fp16 (the fp16 backward: a scaled gradient; overflow -> inf -> skipped step)
           egv_store<EGV_NT_LN>(dxh + (long)row * cols + c4 * 4, (u32x2_t){f16_grad_pack2(o[0], o[1]), f16_grad_pack2(o[2], o[3])});
         } else if (dxh) {   // the same gradient as the next GEMM's operand (row-major split-bf16 planes, ld = cols)
           uint32_t h0, h1, l0, l1;
@@ -289,7 +295,8 @@ extern "C" int egv_layernorm_bwd_partial(const float* dy, const egv_bf16* dy_hi,
                                          const float* add2, float* dx, int64_t lddx, egv_bf16* dx_hi, egv_bf16* dx_lo, int32_t dx_fmt,
                                          float* dgamma, float* dbeta, float* work, void* stream) {
   if ((!dy && !dy_hi) || !x || !gamma || !mean || !rstd || !dx || !work) return EGV_ERR_ARG;
-  if (dx_fmt < 0 || dx_fmt > 1 || (dx_fmt == 1 && dx_lo)) return EGV_ERR_ARG;
+  if (dx_fmt < 0 || dx_fmt > 3 || ((dx_fmt & 1) && dx_lo)) return EGV_ERR_ARG;
+  if ((dx_fmt & 2) && (!dy_hi || dy_lo || dy)) return EGV_ERR_ARG;          // an fp16 dy is ONE plane, given in dy_hi
   if (rows <= 0 || cols <= 0 || cols % 4 != 0 || cols > MAXV * 256) return EGV_ERR_ARG;
   const int parts = egv_layernorm_bwd_parts(rows);
   hipStream_t s = (hipStream_t)stream;

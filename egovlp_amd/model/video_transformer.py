@@ -229,18 +229,19 @@ class _SpaceTimeBlockFn(torch.autograd.Function):
         ops.gemm_nt(G_pl, Wt(fc2_w), passes=Pb, act=ACT_GELU_BWD, aux_in=z, out_planes=dZ, K=D,
                     aux_is_grad=z.dtype != torch.float32, ec=ec)
         _, d_fc2_w, d_fc2_b = _lin_bwd(G_pl, h, None, Pb, need_dx=False, params=(fc2_w,), ec=ec)
-        d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, params=(fc1_w,), ec=ec)   # LayerNorm backward reads planes
+        ln16 = Pb == 4          # fp16 backward: the dgrads in front of a LayerNorm backward hand it ONE plane of un-clamped fp16 (no fp32 copy)
+        d_n2, d_fc1_w, d_fc1_b = _lin_bwd(dZ, n2, Wt(fc1_w), Pb, dx_planes=ln16, params=(fc1_w,), ec=ec)
         # d_sr = G + LN2'(d_n2)
         d_sr, d_n2w, d_n2b, d_sr_pl = ops.layernorm_bwd(d_n2, sr, n2w, mean2, rstd2, add1=G, planes_passes=Pb)
         # ---- spatial attention backward
         d_as, d_sproj_w, d_sproj_b = _lin_bwd(d_sr_pl, a_s, Wt(sproj_w), Pb, dx_planes=True, params=(sproj_w,), ec=ec)
         d_qkv_s = ops.divided_attn_bwd(qkv_s, a_s, d_as, lse_s, B, T, n, H, 0, 1 if h16 else Pb, grad_f16=h16)
-        d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb, params=(sqkv_w,), ec=ec)
+        d_n1, d_sqkv_w, d_sqkv_b = _lin_bwd(d_qkv_s, n1, Wt(sqkv_w), Pb, dx_planes=ln16, params=(sqkv_w,), ec=ec)
         d_tr, d_n1w, d_n1b, d_tr_pl = ops.layernorm_bwd(d_n1, tr, n1w, mean1, rstd1, planes_passes=Pb)
         # ---- temporal attention backward
         d_at, d_tproj_w, d_tproj_b = _lin_bwd(d_tr_pl, a_t, Wt(tproj_w), Pb, dx_planes=True, params=(tproj_w,), ec=ec)
         d_qkv_t = ops.divided_attn_bwd(qkv_t, a_t, d_at, lse_t, B, T, n, H, 1, 1 if h16 else Pb, grad_f16=h16)
-        d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb, params=(tqkv_w,), ec=ec)
+        d_n3, d_tqkv_w, d_tqkv_b = _lin_bwd(d_qkv_t, n3, Wt(tqkv_w), Pb, dx_planes=ln16, params=(tqkv_w,), ec=ec)
         # x feeds norm3, the tr residual and the sr residual: dx = d_tr + d_sr + LN3'(d_n3)
         d_x, d_n3w, d_n3b, d_x_pl = ops.layernorm_bwd(d_n3, x2, n3w, mean3, rstd3, add1=d_tr, add2=d_sr,
                                                        planes_passes=Pb)

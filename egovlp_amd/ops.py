@@ -934,14 +934,17 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, *, add1=None, add2=None, rows=No
         pl = empty_planes_f16x2(rows, cols, dev, single=True)
     else:
         pl = empty_planes(rows, cols, planes_passes, dev) if planes_passes else None
+    dy_f16 = dy_pl is not None and dy_pl.fmt == "f16"      # ONE plane of un-clamped fp16 (the dgrad GEMM of the fp16 backward wrote it)
     if dy_pl is not None:
-        dy_args = (None, _p(dy_pl.hi), _p(dy_pl.lo), dy_pl.ld)
+        if dy_pl.fmt not in ("bf16", "f16"):
+            raise ValueError(f"layernorm_bwd: dy planes must be split-bf16 or one un-clamped fp16 plane, got {dy_pl.fmt!r}")
+        dy_args = (None, _p(dy_pl.hi), None if dy_f16 else _p(dy_pl.lo), dy_pl.ld)
     else:
         dy_args = (_p(dy2d), None, None, dy2d.stride(0))
     check(_lib.lib().egv_layernorm_bwd_fmt(*dy_args, _p(x2d), ldx, _p(gamma), _p(mean), _p(rstd), rows,
                                            cols, _p(add1), _p(add2), _p(dx), lddx, _p(pl.hi) if pl else None,
-                                           _p(pl.lo) if pl else None, 1 if planes_passes == 4 else 0, _p(dg), _p(db), _p(work),
-                                           _stream(x2d)), "egv_layernorm_bwd_fmt")
+                                           _p(pl.lo) if pl else None, (1 if planes_passes == 4 else 0) | (2 if dy_f16 else 0), _p(dg), _p(db),
+                                           _p(work), _stream(x2d)), "egv_layernorm_bwd_fmt")
     if planes_passes:
         return dx, dg, db, pl
     return dx, dg, db

@@ -251,8 +251,10 @@ int egv_layernorm_bwd(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy
                       const float* mean, const float* rstd, int32_t rows, int32_t cols,
                       const float* add1, const float* add2, float* dx, int64_t lddx,
                       egv_bf16* dx_hi, egv_bf16* dx_lo, float* dgamma, float* dbeta, float* work, void* stream);
-/* The same with the format of the dx planes as an argument: dx_fmt 0 = split-bf16 (dx_hi[, dx_lo]); 1 = ONE plane of UN-CLAMPED
- * fp16 in dx_hi (dx_lo must be NULL): the operand of the next dgrad / wgrad GEMMs of the fp16 backward.                            */
+/* The same with the plane formats as an argument.  dx_fmt bit 0: 0 = dx planes are split-bf16 (dx_hi[, dx_lo]); 1 = ONE plane of
+ * UN-CLAMPED fp16 in dx_hi (dx_lo must be NULL): the operand of the next dgrad / wgrad GEMMs of the fp16 backward.  dx_fmt bit 1 (+ 2):
+ * dy is ONE plane of un-clamped fp16 in dy_hi (dy and dy_lo NULL) -- what the dgrad GEMM in front writes in the fp16 backward
+ * (egv_gemm_desc.out_fmt 4): half the bytes of an fp32 dy on both sides, one more fp16 rounding of a scaled gradient.                */
 int egv_layernorm_bwd_fmt(const float* dy, const egv_bf16* dy_hi, const egv_bf16* dy_lo, int64_t lddy,
                           const float* x, int64_t ldx, const float* gamma,
                           const float* mean, const float* rstd, int32_t rows, int32_t cols,

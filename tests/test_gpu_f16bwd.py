@@ -131,6 +131,20 @@ def test_layernorm_backward_writes_unclamped_fp16_planes(ops):
     xd = x.double().requires_grad_(True)
     F.layer_norm(xd, (cols,), gamma.double(), None, 1e-6).backward(dy.double())
     assert rel(dx.cpu().double() - add.double(), xd.grad) < 1e-5
+    # dy handed over as ONE plane of un-clamped fp16 (what the dgrad GEMM in front writes in the fp16 backward, egv_layernorm_bwd_fmt
+    # dx_fmt bit 1): bit-identical to the fp32 path fed the fp16-rounded values -- the plane is decoded exactly, nothing else changes --,
+    # and an inf in the plane reaches dx (the overflow check downstream sees it)
+    dy16 = ops.f16_cast(dy.cuda())
+    dx_a, dg_a, db_a, pl_a = ops.layernorm_bwd(dy16, x.cuda(), gamma.cuda(), mean.cuda(), rstd.cuda(), add1=add.cuda(), planes_passes=4)
+    dx_b, dg_b, db_b, pl_b = ops.layernorm_bwd(dy.to(torch.float16).float().cuda(), x.cuda(), gamma.cuda(), mean.cuda(), rstd.cuda(),
+                                               add1=add.cuda(), planes_passes=4)
+    assert torch.equal(dx_a, dx_b) and torch.equal(pl_a.hi.view(torch.int16), pl_b.hi.view(torch.int16))
+    assert rel(dg_a, dg_b) < 1e-6 and rel(db_a, db_b) < 1e-6                # (the column reduce adds its partial sums with atomics: order)
+    assert rel(dx_a.cpu().double() - add.double(), xd.grad) < 5e-4          # one fp16 rounding of dy: 2^-12 rms
+    big = dy.clone()
+    big[5, 9] = 1.0e6
+    dx_c = ops.layernorm_bwd(ops.f16_cast(big.cuda()), x.cuda(), gamma.cuda(), mean.cuda(), rstd.cuda())[0]
+    assert not bool(torch.isfinite(dx_c[5]).all()) and bool(torch.isfinite(dx_c[6]).all())
 
 
 def test_cast_and_transposed_weight_plane(ops):
