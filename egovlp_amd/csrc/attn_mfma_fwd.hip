@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
 
   // this thread's pieces of a group's K / V image: piece t = tid + 1024 i -> row t / 8, 16-B chunk t % 8 (att_stage_planes' layout)
   constexpr int NLD = (NKP * 8 + 1023) / 1024;
-  constexpr int EARLY = NLD <= 2 ? 2 : 0;            // planes fetched at the top of the tile: k_hi, v_hi
+  constexpr int EARLY = 0;                           // planes fetched at the top of the tile: none (the pipelined chunk loop has no registers to spare)
   u32x4_t pre[NLD][4];                               // [i][k_hi, v_hi, k_lo, v_lo]
   auto fetch = [&](const AttGroup<MODE_SPACE>& gr, auto P0, auto P1) {   // planes [P0, P1); branch-free (clamped rows)
 #pragma unroll
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
   using C0 = std::integral_constant<int, 0>;
   using CE = std::integral_constant<int, EARLY>;
   using C4 = std::integral_constant<int, 4>;
-  using CM = std::integral_constant<int, NLD <= 2 ? 3 : EARLY>;      // planes [EARLY, CM) (k_lo) are fetched behind the last Q.K^T of the tile,
-                                                                     // [CM, 4) (v_lo) behind its last P.V: the registers are free by then
+  using CM = std::integral_constant<int, NLD <= 2 ? 2 : EARLY>;      // planes [EARLY, CM) (k_hi, v_hi) are fetched behind the last Q.K^T of the tile,
+                                                                     // [CM, 4) (k_lo, v_lo) behind its last P.V: the registers are free by then
   auto commit = [&]() {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -333,20 +333,39 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         o[df] = att_mma<3, F16>(vh, vl, ph, pl, o[df] * alpha);
       }
     };
+    // Software-pipelined over the chunks: the Q.K^T MFMAs of chunk c + 1 are issued BEFORE the softmax of chunk c, so that the long
+    // VALU chain (max, exp, sum, fp16 split: ~130 instructions per chunk against 24 MFMAs -- the kernel is VALU-issue-bound, rocprofv3:
+    // VALU active 49 %, MFMA busy 20 % of the launch) has matrix work of its own wave to hide behind instead of leaving that to the
+    // other waves of the SIMD alone.  Two score sets, the chunk loop unrolled by two (the chunk counts here -- 7, 9 -- are odd).
+    // (The 257-key instance -- two tile bodies, 48 registers of K / V pieces at the end -- keeps the plain loop: pipelined it spills.)
+    constexpr int NC = NKF / 2;
+    f32x4_t sa[2], sb[2];
+    if constexpr (NKF <= 16) {
+      static_assert(NKF > 16 || NC % 2 == 1, "the two-chunk software pipeline below ends on an odd chunk count");
+      scores(0, sa);
 #pragma unroll 1
-    for (int c = 0; c < NKF / 2 - 1; ++c) {
-      f32x4_t s[2];
-      scores(c, s);
-      accumulate(c, s);
+      for (int c = 0; c + 2 < NC; c += 2) {
+        scores(c + 1, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(c, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        scores(c + 2, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        accumulate(c + 1, sb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll 1
+      for (int c = 0; c < NC - 1; ++c) {
+        scores(c, sb);
+        accumulate(c, sb);
+      }
+      scores(NC - 1, sa);
     }
-    {
-      f32x4_t s[2];
-      scores(NKF / 2 - 1, s);
-      asm volatile("" ::: "memory");
-      mid();
-      asm volatile("" ::: "memory");
-      accumulate(NKF / 2 - 1, s);
-    }
+    asm volatile("" ::: "memory");
+    mid();
+    asm volatile("" ::: "memory");
+    accumulate(NC - 1, sa);
     asm volatile("" ::: "memory");
     post();
     asm volatile("" ::: "memory");
