@@ -291,21 +291,43 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
     f32x4_t o[4];
 #pragma unroll
     for (int df = 0; df < 4; ++df) o[df] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // The kernel is VALU-issue-bound (~130 VALU instructions per chunk against 24 MFMAs; rocprofv3: VALU active 49 %, MFMA busy 20 %
+    // of the launch), so the chunk body is written for instruction count:
+    //   * the lane part of every LDS fragment address is resolved ONCE per tile (two column-fragment bases, four row-fragment bases);
+    //     a chunk adds its own 4 KiB (32 rows) and everything else -- second fragment, k-step, lo plane -- is an immediate offset
+    //     (att_frag_cols / att_frag_rows re-derive row, chunk and swizzle per call: 24 adds + 12 shifts / ors per chunk);
+    //   * the running maximum lives in the exp2 domain: scores are scaled by 64^-0.5 log2(e) in the one FMA that adds the key bias and
+    //     every exponential is a bare v_exp_f32 (exp() costs a multiply in front of it); lse and the CLS partial convert back;
+    //   * F16: the probabilities (in [0, 1]: nothing to overflow) are split with v_cvt_pkrtz_f16_f32, two values per instruction
+    //     (hi truncated instead of rounded: the lo plane carries the difference either way).
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    constexpr int LO = 2 * PLANE;                    // k_lo - k_hi == v_lo - v_hi
+    const int r15 = lane & 15;
+    const unsigned kc[2] = {(unsigned)(r15 * ATT_ROW_BYTES + ((((lane >> 4)) ^ (r15 & 7)) << 4)),
+                            (unsigned)(r15 * ATT_ROW_BYTES + ((((lane >> 4) + 4) ^ (r15 & 7)) << 4))};
+    unsigned vo[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) vo[df] = (unsigned)att_off(4 * gq + (r15 >> 2), df * 16 + ((r15 & 3) << 2));
     auto scores = [&](const int c, f32x4_t (&s)[2]) {
+      const char* kp0 = k_hi + (c * 4096 + kc[0]);
+      const char* kp1 = k_hi + (c * 4096 + kc[1]);
+      const float* kbp = kbias + (c * 32 + 4 * gq);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int kf = 2 * c + h;
         s[h] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8_t ah = att_frag_cols(k_hi, kf * 16, ks, lane);
-          const bf16x8_t al = att_frag_cols(k_lo, kf * 16, ks, lane);
-          s[h] = att_mma<3, F16>(ah, al, tqh[ks], tql[ks], s[h]);
-        }
-        const f32x4_t kb = *(const f32x4_t*)(kbias + kf * 16 + 4 * gq);
-        s[h] = s[h] * 0.125f + kb;                   // q *= 64^-0.5 (video_transformer.py:106), applied to the scores
+        s[h] = att_mma<3, F16>(*(const bf16x8_t*)(kp0 + h * 2048), *(const bf16x8_t*)(kp0 + h * 2048 + LO), tqh[0], tql[0], s[h]);
+        s[h] = att_mma<3, F16>(*(const bf16x8_t*)(kp1 + h * 2048), *(const bf16x8_t*)(kp1 + h * 2048 + LO), tqh[1], tql[1], s[h]);
+        const f32x4_t kb = *(const f32x4_t*)(kbp + h * 16);
+        s[h] = s[h] * (0.125f * LOG2E) + kb;         // q *= 64^-0.5 (video_transformer.py:106), applied to the scores; exp2 domain
       }
       if (c == 0 && is_cls && gr.f > 0 && gq == 0) s[0][0] = -1e30f;   // CLS key x CLS query: group 0 only
+    };
+    auto frag_rows2 = [&](const char* p) -> bf16x8_t {     // att_frag_rows with the address resolved: rows 4g .. 4g + 3 and the same + 16
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      const s16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+      const s16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * ATT_ROW_BYTES));
+      const s16x8_t z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+      return __builtin_bit_cast(bf16x8_t, z);
     };
     auto accumulate = [&](const int c, const f32x4_t (&s)[2]) {
       float cm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
@@ -313,23 +335,42 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
       cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
       cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
       const float mn = fmaxf(m, cm);
-      const float alpha = __expf(m - mn);            // first chunk: exp(-3e38 - mn) = 0 and l, o are 0 anyway
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);      // first chunk: 2^(-3e38 - mn) = 0 and l, o are 0 anyway
       m = mn;
       float pv[8];
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pv[r] = __expf(s[0][r] - mn);
-        pv[4 + r] = __expf(s[1][r] - mn);
+        pv[r] = __builtin_amdgcn_exp2f(s[0][r] - mn);
+        pv[4 + r] = __builtin_amdgcn_exp2f(s[1][r] - mn);
         ps += pv[r] + pv[4 + r];
       }
       l = l * alpha + ps;
       bf16x8_t ph, pl;
-      att_split8<F16>(pv, ph, pl);
+      if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(2))) __fp16 h2_t;
+        u32x4_t hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const h2_t hp = __builtin_amdgcn_cvt_pkrtz(pv[2 * e], pv[2 * e + 1]);
+          hh[e] = __builtin_bit_cast(uint32_t, hp);
+          ll[e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(pv[2 * e] - (float)hp[0], pv[2 * e + 1] - (float)hp[1]));
+        }
+        ph = __builtin_bit_cast(bf16x8_t, hh);
+        pl = __builtin_bit_cast(bf16x8_t, ll);
+      } else {
+        att_split8<false>(pv, ph, pl);
+      }
+      const char* vbase = v_hi + c * 4096;
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
+#if defined(EGV_NO_TR_READ)
         const bf16x8_t vh = att_frag_rows(v_hi, 32 * c, df * 16, lane);
         const bf16x8_t vl = att_frag_rows(v_lo, 32 * c, df * 16, lane);
+#else
+        const bf16x8_t vh = frag_rows2(vbase + vo[df]);
+        const bf16x8_t vl = frag_rows2(vbase + vo[df] + LO);
+#endif
         o[df] = att_mma<3, F16>(vh, vl, ph, pl, o[df] * alpha);
       }
     };
@@ -377,7 +418,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
 #pragma unroll
       for (int df = 0; df < 4; ++df) *(f32x4_t*)(w + df * 16 + 4 * gq) = o[df];
       if (gq == 0) {
-        w[64] = m;
+        w[64] = m * LN2;                             // egv_attn_cls_combine merges the partials in natural units
         w[65] = l;
       }
     } else if (qi < g.nq) {
@@ -393,7 +434,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         egv_store<EGV_NT_SPACE_ATTN>(oh + d, (u32x2_t){h0, h1});
         if (ol) egv_store<EGV_NT_SPACE_ATTN>(ol + d, (u32x2_t){l0, l1});
       }
-      if (gq == 0 && lse) lse[((long)gr.b * g.H + gr.h) * g.S + (qtok - gr.tok0)] = m + __logf(l);
+      if (gq == 0 && lse) lse[((long)gr.b * g.H + gr.h) * g.S + (qtok - gr.tok0)] = (m + __log2f(l)) * LN2;
     }
   };
 
