@@ -94,9 +94,9 @@ __device__ __forceinline__ void att_split8(const float* v, bf16x8_t& hi, bf16x8_
   if constexpr (F16) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const _Float16 h0 = (_Float16)v[2 * e], h1 = (_Float16)v[2 * e + 1];
-      h[e] = f16x2_pack(h0, h1);
-      l[e] = f16x2_pack((_Float16)(v[2 * e] - (float)h0), (_Float16)(v[2 * e + 1] - (float)h1));
+      const f16pk_h2_t hp = __builtin_convertvector(((f16pk_f2_t){v[2 * e], v[2 * e + 1]}), f16pk_h2_t);
+      h[e] = __builtin_bit_cast(uint32_t, hp);
+      l[e] = f16_pk(v[2 * e] - (float)hp[0], v[2 * e + 1] - (float)hp[1]);
     }
     hi = __builtin_bit_cast(bf16x8_t, h);
     lo = __builtin_bit_cast(bf16x8_t, l);
@@ -187,16 +187,15 @@ enum { MODE_SPACE = 0, MODE_TEXT = 2 };
 //   3  hi = fp16(value), nothing else (the second plane does not exist): one-product proj, fp16 backward
 enum { ATT_OUT_SPLIT = 0, ATT_OUT_BF16_F16 = 1, ATT_OUT_F16X2 = 2, ATT_OUT_F16 = 3, ATT_GRAD_F16 = 4 };
 __device__ __forceinline__ void att_out2(float a, float b, int fmt, uint32_t& hi, uint32_t& lo) {
-  if (fmt == ATT_OUT_F16X2) {
-    _Float16 a1, a2, b1, b2;
-    f16x2_a(a, a1, a2);
-    f16x2_a(b, b1, b2);
-    hi = f16x2_pack(a1, b1);
-    lo = f16x2_pack(a2, b2);
+  if (fmt == ATT_OUT_F16X2) {       // f16x2_a on the pair, packed conversions
+    const float x0 = f16x2_clamp(a), x1 = f16x2_clamp(b);
+    const f16pk_h2_t h = __builtin_convertvector(((f16pk_f2_t){x0 - x0 * F16X2_E, x1 - x1 * F16X2_E}), f16pk_h2_t);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = f16_pk(x0 - (float)h[0], x1 - (float)h[1]);
     return;
   }
   if (fmt == ATT_OUT_F16) {
-    hi = lo = f16x2_pack((_Float16)f16x2_clamp(a), (_Float16)f16x2_clamp(b));
+    hi = lo = f16_pk(f16x2_clamp(a), f16x2_clamp(b));
     return;
   }
   if (fmt == ATT_GRAD_F16) {       // a scaled gradient of the fp16 backward: ONE plane, NOT saturating (overflow -> inf -> skipped step)
@@ -204,7 +203,7 @@ __device__ __forceinline__ void att_out2(float a, float b, int fmt, uint32_t& hi
     return;
   }
   split_bf16x2(a, b, hi, lo);
-  if (fmt) lo = f16x2_pack((_Float16)f16x2_clamp(a), (_Float16)f16x2_clamp(b));
+  if (fmt) lo = f16_pk(f16x2_clamp(a), f16x2_clamp(b));
 }
 // the forward output O as the backward reads it back (delta = rowsum(dO o O)): one 32-bit word of the first plane (and of the second,
 // fmt 0 only) -> two fp32 values

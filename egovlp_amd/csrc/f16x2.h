@@ -39,20 +39,28 @@ __device__ __forceinline__ void f16x2_b(float x, _Float16& b1, _Float16& b2) {
 __device__ __forceinline__ uint32_t f16x2_pack(_Float16 lo, _Float16 hi) {
   return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
 }
+// two fp32 -> one word of two fp16 (round to nearest even, overflow -> inf: what two scalar casts give, bit for bit) as ONE instruction:
+// a <2 x float> -> <2 x half> truncation selects gfx950's v_cvt_pk_f16_f32, where two scalar casts and a pack cost v_cvt_f16_f32 +
+// v_cvt_f16_f32_sdwa + v_or_b32.  Every fp16 plane writer goes through here (GEMM / LayerNorm / attention epilogues are VALU-bound or
+// close to it).
+typedef __attribute__((ext_vector_type(2))) float f16pk_f2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16pk_h2_t;
+__device__ __forceinline__ uint32_t f16_pk(float a, float b) {
+  const f16pk_f2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16pk_h2_t));
+}
 
 // eight consecutive values -> the two 16-byte plane pieces (ROLE 0: first operand, 1: second operand) [+ the bf16 piece]
 template <int ROLE>
 __device__ __forceinline__ void f16x2_encode8(const float (&v)[8], u32x4_t& p1, u32x4_t& p2) {
-  _Float16 h1[8], h2[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    if (ROLE == 0) f16x2_a(v[e], h1[e], h2[e]);
-    else f16x2_b(v[e], h1[e], h2[e]);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    p1[e] = f16x2_pack(h1[2 * e], h1[2 * e + 1]);
-    p2[e] = f16x2_pack(h2[2 * e], h2[2 * e + 1]);
+  for (int e = 0; e < 4; ++e) {      // f16x2_a / f16x2_b on a pair of values, packed conversions
+    const float x0 = f16x2_clamp(v[2 * e]), x1 = f16x2_clamp(v[2 * e + 1]);
+    const f16pk_f2_t t = ROLE == 0 ? (f16pk_f2_t){x0 - x0 * F16X2_E, x1 - x1 * F16X2_E} : (f16pk_f2_t){x0, x1};
+    const f16pk_h2_t h = __builtin_convertvector(t, f16pk_h2_t);
+    p1[e] = __builtin_bit_cast(uint32_t, h);
+    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+    p2[e] = ROLE == 0 ? f16_pk(r0, r1) : f16_pk((float)h[0] + r0 * F16X2_INV_E, (float)h[1] + r1 * F16X2_INV_E);
   }
 }
 // eight consecutive values -> ONE 16-byte piece of plain fp16(value) (saturating): the operand of a single-fp16-product GEMM
@@ -60,7 +68,7 @@ __device__ __forceinline__ void f16x2_encode8(const float (&v)[8], u32x4_t& p1, 
 __device__ __forceinline__ u32x4_t f16_piece8(const float (&v)[8]) {
   u32x4_t p;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) p[e] = f16x2_pack((_Float16)f16x2_clamp(v[2 * e]), (_Float16)f16x2_clamp(v[2 * e + 1]));
+  for (int e = 0; e < 4; ++e) p[e] = f16_pk(f16x2_clamp(v[2 * e]), f16x2_clamp(v[2 * e + 1]));
   return p;
 }
 // The same WITHOUT saturation: gradient planes of the fp16 backward.  A scaled gradient beyond fp16's range must become inf (and then
@@ -69,7 +77,7 @@ __device__ __forceinline__ u32x4_t f16_piece8(const float (&v)[8]) {
 __device__ __forceinline__ u32x4_t f16_grad_piece8(const float (&v)[8]) {
   u32x4_t p;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) p[e] = f16x2_pack((_Float16)v[2 * e], (_Float16)v[2 * e + 1]);
+  for (int e = 0; e < 4; ++e) p[e] = f16_pk(v[2 * e], v[2 * e + 1]);
   return p;
 }
 // eight consecutive values -> an fp16 SPLIT (hi = fp16(v), lo = fp16(v - hi); saturating): the qkv planes of the fp16 attention -- the
@@ -78,12 +86,12 @@ __device__ __forceinline__ void f16_split8(const float (&v)[8], u32x4_t& p1, u32
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float a = f16x2_clamp(v[2 * e]), b = f16x2_clamp(v[2 * e + 1]);
-    const _Float16 h0 = (_Float16)a, h1 = (_Float16)b;
-    p1[e] = f16x2_pack(h0, h1);
-    p2[e] = f16x2_pack((_Float16)(a - (float)h0), (_Float16)(b - (float)h1));
+    const f16pk_h2_t h = __builtin_convertvector(((f16pk_f2_t){a, b}), f16pk_h2_t);
+    p1[e] = __builtin_bit_cast(uint32_t, h);
+    p2[e] = f16_pk(a - (float)h[0], b - (float)h[1]);
   }
 }
-__device__ __forceinline__ uint32_t f16_grad_pack2(float a, float b) { return f16x2_pack((_Float16)a, (_Float16)b); }
+__device__ __forceinline__ uint32_t f16_grad_pack2(float a, float b) { return f16_pk(a, b); }
 // two fp16 values of one 32-bit word -> fp32
 __device__ __forceinline__ void f16x2_unpack(uint32_t w, float& a, float& b) {
   a = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));

@@ -73,7 +73,7 @@ __device__ __forceinline__ void split_transpose_tile(
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (r + e < rows) ? f16x2_clamp(tile[tc + e][cc + tr]) : 0.f;
-        *(u32x2_t*)(t16 + (long)c * ldt + r) = (u32x2_t){f16x2_pack((_Float16)v[0], (_Float16)v[1]), f16x2_pack((_Float16)v[2], (_Float16)v[3])};
+        *(u32x2_t*)(t16 + (long)c * ldt + r) = (u32x2_t){f16_pk(v[0], v[1]), f16_pk(v[2], v[3])};
       }
     }
   }
