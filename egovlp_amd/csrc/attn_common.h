@@ -86,6 +86,18 @@ __device__ __forceinline__ bf16x8_t att_frag_rows(const char* plane, int r0, int
 #endif
 }
 
+// The same with the lane's address already resolved (p = plane + att_off(r0 + 4g + (p >> 2), col0 + 4 (p & 3))): the kernels whose chunk
+// loops are VALU-issue-bound resolve the lane part once per tile and add the chunk's rows as one offset.
+#if !defined(EGV_NO_TR_READ)
+__device__ __forceinline__ bf16x8_t att_frag_rows_at(const char* p) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  const s16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * ATT_ROW_BYTES));
+  const s16x8_t z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+  return __builtin_bit_cast(bf16x8_t, z);
+}
+#endif
+
 // 8 fp32 -> split bf16x8 pair (four v_cvt_pk_bf16_f32 per plane); F16: the same split in fp16 (hi = fp16(v), lo = fp16(v - hi), NOT
 // saturating: the values are probabilities in [0, 1] or scaled gradients, whose overflow must surface as inf) in the same registers
 template <bool F16 = false>

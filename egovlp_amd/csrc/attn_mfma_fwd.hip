@@ -322,13 +322,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
       }
       if (c == 0 && is_cls && gr.f > 0 && gq == 0) s[0][0] = -1e30f;   // CLS key x CLS query: group 0 only
     };
-    auto frag_rows2 = [&](const char* p) -> bf16x8_t {     // att_frag_rows with the address resolved: rows 4g .. 4g + 3 and the same + 16
-      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-      const s16x4_t x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
-      const s16x4_t y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * ATT_ROW_BYTES));
-      const s16x8_t z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
-      return __builtin_bit_cast(bf16x8_t, z);
-    };
     auto accumulate = [&](const int c, const f32x4_t (&s)[2]) {
       float cm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
                        fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
@@ -368,8 +361,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream3_kernel(const AttGeom g,
         const bf16x8_t vh = att_frag_rows(v_hi, 32 * c, df * 16, lane);
         const bf16x8_t vl = att_frag_rows(v_lo, 32 * c, df * 16, lane);
 #else
-        const bf16x8_t vh = frag_rows2(vbase + vo[df]);
-        const bf16x8_t vl = frag_rows2(vbase + vo[df] + LO);
+        const bf16x8_t vh = att_frag_rows_at(vbase + vo[df]);
+        const bf16x8_t vl = att_frag_rows_at(vbase + vo[df] + LO);
 #endif
         o[df] = att_mma<3, F16>(vh, vl, ph, pl, o[df] * alpha);
       }
