@@ -173,7 +173,7 @@ def test_cast_and_transposed_weight_plane(ops):
     assert torch.equal(t16.hi[:, :2304].cpu().view(torch.int16), w.detach().cpu().t().contiguous().to(torch.float16).view(torch.int16))
 
 
-@pytest.mark.parametrize("B,T,n,H", [(2, 4, 196, 12), (2, 3, 49, 4)])
+@pytest.mark.parametrize("B,T,n,H", [(2, 4, 196, 12), (2, 3, 49, 4), (7, 4, 196, 12)])     # the last: 336 groups on 256 persistent workgroups
 @pytest.mark.parametrize("mode", [0, 1])
 def test_attention_fp16_output_formats_and_fp16_gradient_planes(ops, B, T, n, H, mode):
     """The forward's fp16 output formats ('f16x2': a1 / a2 planes; 'f16': one plane) hold the same O as the split-bf16 planes, the backward

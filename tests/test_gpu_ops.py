@@ -293,7 +293,8 @@ def _ref_divided(qkv, B, T, n, H, mode):
 @pytest.mark.parametrize("passes", [3, 1])
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("B,T,n,H", [(2, 3, 4, 2), (1, 4, 196, 2), (2, 2, 37, 1), (2, 4, 16, 4), (1, 6, 20, 4), (1, 16, 12, 4),
-                                     (2, 9, 7, 8), (1, 16, 5, 2), (1, 8, 9, 3)])
+                                     (2, 9, 7, 8), (1, 16, 5, 2), (1, 8, 9, 3),
+                                     (7, 4, 196, 12)])     # 336 space groups on the 256 persistent workgroups of the forward: 80 of them walk two
 def test_divided_attention_fwd_bwd(ops, passes, mode, B, T, n, H):
     g = torch.Generator().manual_seed(100 * mode + n)
     S = 1 + T * n
